@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the dense flow+depth hot path on synthetic frame pairs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vga|720p|1080p]
+
+One *step* = one pass of the hot path over one frame pair per GPU, frames already resident in HBM:
+dfe_flow_depth_pair_f32 = SSD cost-volume build (materialised once, reference layout) -> fused
+arg-min / centre tie-break / extractOutput / decode tail -> flow->depth.  N > 1 is launched by
+torch.distributed.run, one rank per GPU; every rank processes its own pair (pairs are independent:
+weak scaling, no data-path collective; RCCL is used for the barrier and the max-over-ranks only).
+
+The JSON line carries `roofline` for the dominant kernel (the cost-volume build: algorithmic bytes
+B_alg = 2*C*H*W*4 + Ho*Wo*hWin*wWin*4 per launch over its HIP-event time, measured live on the
+kernel's stream inside the timed region) and `cpu_baseline` (the CPU oracle, i.e. a port of the
+reference's loop nest, timed on this host's cores on a bounded band of output rows, rank 0 / N=1).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (H, W, C, k, hWin, wWin)  -- 7x7 patch, +-16 search (33x33 window), fp32
+    "vga": (480, 640, 3, 7, 33, 33),
+    "720p": (720, 1280, 3, 7, 33, 33),
+    "1080p": (1080, 1920, 3, 7, 33, 33),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(H, W, Cc, k, hWin, wWin):
+    Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
+    return 2 * Cc * H * W * 4 + Ho * Wo * hWin * wWin * 4
+
+
+def cpu_baseline(f0, f1, k, hWin, wWin, cx, cy, budget_s=12.0):
+    """The oracle (a port of the reference's CPU loop nest: 5-deep SSD loop with OpenMP over output
+    rows + min/tie-break + extractOutput + decode + depth), timed on a band of output rows sized
+    for ~budget_s of work.  Mpix/s is scaled by the band's share of the pair."""
+    import numpy as np
+    from tests import oracle as orc
+    from tests import refpath as rp
+
+    Cc, H, W = f0.shape
+    Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
+    halo = k - 1 + hWin - 1
+
+    def run(rows):
+        r0 = (Ho - rows) // 2
+        t = time.perf_counter()
+        band = orc.ssd_cost_volume(f0[:, r0 : r0 + rows + halo], f1[:, r0 : r0 + rows + halo], k, k, hWin, wWin)
+        vol = band.reshape(rows, Wo, hWin * wWin)
+        idx, _ = orc.argbest_center(vol, rp.middle_index(hWin, wWin), False)
+        y, x = orc.x2yx(idx, hWin, wWin)
+        sc, im = np.zeros((rows, Wo), np.float32), np.zeros((rows, Wo), np.int64)
+        orc.extract_output(vol, 0.21, im, sc)
+        flow = np.stack([y, x]).astype(np.float32)
+        orc.flow_to_depth_cartesian(flow, cx, cy)
+        return time.perf_counter() - t
+
+    t2 = run(2)
+    rows = int(max(2, min(Ho, round(2 * budget_s / max(t2, 1e-6)))))
+    t = run(rows)
+    mpix = (H * W * rows / Ho) / t / 1e6
+    return {
+        "value": round(mpix, 4),
+        "unit": "Mpixels/s",
+        "cores": orc.max_threads(),
+        "kind": "port",
+        "sample": "%d of %d output rows of one %dx%d pair (cost volume + arg-min/extract/decode/depth), %.1f s" % (rows, Ho, W, H, t),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import depth_estimation_amd as d
+    from tests import refpath as rp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libdfe has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    H, W, Cc, k, hWin, wWin = WORKLOADS[args.workload]
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=rank, max_flow=12)  # one seeded pair per rank
+    t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
+    flow = torch.empty((2, H, W), device=dev)
+    scores = torch.empty((H, W), device=dev)
+    depth = torch.empty((H, W), device=dev)
+    dconf = torch.empty((H, W), device=dev)
+    ctx = d.get_ctx(local_rank)
+    lib = d.lib()
+
+    def step():
+        ctx.check(
+            lib.dfe_flow_depth_pair_f32(
+                ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, hWin, wWin, cx, cy, 0.21,
+                flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), dconf.data_ptr(),
+            )
+        )
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel = ctx.last_kernel()
+    ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    cv_ms, cv_n = C.c_double(), C.c_int()
+    ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(cv_ms), C.byref(cv_n)))
+    ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin)
+        kern_s = cv_ms.value / 1e3 / max(cv_n.value, 1)
+        achieved = balg / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md)
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s dense flow+depth, %dx%d pair, 7x7 patch +-16 search" % (W, H),
+            "value": round(world * args.steps * H * W / elapsed / 1e6, 3),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d C=%d single-scale dense SSD cost volume (7x7 patch, %dx%d window = +-16) "
+                "+ arg-min/extractOutput/decode + flow->depth, one pair per GPU per step" % (W, H, Cc, hWin, wWin),
+                "pairs_per_step": world,
+                "sharding": "pair-per-gpu" if world > 1 else "single",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": kernel,
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": balg,
+                "kernel_ms": round(kern_s * 1e3, 5),
+                "launches_timed": cv_n.value,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(f0, f1, k, hWin, wWin, cx, cy)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+"""depth_estimation_amd -- host-side mirror of the reference's operator interface for the dense
+patch-correlation flow->depth hot path, over the C ABI of libdfe.so (include/dfe.h).
+
+The reference's host language is Lua/Torch7 (absent from the build image), so this mirror is
+Python: same names, argument order and error behaviour as the Lua modules / functions it stands
+in for (cited per symbol), with torch CUDA tensors playing the role of Torch7 tensors.  torch is
+plumbing only (device memory, streams); every computation goes through libdfe.so, and there is
+no CPU fallback -- a missing library or device raises.
+
+    nn.SpatialMatching / nn.SpatialRadialMatching     (nnx modules used by the reference)
+    extractoutput.extractOutput / extractOutputMarginalized   (extract_output.cpp)
+    x2yx, yx2x, yx2xMulti, x2yxMulti, x2yxMulti2, getMiddleIndex, getOutputConfidences,
+    processOutput                                       (opticalflow_model*.lua)
+    unfold, compute_cartesian_groundtruth_cross_correlation  (radial/radial_opticalflow_groundtruth.lua)
+"""
+from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
+from .context import Context, get_ctx  # noqa: F401
+from . import nn  # noqa: F401
+from . import extractoutput  # noqa: F401
+from .opticalflow_model import (  # noqa: F401
+    x2yx,
+    yx2x,
+    centered2onebased,
+    onebased2centered,
+    yx2xMulti,
+    x2yxMulti,
+    x2yxMulti2,
+    x2yxMultiNumber,
+    getMiddleIndex,
+    getOutputConfidences,
+    processOutput,
+)
+from .groundtruth import (  # noqa: F401
+    unfold,
+    cross_correlation_pad_output,
+    compute_cartesian_groundtruth_cross_correlation,
+)

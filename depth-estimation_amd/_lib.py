@@ -1,0 +1,93 @@
+"""ctypes binding of libdfe.so (C ABI: include/dfe.h).  No CPU fallback: if the shared library
+is missing or no gfx950 device is present, every entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdfe.so")
+
+DFE_OK = 0
+DFE_MAX_RATIOS = 10
+
+c_f32p = C.POINTER(C.c_float)
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol include/dfe.h declares
+PROTOTYPES = {
+    "dfe_version": (C.c_int, []),
+    "dfe_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dfe_ctx_destroy": (None, [C.c_void_p]),
+    "dfe_last_error": (C.c_char_p, [C.c_void_p]),
+    "dfe_ctx_synchronize": (C.c_int, [C.c_void_p]),
+    "dfe_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "dfe_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dfe_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),
+    "dfe_ssd_cost_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "dfe_spatial_matching_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "dfe_radial_matching_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "dfe_argbest_center": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_extract_output": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p]),
+    "dfe_extract_output_marginalized": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p],
+    ),
+    "dfe_x2yx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_x2yx_multi": (
+        C.c_int,
+        [C.c_void_p, C.c_int, C.c_int, c_i32p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int],
+    ),
+    "dfe_yx2x_multi": (C.c_int64, [C.c_int, C.c_int, c_i32p, C.c_int, C.c_double, C.c_double]),
+    "dfe_x2yx_multi_number": (C.c_int, [C.c_int, C.c_int, c_i32p, C.c_int, C.c_int64, c_i64p, c_i64p]),
+    "dfe_multi_nclasses": (C.c_int64, [C.c_int, C.c_int, c_i32p, C.c_int]),
+    "dfe_ssd_flow_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_double] + [C.c_void_p] * 6,
+    ),
+    "dfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "dfe_flow_tail": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 4,
+    ),
+    "dfe_flow_to_depth_cartesian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_flow_depth_pair_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_double] + [C.c_void_p] * 4,
+    ),
+}
+
+_lib = None
+
+
+class DfeError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libdfe error %d: %s" % (code, text))
+        self.code = code
+
+
+def lib():
+    """Load libdfe.so (built in-tree by depth-estimation_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdfe.so not found at %s -- build it with `make -C depth-estimation_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH
+            )
+        l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def ratios_array(ratios):
+    r = list(int(v) for v in ratios)
+    return (C.c_int * len(r))(*r), len(r)

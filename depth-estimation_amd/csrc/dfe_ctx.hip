@@ -1,0 +1,148 @@
+// dfe_ctx.hip -- context, error text, device memory helpers of the C ABI (include/dfe.h).
+#include "dfe_internal.h"
+
+static thread_local char g_create_err[512] = "";
+
+int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...) {
+    char *dst = ctx ? ctx->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        // grow-only; a free/realloc here is a stream-ordered hazard only if a previous op still
+        // uses the arena, so drain the stream first (rare: sizes settle after the first call).
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) DFE_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->scratch, bytes);
+        if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        ctx->scratch_bytes = bytes;
+    }
+    *out = ctx->scratch;
+    return DFE_OK;
+}
+
+extern "C" {
+
+int dfe_version(void) { return 100; }
+
+int dfe_ctx_create(int device, void *stream, dfe_ctx **out) {
+    if (!out) return dfe_fail(nullptr, DFE_E_ARG, "dfe_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return dfe_fail(nullptr, DFE_E_HIP, "dfe_ctx_create: no HIP device (%s); libdfe has no CPU fallback",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return dfe_fail(nullptr, DFE_E_ARG, "dfe_ctx_create: device %d of %d", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return dfe_fail(nullptr, DFE_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return dfe_fail(nullptr, DFE_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return dfe_fail(nullptr, DFE_E_UNSUPPORTED, "device %d is %s; libdfe ships gfx950 code only", device, prop.gcnArchName);
+    dfe_ctx *ctx = new dfe_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return dfe_fail(nullptr, DFE_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        ctx->own_stream = true;
+    }
+    e = hipMalloc((void **)&ctx->dflag, sizeof(int));
+    if (e != hipSuccess) { dfe_ctx_destroy(ctx); return dfe_fail(nullptr, DFE_E_ALLOC, "hipMalloc flag: %s", hipGetErrorString(e)); }
+    *out = ctx;
+    return DFE_OK;
+}
+
+void dfe_ctx_destroy(dfe_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->dflag) (void)hipFree(ctx->dflag);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *dfe_last_error(const dfe_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
+
+int dfe_ctx_synchronize(dfe_ctx *ctx) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DFE_OK;
+}
+
+void *dfe_ctx_stream(dfe_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr) {
+    DFE_REQUIRE(ctx, ctx && dptr, DFE_E_ARG, "dfe_malloc: NULL argument");
+    DFE_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return DFE_OK;
+}
+
+int dfe_free(dfe_ctx *ctx, void *dptr) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    if (dptr) DFE_HIP(ctx, hipFree(dptr));
+    return DFE_OK;
+}
+
+int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    DFE_REQUIRE(ctx, ctx && (bytes == 0 || (dst && src)), DFE_E_ARG, "dfe_memcpy_h2d: NULL argument");
+    DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DFE_OK;
+}
+
+int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    DFE_REQUIRE(ctx, ctx && (bytes == 0 || (dst && src)), DFE_E_ARG, "dfe_memcpy_d2h: NULL argument");
+    DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return DFE_OK;
+}
+
+int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, mode >= 0 && mode <= 2, DFE_E_ARG, "cost-volume kernel mode %d not in 0..2", mode);
+    ctx->cv_mode = mode;
+    return DFE_OK;
+}
+
+const char *dfe_last_kernel(const dfe_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int dfe_profile_enable(dfe_ctx *ctx, int on) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    ctx->profile = on != 0;
+    return DFE_OK;
+}
+
+int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches) {
+    DFE_REQUIRE(ctx, ctx && total_ms && launches, DFE_E_ARG, "dfe_profile_read: NULL argument");
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->prof_events.size(); i += 2) {
+        float ms = 0.f;
+        DFE_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
+        sum += ms;
+        ++n;
+    }
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    ctx->prof_events.clear();
+    *total_ms = sum;
+    *launches = n;
+    return DFE_OK;
+}
+
+}  // extern "C"

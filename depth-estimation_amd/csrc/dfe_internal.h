@@ -1,0 +1,60 @@
+// dfe_internal.h -- shared by the translation units of libdfe.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/dfe.h"
+
+struct dfe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int cv_mode = 0;                  // dfe_set_cost_volume_kernel
+    const char *last_kernel = "";
+    void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)
+    size_t scratch_bytes = 0;
+    int *dflag = nullptr;             // one device int for error flags raised by kernels
+    char err[512] = {0};
+    // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)
+    bool profile = false;
+    std::vector<hipEvent_t> prof_events;   // start/stop pairs, resolved by dfe_profile_read
+};
+
+// brackets the cost-volume kernel launch with events on the ctx stream when profiling is on
+struct DfeProfScope {
+    dfe_ctx *ctx;
+    explicit DfeProfScope(dfe_ctx *c) : ctx(c) {
+        if (ctx->profile) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, ctx->stream); ctx->prof_events.push_back(e); }
+        }
+    }
+    ~DfeProfScope() {
+        if (ctx->profile && (ctx->prof_events.size() & 1)) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, ctx->stream); ctx->prof_events.push_back(e); }
+        }
+    }
+};
+
+int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...);
+int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
+
+#define DFE_HIP(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return dfe_fail((ctx), DFE_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                        \
+    } while (0)
+
+#define DFE_REQUIRE(ctx, cond, code, ...)                    \
+    do {                                                     \
+        if (!(cond)) return dfe_fail((ctx), (code), __VA_ARGS__); \
+    } while (0)
+
+#define DFE_LAUNCH_CHECK(ctx) DFE_HIP(ctx, hipGetLastError())
+
+static inline int dfe_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,99 @@
+"""Stand-ins for the nnx modules on the hot path, with Torch7's nn.Module protocol
+(updateOutput / forward, self.output)."""
+import torch
+
+from ._lib import lib
+from .context import get_ctx, ptr
+
+
+class Module:
+    def __init__(self):
+        self.output = None
+
+    def forward(self, input):
+        return self.updateOutput(input)
+
+    def __call__(self, input):
+        return self.forward(input)
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be a FloatTensor (torch.float32), got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+class SpatialMatching(Module):
+    """nn.SpatialMatching(maxh, maxw, full_output=false) -- un-vendored nnx module.
+    Reference call sites: opticalflow_model.lua:93, opticalflow_model_multiscale.lua:216,
+    radial/radial_opticalflow_groundtruth.lua:83, tests/time_matching.lua:18.
+    forward({in1 KxH1xW1, in2 Kx(H1+maxh-1)x(W1+maxw-1)}) -> H1 x W1 x maxh x maxw."""
+
+    def __init__(self, maxh, maxw, full_output=False):
+        super().__init__()
+        if full_output:
+            raise NotImplementedError("SpatialMatching: the reference only uses full_output=false")
+        self.maxh, self.maxw = int(maxh), int(maxw)
+
+    def updateOutput(self, input):
+        in1, in2 = input
+        in1, in2 = _f32c(in1, "input[1]"), _f32c(in2, "input[2]")
+        K, H1, W1 = in1.shape
+        if tuple(in2.shape) != (K, H1 + self.maxh - 1, W1 + self.maxw - 1):
+            raise ValueError(
+                "SpatialMatching: input[2] must be %s for input[1] %s and window %dx%d, got %s"
+                % ((K, H1 + self.maxh - 1, W1 + self.maxw - 1), tuple(in1.shape), self.maxh, self.maxw, tuple(in2.shape))
+            )
+        ctx = get_ctx(in1)
+        out = torch.empty((H1, W1, self.maxh, self.maxw), dtype=torch.float32, device=in1.device)
+        ctx.check(lib().dfe_spatial_matching_f32(ctx.handle, ptr(in1), ptr(in2), K, H1, W1, self.maxh, self.maxw, ptr(out)))
+        self.output = out
+        return out
+
+
+class SpatialRadialMatching(Module):
+    """nn.SpatialRadialMatching(hWin) -- un-vendored nnx module.
+    Reference call sites: radial/radial_opticalflow_network.lua:33, radial/radial_opticalflow_groundtruth.lua:152.
+    forward({in1 KxH1xW, in2 Kx(H1+hWin-1)xW}) -> H1 x W x hWin."""
+
+    def __init__(self, hWin):
+        super().__init__()
+        self.hWin = int(hWin)
+
+    def updateOutput(self, input):
+        in1, in2 = input
+        in1, in2 = _f32c(in1, "input[1]"), _f32c(in2, "input[2]")
+        K, H1, W = in1.shape
+        if tuple(in2.shape) != (K, H1 + self.hWin - 1, W):
+            raise ValueError("SpatialRadialMatching: input[2] must be %s, got %s" % ((K, H1 + self.hWin - 1, W), tuple(in2.shape)))
+        ctx = get_ctx(in1)
+        out = torch.empty((H1, W, self.hWin), dtype=torch.float32, device=in1.device)
+        ctx.check(lib().dfe_radial_matching_f32(ctx.handle, ptr(in1), ptr(in2), K, H1, W, self.hWin, ptr(out)))
+        self.output = out
+        return out
+
+
+class SSDCostVolume(Module):
+    """unfold(kh,kw) + crop + SpatialMatching(hWin,wWin) on raw frames in one op (A0+A1); the
+    reference composes it from three modules, radial/radial_opticalflow_groundtruth.lua:79-84.
+    forward({img1 CxHxW, img2 CxHxW}) -> Ho x Wo x hWin x wWin."""
+
+    def __init__(self, hWin, wWin, hKer, wKer):
+        super().__init__()
+        self.hWin, self.wWin, self.hKer, self.wKer = int(hWin), int(wWin), int(hKer), int(wKer)
+
+    def updateOutput(self, input):
+        i0, i1 = input
+        i0, i1 = _f32c(i0, "input[1]"), _f32c(i1, "input[2]")
+        if i0.shape != i1.shape or i0.dim() != 3:
+            raise ValueError("SSDCostVolume: frames must both be CxHxW, got %s and %s" % (tuple(i0.shape), tuple(i1.shape)))
+        Cc, H, W = i0.shape
+        Ho = H - self.hKer + 1 - self.hWin + 1
+        Wo = W - self.wKer + 1 - self.wWin + 1
+        ctx = get_ctx(i0)
+        out = torch.empty((max(Ho, 0), max(Wo, 0), self.hWin, self.wWin), dtype=torch.float32, device=i0.device)
+        ctx.check(
+            lib().dfe_ssd_cost_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, self.hKer, self.wKer, self.hWin, self.wWin, ptr(out))
+        )
+        self.output = out
+        return out

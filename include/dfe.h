@@ -1,0 +1,173 @@
+/*
+ * dfe.h -- C ABI of libdfe.so: the MI355X (gfx950) implementation of the dense
+ * patch-correlation flow->depth hot path of MichaelMathieu/depth-estimation.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one operator the
+ * reference reaches through Torch7's nn.Module protocol or through its two
+ * native Lua C modules; the replaced reference interface is cited as
+ * "replaces: file:line" (paths relative to the reference repository).  A
+ * LuaJIT-FFI caller binds exactly these prototypes.
+ *
+ * Conventions
+ *  - plain C types only; every tensor is a dense row-major buffer, sizes in elements;
+ *  - all tensor pointers are DEVICE pointers (hipMalloc / dfe_malloc / any allocator of the
+ *    same HIP runtime, e.g. torch).  dfe_memcpy_* stage host data for callers without one;
+ *  - the caller allocates inputs AND outputs (the reference's ops also write into
+ *    caller-allocated tensors, extract_output.cpp:63-81); the library owns only ctx scratch;
+ *  - class ids are 1-based int64 exactly as the reference's LongTensors;
+ *  - every function returns DFE_OK or a negative DFE_E_*; dfe_last_error(ctx) gives the text
+ *    (the Lua skin turns that into error(), matching CascadingAddTable.lua:111,115,123);
+ *  - work is enqueued on the ctx's HIP stream and NOT synchronised unless stated;
+ *  - a ctx is single-threaded; use one ctx per GPU / host thread;
+ *  - there is no CPU fallback: without a gfx950 device dfe_ctx_create fails with DFE_E_HIP.
+ */
+#ifndef DFE_H
+#define DFE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFE_OK 0
+#define DFE_E_ARG (-1)
+#define DFE_E_SHAPE (-2)
+#define DFE_E_ALLOC (-3)
+#define DFE_E_HIP (-4)
+#define DFE_E_UNSUPPORTED (-5)
+
+#define DFE_MAX_RATIOS 10 /* x2yxMulti2.c:1 N_MAX_RATIOS */
+
+typedef struct dfe_ctx dfe_ctx;
+
+/* ---- context, memory --------------------------------------------------- */
+int dfe_version(void);
+/* stream == NULL: the ctx creates its own non-blocking stream; otherwise the caller's hipStream_t */
+int dfe_ctx_create(int device, void *stream, dfe_ctx **out);
+void dfe_ctx_destroy(dfe_ctx *ctx);
+const char *dfe_last_error(const dfe_ctx *ctx); /* ctx may be NULL: last creation error */
+int dfe_ctx_synchronize(dfe_ctx *ctx);
+void *dfe_ctx_stream(dfe_ctx *ctx);
+int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr);
+int dfe_free(dfe_ctx *ctx, void *dptr);
+int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+/* cost-volume kernel selection: 0 = auto (default), 1 = force the reference-order kernel
+ * (bit-identical float summation order to the CPU path), 2 = force the tiled fast kernel
+ * (DFE_E_UNSUPPORTED from the op when the shape has no fast kernel) */
+int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
+/* name of the kernel the last cost-volume call launched (static string) */
+const char *dfe_last_kernel(const dfe_ctx *ctx);
+
+/* per-launch HIP-event timing of the cost-volume kernel on the ctx stream (bench.py's roofline):
+ * enable, run, then read the summed kernel time and launch count (read synchronises and resets) */
+int dfe_profile_enable(dfe_ctx *ctx, int on);
+int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
+
+/* ---- A0+A1: dense SSD cost volume from raw frames ----------------------- */
+/* replaces: unfold + SpatialPadding crop + nn.SpatialMatching(hWin,wWin,false):forward
+ *   radial/radial_opticalflow_groundtruth.lua:79-84 (= version2/groundtruth.lua:77-82),
+ *   the raw-patch (identity filter) case of opticalflow_model.lua:81-99.
+ * I0,I1 [C][H][W] f32.  out [Ho][Wo][hWin][wWin] f32,
+ *   Ho = H-kh+1-hWin+1, Wo = W-kw+1-wWin+1,
+ *   out[y][x][dy][dx] = sum_{c,i,j} (I0[c][y+oy+i][x+ox+j] - I1[c][y+dy+i][x+dx+j])^2,
+ *   oy = floor((hWin-1)/2), ox = floor((wWin-1)/2). */
+int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
+                            int kh, int kw, int hWin, int wWin, float *out);
+
+/* ---- A1: nn.SpatialMatching(maxh,maxw,false):updateOutput on feature maps -- */
+/* replaces: nnx SpatialMatching call sites opticalflow_model_multiscale.lua:216,
+ *   opticalflow_model.lua:93, version2/network.lua:30, tests/time_matching.lua:18.
+ * in1 [K][H1][W1], in2 [K][H1+maxh-1][W1+maxw-1] -> out [H1][W1][maxh][maxw]. */
+int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
+                             int W1, int maxh, int maxw, float *out);
+
+/* ---- A1r: nn.SpatialRadialMatching(hWin):updateOutput --------------------- */
+/* replaces: radial/radial_opticalflow_network.lua:33,71-72.
+ * in1 [K][H1][W], in2 [K][H1+hWin-1][W] -> out [H1][W][hWin]. */
+int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
+                            int W, int hWin, float *out);
+
+/* ---- A6: arg-min / arg-max with the centre tie-break ---------------------- */
+/* replaces: output:min(3) + centre override radial/radial_opticalflow_groundtruth.lua:88-94;
+ *   input:max(3) + override in getOutputConfidences opticalflow_model.lua:153-161.
+ * vol [P][N] -> idx [P] (1-based, first extremum wins, centre wins exact ties with the best),
+ *   best [P] (may be NULL).  middle <= 0 disables the override. */
+int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int middle, int take_max,
+                       int64_t *idx, float *best);
+
+/* ---- A7 / A8: extractoutput.* --------------------------------------------- */
+/* replaces: extractoutput.extractOutput(input, scores, threshold, imaxs)
+ *   extract_output.cpp:63-155 (Lua registration :357-366); same argument order.
+ * input [H][W][N] f32; imaxs [H][W] int64, scores [H][W] f32.  Pixels with no value
+ * above threshold are left untouched, as in the reference. */
+int dfe_extract_output(dfe_ctx *ctx, const float *input, int H, int W, int N, float *scores,
+                       double threshold, int64_t *imaxs);
+/* replaces: extractoutput.extractOutputMarginalized(input, threshold, threshold_acc, ret, retgd)
+ *   extract_output.cpp:157-255.  retgd is zeroed first (:166). */
+int dfe_extract_output_marginalized(dfe_ctx *ctx, const float *input, int H, int W, int N,
+                                    double threshold, double threshold_acc, int64_t *ret,
+                                    int64_t *retgd);
+
+/* ---- A9 / A10: class id -> displacement ----------------------------------- */
+/* replaces: x2yx + centered2onebased opticalflow_model.lua:16-34,209-213;
+ *   radial/radial_opticalflow_groundtruth.lua:97-100. */
+int dfe_x2yx(dfe_ctx *ctx, const int64_t *idx, int64_t P, int maxh, int maxw, int64_t *y,
+             int64_t *x);
+/* replaces: x2yxMulti2(geometry, LongTensor) opticalflow_model_multiscale.lua:72-81 (body
+ *   x2yxMulti2.c:1-95).  compat_c = 0: the Lua scalar semantics x2yxMultiNumber :83-132 that the
+ *   reference's round-trip test pins (tests/test_multiscale.lua:57-80); compat_c = 1: the shipped C
+ *   body bug for bug (ids it never matches leave y/x untouched). ratios are the Lua table values
+ *   ratios[1..n]. Returns DFE_E_ARG if an id is outside 1..nclasses (compat_c = 0 only; the device
+ *   flag is read back, so this call synchronises). */
+int dfe_x2yx_multi(dfe_ctx *ctx, int maxh, int maxw, const int *ratios, int nratios,
+                   const int64_t *idx, int64_t P, int64_t *y, int64_t *x, int compat_c);
+/* host-side scalar codec (no device work): yx2xMulti :10-52, x2yxMultiNumber :83-132 */
+int64_t dfe_yx2x_multi(int maxh, int maxw, const int *ratios, int nratios, double y, double x);
+int dfe_x2yx_multi_number(int maxh, int maxw, const int *ratios, int nratios, int64_t id,
+                          int64_t *y, int64_t *x);
+int64_t dfe_multi_nclasses(int maxh, int maxw, const int *ratios, int nratios);
+
+/* ---- dense single-scale flow in one call (A0+A1+A6+A7+A9; the volume lives only in ctx scratch) --- */
+/* replaces: compute_cartesian_groundtruth_cross_correlation radial/radial_opticalflow_groundtruth.lua:66-112
+ *   up to (not including) the pad-back :108.
+ * Outputs, all [Ho][Wo]: idx = arg-min class with centre tie-break (:88-94), flow_y/flow_x
+ *   decoded displacement (:97-100), scores/imaxs = extractOutput(cost, thr) (:105; pixels with
+ *   nothing above thr keep the caller's values), best = min cost.  Any output may be NULL. */
+int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh,
+                     int kw, int hWin, int wWin, double extract_threshold, int64_t *idx,
+                     float *best, float *flow_y, float *flow_x, float *scores, int64_t *imaxs);
+
+/* ---- A6+A7+A9 in one pass over an existing volume (rows x Wo pixels, hWin*wWin cells) ------- */
+/* replaces: radial/radial_opticalflow_groundtruth.lua:87-105 (min(3), centre tie-break, decode,
+ *   extractOutput) and the pad-back of :108 for the float planes: fy/fx (and scores when
+ *   scores_padded != 0) are written at [(row_off+y+pad_t)*pitch + x+pad_l]; idx/best/imaxs (and
+ *   scores when scores_padded == 0) at [(row_off+y)*Wo + x].  Any output may be NULL; scores and
+ *   imaxs of pixels with nothing above the threshold are left untouched. */
+int dfe_flow_tail(dfe_ctx *ctx, const float *vol, int rows, int Wo, int hWin, int wWin,
+                  double threshold, int row_off, int64_t *idx, float *best, float *fy, float *fx,
+                  float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded);
+
+/* ---- A12: flow -> depth ----------------------------------------------------------------- */
+/* replaces: the inline-C `radial(geometry, flow, mh, mw)` of test_opticalflow.lua:143-216.
+ * flow [2][H][W] (plane 0 = y, plane 1 = x); (cx,cy) = focus of expansion = (mw,mh); infty = W/2.
+ * depth = min(|p-c|/|flow|, infty) where |flow| >= 0.2 else infty; conf as shipped uses
+ * px*dx + dy*dy (:181); fix_dot != 0 selects px*dx + py*dy. */
+int dfe_flow_to_depth_cartesian(dfe_ctx *ctx, const float *flow, int H, int W, float cx, float cy,
+                                int fix_dot, float *depth, float *conf);
+
+/* ---- the one-call single-scale pipeline: frames -> flow + confidence + depth ------------- */
+/* replaces: the per-frame body of the dense drivers (depth_estimation_opticalflow.lua:113-116 +
+ *   test_opticalflow.lua:349-355 flow -> depth) for the single-scale raw-patch matcher.
+ * flow [2][H][W], scores [H][W], depth [H][W], depth_conf [H][W]: full-frame, zero outside the
+ * centre-pasted Ho x Wo region (opticalflow_model.lua:227-249).  The cost volume is materialised
+ * in ctx scratch (<= 1 GiB bands) by dfe_ssd_cost_volume_f32's kernel and consumed by dfe_flow_tail. */
+int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
+                            int k, int hWin, int wWin, float foe_x, float foe_y,
+                            double extract_threshold, float *flow, float *scores, float *depth,
+                            float *depth_conf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

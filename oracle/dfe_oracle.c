@@ -1,0 +1,600 @@
+/*
+ * dfe_oracle.c -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY
+ * (see dfe_oracle.h for the rules and the pinning status: the reference's native files
+ * cannot be built here, so this restatement is pinned by the reference's own data-free
+ * known-answer tests; pieces living in un-vendored nnx/nn are "parity unpinned").
+ *
+ * Build (reference flags, /root/reference Makefile:2):
+ *   gcc -O3 -funroll-loops -fopenmp -fPIC -shared -o libdfe_oracle.so dfe_oracle.c -lm
+ * -ffast-math is deliberately NOT used: summation order is part of the contract.
+ */
+#include "dfe_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 0;
+void orc_set_num_threads(int n) { g_threads = n; }
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return g_threads > 0 ? g_threads : omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+#ifdef _OPENMP
+#define ORC_PAR_FOR _Pragma("omp parallel for schedule(static) num_threads(orc_get_max_threads())")
+#else
+#define ORC_PAR_FOR
+#endif
+
+static inline int ifloor_div2(int a) { return a >> 1; }           /* floor(a/2), a>=0 */
+static inline int iceil_div2(int a) { return (a + 1) >> 1; }      /* ceil(a/2),  a>=0 */
+/* ref: common.lua:24-26 round(x)=floor(x+0.5) */
+static inline double lua_round(double x) { return floor(x + 0.5); }
+
+/* ---- A0 ---------------------------------------------------------------- */
+void orc_unfold(const float *img, int C, int H, int W, int kh, int kw, float *out) {
+    /* ref: radial/radial_opticalflow_groundtruth.lua:9-21: imgc[{{},i,j}] = reshape(C x hKer x wKer) */
+    int Ho = H - kh + 1, Wo = W - kw + 1;
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < kh; ++i)
+            for (int j = 0; j < kw; ++j) {
+                float *o = out + (size_t)((c * kh + i) * kw + j) * Ho * Wo;
+                for (int y = 0; y < Ho; ++y)
+                    for (int x = 0; x < Wo; ++x)
+                        o[(size_t)y * Wo + x] = img[((size_t)c * H + y + i) * W + x + j];
+            }
+}
+
+/* ---- A1 ---------------------------------------------------------------- */
+void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int W1,
+                          int maxh, int maxw, float *out) {
+    /* out[y][x][dy][dx] = sum_k (in1[k][y][x] - in2[k][y+dy][x+dx])^2, accumulated in
+     * float in feature order (nnx `real`=float). Layout pinned by opticalflow_model.lua:98
+     * (SmartReshape({-1,-2},{-3,-4})) and the index convention by tests/test_multiscale.lua:149-166. */
+    int H2 = H1 + maxh - 1, W2 = W1 + maxw - 1;
+    ORC_PAR_FOR
+    for (int y = 0; y < H1; ++y)
+        for (int x = 0; x < W1; ++x)
+            for (int dy = 0; dy < maxh; ++dy)
+                for (int dx = 0; dx < maxw; ++dx) {
+                    float s = 0.f;
+                    for (int k = 0; k < K; ++k) {
+                        float d = in1[((size_t)k * H1 + y) * W1 + x] -
+                                  in2[((size_t)k * H2 + y + dy) * W2 + x + dx];
+                        s += d * d;
+                    }
+                    out[(((size_t)y * W1 + x) * maxh + dy) * maxw + dx] = s;
+                }
+    (void)H2;
+}
+
+void orc_ssd_cost_volume(const float *I0, const float *I1, int C, int H, int W,
+                         int kh, int kw, int hWin, int wWin, float *out, int row0, int row1) {
+    /* ref: radial/radial_opticalflow_groundtruth.lua:79-84.  Feature k=(c,i,j) of frame0 at
+     * output (y,x) is I0[c][y+oy+i][x+ox+j] with oy=floor((hWin-1)/2) (the SpatialPadding crop,
+     * :81-82); of frame1 at cell (dy,dx) it is I1[c][y+dy+i][x+dx+j]. Same k order as A0. */
+    int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
+    int oy = (hWin - 1) / 2, ox = (wWin - 1) / 2;
+    if (row0 < 0) row0 = 0;
+    if (row1 > Ho) row1 = Ho;
+    ORC_PAR_FOR
+    for (int y = row0; y < row1; ++y)
+        for (int x = 0; x < Wo; ++x)
+            for (int dy = 0; dy < hWin; ++dy)
+                for (int dx = 0; dx < wWin; ++dx) {
+                    float s = 0.f;
+                    for (int c = 0; c < C; ++c)
+                        for (int i = 0; i < kh; ++i) {
+                            const float *a = I0 + ((size_t)c * H + y + oy + i) * W + x + ox;
+                            const float *b = I1 + ((size_t)c * H + y + dy + i) * W + x + dx;
+                            for (int j = 0; j < kw; ++j) {
+                                float d = a[j] - b[j];
+                                s += d * d;
+                            }
+                        }
+                    out[(((size_t)y * Wo + x) * hWin + dy) * wWin + dx] = s;
+                }
+}
+
+/* ---- A1r --------------------------------------------------------------- */
+void orc_radial_matching(const float *in1, const float *in2, int K, int H1, int W, int hWin,
+                         float *out) {
+    /* ref: radial/radial_opticalflow_network.lua:33,59-72; consumer `min(3)-1`
+     * radial/train_radial_opticalflow.lua:166-167 */
+    int H2 = H1 + hWin - 1;
+    ORC_PAR_FOR
+    for (int y = 0; y < H1; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int d = 0; d < hWin; ++d) {
+                float s = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    float t = in1[((size_t)k * H1 + y) * W + x] - in2[((size_t)k * H2 + y + d) * W + x];
+                    s += t * t;
+                }
+                out[((size_t)y * W + x) * hWin + d] = s;
+            }
+}
+
+/* ---- A6 ---------------------------------------------------------------- */
+void orc_argbest_center(const float *vol, int64_t P, int N, int middle, int take_max,
+                        int64_t *idx, float *best) {
+    /* ref: radial/radial_opticalflow_groundtruth.lua:88-94: m,idx=output:min(3);
+     * flat=m:eq(output[middleidx]); idx=flat*middleidx+(1-flat)*idx.  TH min/max keep the
+     * first extremum (strict comparison). opticalflow_model.lua:153-161 is the max twin. */
+    for (int64_t p = 0; p < P; ++p) {
+        const float *v = vol + p * N;
+        float b = v[0];
+        int bi = 0;
+        for (int n = 1; n < N; ++n) {
+            if (take_max ? (v[n] > b) : (v[n] < b)) { b = v[n]; bi = n; }
+        }
+        int64_t id = bi + 1;
+        if (middle > 0 && b == v[middle - 1]) id = middle;
+        idx[p] = id;
+        if (best) best[p] = b;
+    }
+}
+
+/* ---- A7 / A8 ----------------------------------------------------------- */
+/* ref: version2/extract_output.cpp:17-26 sortswap: swaps value and index iff *b > *a */
+static inline void sortswap(float *v, float *ix, int a, int b) {
+    if (v[b] > v[a]) {
+        float t = v[b]; v[b] = v[a]; v[a] = t;
+        t = ix[b]; ix[b] = ix[a]; ix[a] = t;
+    }
+}
+static void sort4(float *v, float *ix) { /* ref: :27-33 */
+    sortswap(v, ix, 0, 2); sortswap(v, ix, 1, 3); sortswap(v, ix, 0, 1);
+    sortswap(v, ix, 2, 3); sortswap(v, ix, 1, 2);
+}
+static void sort8(float *v, float *ix) { /* ref: :35-61 */
+    sortswap(v, ix, 0, 1); sortswap(v, ix, 2, 3); sortswap(v, ix, 4, 5); sortswap(v, ix, 6, 7);
+    sortswap(v, ix, 0, 2); sortswap(v, ix, 1, 3); sortswap(v, ix, 4, 6); sortswap(v, ix, 5, 7);
+    sortswap(v, ix, 1, 2); sortswap(v, ix, 5, 6); sortswap(v, ix, 0, 4); sortswap(v, ix, 3, 7);
+    sortswap(v, ix, 1, 5); sortswap(v, ix, 2, 6);
+    sortswap(v, ix, 1, 4); sortswap(v, ix, 3, 6);
+    sortswap(v, ix, 2, 4); sortswap(v, ix, 3, 5);
+    sortswap(v, ix, 3, 4);
+}
+/* shared body of ExtractOutput / ExtractOutputMarginalized: returns 0 if the pixel is skipped */
+static int extract_pixel(const float *v, int N, double threshold, int M, int64_t *imax, double *acc_out) {
+    float hv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* ref: :86-90 zeroed highs */
+    int n = 0;
+    for (int k = 0; k < N; ++k) { /* ref: :99-112 */
+        if (v[k] > threshold) {   /* float promoted to double vs double threshold, as in the reference */
+            hv[n] = v[k];
+            hi[n] = (float)(k + 1); /* index is stored in a float temp, ref :105 */
+            if (++n == M) break;
+        }
+    }
+    if (!(hv[0] > 0)) return 0; /* ref: :121 */
+    if (M == 4) sort4(hv, hi); else sort8(hv, hi);
+    *imax = (int64_t)hi[0];     /* ref: :123 */
+    for (int k = 1; k < M; ++k) hv[k] += hv[k - 1]; /* ref: :124-125 float prefix sums */
+    double acc = 0;             /* ref: :126-128 accreal=double */
+    for (int k = 0; k < M; ++k) acc += hv[k];
+    *acc_out = acc;
+    return 1;
+}
+void orc_extract_output(const float *input, int64_t P, int N, double threshold, int64_t *imaxs,
+                        float *scores) {
+    int M = threshold < 0.2 ? 8 : 4; /* ref: :83-85 */
+    for (int64_t p = 0; p < P; ++p) {
+        int64_t im; double acc;
+        if (extract_pixel(input + p * N, N, threshold, M, &im, &acc)) {
+            imaxs[p] = im;
+            scores[p] = (float)acc;
+        }
+    }
+}
+void orc_extract_output_marginalized(const float *input, int64_t P, int N, double threshold,
+                                     double threshold_acc, int64_t *ret, int64_t *retgd) {
+    int M = threshold < 0.2 ? 8 : 4;
+    for (int64_t p = 0; p < P; ++p) retgd[p] = 0; /* ref: :166 THLongTensor_zero(retgd) */
+    for (int64_t p = 0; p < P; ++p) {
+        int64_t im; double acc;
+        if (extract_pixel(input + p * N, N, threshold, M, &im, &acc)) {
+            ret[p] = im;
+            if (acc >= threshold_acc) retgd[p] = 1; /* ref: :227-228 */
+        }
+    }
+}
+
+/* ---- A9 ---------------------------------------------------------------- */
+void orc_x2yx(const int64_t *idx, int64_t P, int maxh, int maxw, int64_t *y, int64_t *x) {
+    /* ref: radial/radial_opticalflow_groundtruth.lua:97-100 */
+    for (int64_t p = 0; p < P; ++p) {
+        int64_t fl = (idx[p] - 1) / maxw; /* idx>=1 so trunc == floor */
+        y[p] = fl - (maxh - 1) / 2;
+        x[p] = idx[p] - 1 - fl * maxw - (maxw - 1) / 2;
+    }
+}
+
+/* ---- A10 --------------------------------------------------------------- */
+static int ring_d(int maxw, const int *ratios, int i) { /* i: 0-based scale index >=1 */
+    /* ref: opticalflow_model_multiscale.lua:94-95 / :296 round(maxw*(r_i-r_{i-1})/(2 r_i)) */
+    return (int)lua_round((double)maxw * (ratios[i] - ratios[i - 1]) / (2.0 * ratios[i]));
+}
+int64_t orc_multi_nclasses(int maxh, int maxw, const int *ratios, int nratios) {
+    int64_t n = (int64_t)maxh * maxw;
+    for (int i = 1; i < nratios; ++i) {
+        int d = ring_d(maxw, ratios, i);
+        n += 2 * d * maxw + 2 * (maxh - 2 * d) * d;
+    }
+    return n;
+}
+static int is_in(double size, double v) { /* ref: :13-15 */
+    return (v >= -ceil(size / 2) + 1) && (v <= floor(size / 2));
+}
+int64_t orc_yx2x_multi(int maxh, int maxw, const int *ratios, int nratios, double y, double x) {
+    /* ref: opticalflow_model_multiscale.lua:10-52 */
+    x = lua_round(x);
+    y = lua_round(y);
+    int i = 0;
+    double tx = 0, ty = 0;
+    for (; i < nratios; ++i) {
+        if (is_in((double)maxw * ratios[i], x) && is_in((double)maxh * ratios[i], y)) {
+            tx = ceil(x / ratios[i]) + ceil(maxw / 2.0);
+            ty = ceil(y / ratios[i]) + ceil(maxh / 2.0);
+            break;
+        }
+    }
+    if (i >= nratios) return -1; /* ref :29 assert */
+    int64_t targetx = (int64_t)tx, targety = (int64_t)ty, it;
+    if (i == 0) return (targety - 1) * maxw + targetx;
+    int d = (int)floor((double)maxw * (ratios[i] - ratios[i - 1]) / (2.0 * ratios[i]) + 0.5);
+    if (targety <= d) it = (targety - 1) * maxw + targetx;
+    else if (targety > maxh - d)
+        it = d * maxw + 2 * (maxh - 2 * d) * d + (targety - (maxh - d) - 1) * maxw + targetx;
+    else if (targetx <= d) it = d * maxw + (targety - d - 1) * d + targetx;
+    else if (targetx > maxw - d)
+        it = d * maxw + (maxh - 2 * d) * d + (targety - d - 1) * d + targetx - (maxw - d);
+    else return -1; /* ref :45-46 assert(false) */
+    /* ref :48-49: NOTE uses the ring length of scale i for every skipped scale */
+    return (int64_t)maxw * maxh + (int64_t)(i - 1) * (2 * d * maxw + 2 * (maxh - 2 * d) * d) + it;
+}
+int orc_x2yx_multi_number(int maxh, int maxw, const int *ratios, int nratios, int64_t id,
+                          int64_t *oy, int64_t *ox) {
+    /* ref: opticalflow_model_multiscale.lua:83-132 */
+    int chh = iceil_div2(maxh), chw = iceil_div2(maxw);
+    int64_t x = id;
+    if (x < 1) return -1;
+    if (x <= (int64_t)maxh * maxw) {
+        int64_t ty = (x - 1) / maxw + 1, tx = (x - 1) % maxw + 1;
+        *oy = ty - chh; *ox = tx - chw;
+        return 0;
+    }
+    x -= (int64_t)maxh * maxw;
+    for (int i = 1; i < nratios; ++i) {
+        int d = ring_d(maxw, ratios, i);
+        int64_t len = 2 * d * maxw + 2 * (maxh - 2 * d) * d, ty, tx;
+        if (x <= len) {
+            if (x <= (int64_t)d * maxw) { /* top block d x maxw */
+                ty = (x - 1) / maxw + 1; tx = (x - 1) % maxw + 1;
+            } else {
+                x -= (int64_t)d * maxw;
+                if (x <= (int64_t)(maxh - 2 * d) * d) { /* left block */
+                    ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1;
+                } else {
+                    x -= (int64_t)(maxh - 2 * d) * d;
+                    if (x <= (int64_t)(maxh - 2 * d) * d) { /* right block */
+                        ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1 + maxw - d;
+                    } else {
+                        x -= (int64_t)(maxh - 2 * d) * d;
+                        if (x > (int64_t)d * maxw) return -1;
+                        ty = (x - 1) / maxw + 1 + maxh - d; tx = (x - 1) % maxw + 1; /* bottom */
+                    }
+                }
+            }
+            *oy = (ty - chh) * ratios[i]; *ox = (tx - chw) * ratios[i];
+            return 0;
+        }
+        x -= len;
+    }
+    return -1; /* ref :131 assert(false) */
+}
+int orc_x2yx_multi(int maxh, int maxw, const int *ratios, int nratios, const int64_t *idx,
+                   int64_t P, int64_t *y, int64_t *x) {
+    int rc = 0;
+    for (int64_t p = 0; p < P; ++p)
+        if (orc_x2yx_multi_number(maxh, maxw, ratios, nratios, idx[p], &y[p], &x[p])) rc = -1;
+    return rc;
+}
+void orc_x2yx_multi_compat_c(int maxh, int maxw, const int *ratios_lua, int nratios,
+                             const int64_t *idx, int64_t P, int64_t *rety, int64_t *retx) {
+    /* ref: x2yxMulti2.c:1-95, bug for bug.  (1) :15-19 reads Lua keys 0..n-1 of a 1-based
+     * table => ratios[0]=0 (nil->0), ratios[k]=lua[k]; (2) :41 lengths drop the factor d;
+     * (3) strict '<' at :50,:61,:79; ceil(maxh/2) on ints (:24-25) is maxh/2;
+     * (4) unmatched ids write nothing. C integer / and % on x-1=-1 kept as is. */
+    int ratios[ORC_MAX_RATIOS];
+    for (int i = 0; i < nratios && i < ORC_MAX_RATIOS; ++i) ratios[i] = (i == 0) ? 0 : ratios_lua[i - 1];
+    int chmaxh = maxh / 2, chmaxw = maxw / 2;
+    int patcharea = maxh * maxw;
+    int borders[ORC_MAX_RATIOS], lengths[ORC_MAX_RATIOS];
+    for (int i = 1; i < nratios; ++i) {
+        borders[i] = (int)roundf((float)maxw * ((float)ratios[i] - (float)ratios[i - 1]) / (2.0f * (float)ratios[i]));
+        lengths[i] = 2 * maxw + 2 * (maxh - 2 * borders[i]) * borders[i];
+    }
+    for (int64_t p = 0; p < P; ++p) {
+        long x = (long)idx[p];
+        if (x < patcharea) {
+            rety[p] = (long)floor((double)((x - 1) / maxw)) + 1 - chmaxh;
+            retx[p] = (x - 1) % maxw + 1 - chmaxw;
+        } else {
+            x -= patcharea;
+            for (int k = 1; k < nratios; ++k) {
+                int d = borders[k];
+                int mH = (maxh - 2 * d) * d;
+                if (x <= lengths[k]) {
+                    if (x < d * maxw) {
+                        rety[p] = ((x - 1) / maxw + 1 - chmaxh) * ratios[k];
+                        retx[p] = ((x - 1) % maxw + 1 - chmaxw) * ratios[k];
+                        break;
+                    }
+                    x -= d * maxw;
+                    if (x <= mH) {
+                        rety[p] = (d ? ((x - 1) / d + 1 + d - chmaxh) : 0) * ratios[k];
+                        retx[p] = (d ? ((x - 1) % d + 1 - chmaxw) : 0) * ratios[k];
+                        break;
+                    }
+                    x -= mH;
+                    if (x <= mH) {
+                        rety[p] = (d ? ((x - 1) / d + 1 + d - chmaxh) : 0) * ratios[k];
+                        retx[p] = (d ? ((x - 1) % d + 1 + maxw - d - chmaxw) : 0) * ratios[k];
+                        break;
+                    }
+                    x -= mH;
+                    if (x < d * maxw) {
+                        rety[p] = ((x - 1) / maxw + 1 + maxh - d - chmaxh) * ratios[k];
+                        retx[p] = ((x - 1) % maxw + 1 - chmaxw) * ratios[k];
+                        break;
+                    }
+                } else {
+                    x -= lengths[k];
+                }
+            }
+        }
+    }
+}
+
+/* ---- A2 pieces --------------------------------------------------------- */
+void orc_downsample_box(const float *img, int C, int H, int W, int r, float *out) {
+    /* nn.SpatialDownSampling(r,r): mean of each r x r block. ref: opticalflow_model_multiscale.lua:146.
+     * [3P nnx: accumulation order row-major inside the block, scaled by 1/(r*r) -- parity unpinned] */
+    int Ho = H / r, Wo = W / r;
+    float inv = 1.0f / (float)(r * r);
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float s = 0.f;
+                for (int i = 0; i < r; ++i)
+                    for (int j = 0; j < r; ++j) s += img[((size_t)c * H + y * r + i) * W + x * r + j];
+                out[((size_t)c * Ho + y) * Wo + x] = s * inv;
+            }
+}
+void orc_zero_pad(const float *img, int C, int H, int W, int pl, int pr, int pt, int pb, float *out) {
+    /* nn.SpatialZeroPadding(l,r,t,b), non-negative pads. ref: :136-141,147 */
+    int Ho = H + pt + pb, Wo = W + pl + pr;
+    memset(out, 0, sizeof(float) * (size_t)C * Ho * Wo);
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < H; ++y)
+            memcpy(out + ((size_t)c * Ho + y + pt) * Wo + pl, img + ((size_t)c * H + y) * W, sizeof(float) * W);
+}
+void orc_pyramid_scale_volume(const float *I0, const float *I1, int C, int H, int W, int r,
+                              int kh, int kw, int maxh, int maxw, float *out) {
+    /* ref: opticalflow_model_multiscale.lua:134-173 (downsample, pad hPatch2-1 = maxh-1+kh-1 split
+     * floor/ceil), :196-216 (frame0 cropped by maxw-1 split floor/ceil, identity kxk patch
+     * features, SpatialMatching(maxh,maxw)).  Result at native scale [H/r][W/r][maxh][maxw]. */
+    int Hs = H / r, Ws = W / r;
+    int hp = maxh - 1 + kh - 1, wp = maxw - 1 + kw - 1;
+    int pt = hp / 2, pb = hp - pt, pl = wp / 2, pr = wp - pl;
+    int Hp = Hs + hp, Wp = Ws + wp;
+    float *d0 = (float *)malloc(sizeof(float) * (size_t)C * Hs * Ws);
+    float *d1 = (float *)malloc(sizeof(float) * (size_t)C * Hs * Ws);
+    float *p0 = (float *)malloc(sizeof(float) * (size_t)C * Hp * Wp);
+    float *p1 = (float *)malloc(sizeof(float) * (size_t)C * Hp * Wp);
+    orc_downsample_box(I0, C, H, W, r, d0);
+    orc_downsample_box(I1, C, H, W, r, d1);
+    orc_zero_pad(d0, C, Hs, Ws, pl, pr, pt, pb, p0);
+    orc_zero_pad(d1, C, Hs, Ws, pl, pr, pt, pb, p1);
+    /* frame0 crop floor((maxh-1)/2) top / ceil bottom == the oy offset of orc_ssd_cost_volume */
+    orc_ssd_cost_volume(p0, p1, C, Hp, Wp, kh, kw, maxh, maxw, out, 0, Hs);
+    free(d0); free(d1); free(p0); free(p1);
+}
+
+/* ---- A3 ---------------------------------------------------------------- */
+void orc_softmin(const float *cost, int64_t P, int N, float *prob) {
+    /* nn.Minus -> nn.SoftMax over the N window cells. ref: opticalflow_model_multiscale.lua:270-279.
+     * [3P nn.SoftMax: max-subtracted, exact exp, float sum in index order -- parity unpinned] */
+    for (int64_t p = 0; p < P; ++p) {
+        const float *c = cost + p * N;
+        float *o = prob + p * N;
+        float m = -c[0];
+        for (int n = 1; n < N; ++n) if (-c[n] > m) m = -c[n];
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) { float e = expf(-c[n] - m); o[n] = e; s += e; }
+        float inv = 1.0f / s;
+        for (int n = 0; n < N; ++n) o[n] *= inv;
+    }
+}
+
+/* ---- A4 / A5 ----------------------------------------------------------- */
+static int cascade_check(int nratios, const int *ratios, int maxh, int maxw) {
+    for (int i = 0; i + 1 < nratios; ++i) { /* ref: CascadingAddTable.lua:121-124 */
+        int r = ratios[i], r2 = ratios[i + 1];
+        if ((maxh * (r2 - r)) % (2 * r2) != 0 || (maxw * (r2 - r)) % (2 * r2) != 0) return -1;
+        if (r2 % r != 0) return -1;
+    }
+    return 0;
+}
+/* out_i = in_i + replicate_{r2/r}( crop(out_{i+1}, dh, dw) )   ref: CascadingAddTable.lua:117-132 */
+static void cascade_window(float *const *win, int nratios, const int *ratios, int maxh, int maxw) {
+    for (int i = nratios - 2; i >= 0; --i) {
+        int r = ratios[i], r2 = ratios[i + 1], q = r2 / r;
+        int dh = maxh * (r2 - r) / (2 * r2), dw = maxw * (r2 - r) / (2 * r2);
+        for (int a = 0; a < maxh; ++a)
+            for (int b = 0; b < maxw; ++b)
+                win[i][a * maxw + b] += win[i + 1][(dh + a / q) * maxw + dw + b / q];
+    }
+}
+int orc_cascading_add(const float *const *in, int nratios, const int *ratios, int64_t P, int maxh,
+                      int maxw, float *const *out) {
+    if (cascade_check(nratios, ratios, maxh, maxw)) return -1;
+    int N = maxh * maxw;
+    float *w[ORC_MAX_RATIOS];
+    for (int64_t p = 0; p < P; ++p) {
+        for (int s = 0; s < nratios; ++s) {
+            w[s] = out[s] + p * N;
+            memcpy(w[s], in[s] + p * N, sizeof(float) * N);
+        }
+        cascade_window(w, nratios, ratios, maxh, maxw);
+    }
+    return 0;
+}
+int orc_cascade_ring(const float *const *prob, int nratios, const int *ratios, int H, int W,
+                     int maxh, int maxw, float *out) {
+    if (cascade_check(nratios, ratios, maxh, maxw) || nratios > ORC_MAX_RATIOS) return -1;
+    int N = maxh * maxw;
+    int64_t ncls = orc_multi_nclasses(maxh, maxw, ratios, nratios);
+    float *buf = (float *)malloc(sizeof(float) * (size_t)N * nratios);
+    float *w[ORC_MAX_RATIOS];
+    for (int s = 0; s < nratios; ++s) w[s] = buf + (size_t)s * N;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            for (int s = 0; s < nratios; ++s) { /* nearest-neighbour upsample x r of dims (1,2) */
+                int r = ratios[s], Ws = W / r;
+                memcpy(w[s], prob[s] + ((size_t)(y / r) * Ws + x / r) * N, sizeof(float) * N);
+            }
+            cascade_window(w, nratios, ratios, maxh, maxw);
+            float *o = out + ((size_t)y * W + x) * ncls;
+            memcpy(o, w[0], sizeof(float) * N); /* scale 1: all cells. ref: :294 */
+            o += N;
+            for (int s = 1; s < nratios; ++s) { /* ring blocks top,left,right,bottom. ref: :295-324 */
+                int d = ring_d(maxw, ratios, s);
+                for (int a = 0; a < d; ++a) for (int b = 0; b < maxw; ++b) *o++ = w[s][a * maxw + b];
+                for (int a = d; a < maxh - d; ++a) for (int b = 0; b < d; ++b) *o++ = w[s][a * maxw + b];
+                for (int a = d; a < maxh - d; ++a) for (int b = maxw - d; b < maxw; ++b) *o++ = w[s][a * maxw + b];
+                for (int a = maxh - d; a < maxh; ++a) for (int b = 0; b < maxw; ++b) *o++ = w[s][a * maxw + b];
+            }
+        }
+    free(buf);
+    return 0;
+}
+
+/* ---- A11 --------------------------------------------------------------- */
+void orc_paste_center(const float *src, int h, int w, float *dst, int H, int W) {
+    /* ref: opticalflow_model.lua:227-249: zero, offset floor((H-h)/2) */
+    int ho = (H - h) / 2, wo = (W - w) / 2;
+    memset(dst, 0, sizeof(float) * (size_t)H * W);
+    for (int y = 0; y < h; ++y) memcpy(dst + (size_t)(y + ho) * W + wo, src + (size_t)y * w, sizeof(float) * w);
+}
+
+/* ---- A12 --------------------------------------------------------------- */
+void orc_flow_to_depth_cartesian(const float *flow, int H, int W, float mw, float mh, int fix_dot,
+                                 float *depth, float *conf) {
+    /* ref: test_opticalflow.lua:143-189.  Arguments (cx,cy)=(mw,mh). float variables, double
+     * sqrt (C promotion) rounded back to float on assignment, exactly as the inline C. */
+    float infty = (float)((double)W / 2); /* ref :148 geometry.wImg/2 passed as lua number -> float */
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            float py = (float)i - mh, px = (float)j - mw;
+            float pn = (float)sqrt((double)(px * px + py * py));
+            float dy = flow[(size_t)i * W + j], dx = flow[(size_t)H * W + (size_t)i * W + j];
+            float dn = (float)sqrt((double)(dx * dx + dy * dy));
+            float r = 0.f, c = 0.f; /* ref :146-147 zero-initialised outputs */
+            if (dn >= 0.2f) {
+                float q = pn / dn;
+                r = q < infty ? q : infty;
+                float dot = fix_dot ? (px * dx + py * dy) : (px * dx + dy * dy); /* ref :181 (sic) */
+                if (dot > 0.125f) c = 1.0f;
+            } else {
+                c = 1.0f;
+                r = infty;
+            }
+            depth[(size_t)i * W + j] = r;
+            conf[(size_t)i * W + j] = c;
+        }
+}
+void orc_flow_to_depth_radial(const float *rflow, const float *unused, int H, int W, float xc,
+                              float yc, float infty, float *depth, float *conf) {
+    /* ref: radial/radial_opticalflow_display.lua:6-58; returns ret/infty and confs */
+    (void)unused;
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            float a = (float)j - xc, b = (float)i - yc;
+            float d = (float)sqrt((double)(a * a + b * b));
+            float o = 0.f, c = 1.f;
+            if (d > 10.0f) {
+                float f = rflow[(size_t)i * W + j];
+                o = (f < 0.1f) ? infty : d / f;
+            } else c = 0.f;
+            depth[(size_t)i * W + j] = o / infty;
+            conf[(size_t)i * W + j] = c;
+        }
+}
+
+/* ---- A13 / A14 --------------------------------------------------------- */
+void orc_polar_grid_c2p(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc, int lpad,
+                        int rpad, float rmax, float alpha, float *mask) {
+    /* ref: radial/cartesian2polar.lua:4-49 */
+    (void)wsrc; (void)hsrc;
+    int Wp = wdst + lpad + rpad;
+    float kr = (float)((double)rmax / pow((double)hdst, (double)alpha));
+    float ktheta = (float)(2 * M_PI / wdst);
+    float *m0 = mask, *m1 = mask + (size_t)hdst * Wp;
+    for (int i = 0; i < hdst; ++i)
+        for (int j = 0; j < wdst; ++j) {
+            float r = (float)(kr * pow((double)(float)i, (double)alpha));
+            float th = ktheta * (float)j;
+            m0[(size_t)i * Wp + lpad + j] = (float)(r * sin((double)th) + yc);
+            m1[(size_t)i * Wp + lpad + j] = (float)(r * cos((double)th) + xc);
+        }
+    for (int pl = 0; pl < 2; ++pl) { /* circular column padding :42-47 */
+        float *m = pl ? m1 : m0;
+        for (int i = 0; i < hdst; ++i) {
+            for (int j = 0; j < lpad; ++j) m[(size_t)i * Wp + j] = m[(size_t)i * Wp + lpad + wdst - lpad + j];
+            for (int j = 0; j < rpad; ++j) m[(size_t)i * Wp + lpad + wdst + j] = m[(size_t)i * Wp + lpad + j];
+        }
+    }
+}
+void orc_polar_grid_p2c(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc, float rmax,
+                        float alpha, float *mask) {
+    /* ref: radial/cartesian2polar.lua:51-89 */
+    float pi2 = (float)(2 * M_PI);
+    float kx = (float)((double)wsrc / (2 * M_PI));
+    float ky = (float)((double)hsrc / pow((double)rmax, 1.0 / (double)alpha));
+    float invalpha = (float)(1.0 / (double)alpha) * 0.5f;
+    float *m0 = mask, *m1 = mask + (size_t)hdst * wdst;
+    for (int i = 0; i < hdst; ++i)
+        for (int j = 0; j < wdst; ++j) {
+            float x = (float)j - xc, y = (float)i - yc;
+            m0[(size_t)i * wdst + j] = (float)(pow((double)(x * x + y * y), (double)invalpha) * ky);
+            m1[(size_t)i * wdst + j] = (float)(fmod(atan2((double)y, (double)x) + pi2, (double)pi2) * kx);
+        }
+}
+void orc_warp_bilinear(const float *img, int C, int H, int W, const float *mask, int Hd, int Wd,
+                       float *out) {
+    /* image.warp(img, mask, 'bilinear', false): absolute coords, plane0=y plane1=x, 0-based.
+     * ref: radial/cartesian2polar.lua:91-93.  [3P image: border policy = clamp -- parity unpinned] */
+    const float *my = mask, *mx = mask + (size_t)Hd * Wd;
+    for (int i = 0; i < Hd; ++i)
+        for (int j = 0; j < Wd; ++j) {
+            float fy = my[(size_t)i * Wd + j], fx = mx[(size_t)i * Wd + j];
+            fy = fy < 0 ? 0 : (fy > (float)(H - 1) ? (float)(H - 1) : fy);
+            fx = fx < 0 ? 0 : (fx > (float)(W - 1) ? (float)(W - 1) : fx);
+            int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+            float wy = fy - (float)y0, wx = fx - (float)x0;
+            for (int c = 0; c < C; ++c) {
+                const float *p = img + (size_t)c * H * W;
+                float v = (1 - wy) * ((1 - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1]) +
+                          wy * ((1 - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1]);
+                out[((size_t)c * Hd + i) * Wd + j] = v;
+            }
+        }
+}

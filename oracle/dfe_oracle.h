@@ -1,0 +1,142 @@
+/*
+ * dfe_oracle.h -- CPU restatement of the reference's dense patch-correlation
+ * flow->depth hot path (MichaelMathieu/depth-estimation).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under depth-estimation_amd/ (the product)
+ * may include, link or call this.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / the baseline.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - The reference is Lua on Torch7; no Lua/Torch7 runtime or headers exist
+ *     in the build image, and its two native files need luaT.h / TH.h / lua.h
+ *     (absent).  Nothing of the reference can be compiled or run here without
+ *     writing stand-in headers, so oracle/_ref does not exist.
+ *   - The restatement is pinned by the reference's own known-answer tests that
+ *     need no data files: cartesian_groundtruth_cc_testme
+ *     (radial/radial_opticalflow_groundtruth.lua:170-210), the codec round trip
+ *     and brute-force SSD cross-check of tests/test_multiscale.lua:57-80,
+ *     135-166, and a hand-derived extractOutput vector.  Pieces whose
+ *     arithmetic lives in un-vendored nnx/nn (SoftMax numerics, down-sampling
+ *     edge policy, image.warp border policy) are "parity unpinned".
+ *
+ * All tensors are dense row-major; sizes in elements.  Class ids are 1-based
+ * exactly as in the reference.  "ref:" comments give reference file:line.
+ */
+#ifndef DFE_ORACLE_H
+#define DFE_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_RATIOS 10 /* ref: x2yxMulti2.c:1 N_MAX_RATIOS */
+
+void orc_set_num_threads(int n); /* ref: openmp.setDefaultNumThreads, depth_estimation_opticalflow.lua:40 */
+int orc_get_max_threads(void);
+
+/* A0 unfold (im2col). ref: radial/radial_opticalflow_groundtruth.lua:9-21
+ * img [C][H][W] -> out [C*kh*kw][H-kh+1][W-kw+1], feature (c,i,j) = c*kh*kw+i*kw+j */
+void orc_unfold(const float *img, int C, int H, int W, int kh, int kw, float *out);
+
+/* A1 nn.SpatialMatching(maxh,maxw,false) on feature maps.
+ * ref call sites: opticalflow_model.lua:93, radial/radial_opticalflow_groundtruth.lua:83;
+ * semantics pinned by tests/test_multiscale.lua:149-166.
+ * in1 [K][H1][W1], in2 [K][H1+maxh-1][W1+maxw-1] -> out [H1][W1][maxh][maxw] */
+void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int W1,
+                          int maxh, int maxw, float *out);
+
+/* A0+A1 fused on raw frames (never materialises the unfolded features):
+ * unfold(kh,kw) -> crop frame0 features by floor/ceil((win-1)/2) -> SpatialMatching.
+ * ref: radial/radial_opticalflow_groundtruth.lua:79-84.
+ * rows [row0,row1) of the Ho x Wo output are computed (row0=0,row1=Ho for all);
+ * out is the full [Ho][Wo][hWin][wWin] buffer. Ho=H-kh+1-hWin+1, Wo=W-kw+1-wWin+1 */
+void orc_ssd_cost_volume(const float *I0, const float *I1, int C, int H, int W,
+                         int kh, int kw, int hWin, int wWin, float *out,
+                         int row0, int row1);
+
+/* A1r nn.SpatialRadialMatching(hWin). ref: radial/radial_opticalflow_network.lua:33,59-72
+ * in1 [K][H1][W], in2 [K][H1+hWin-1][W] -> out [H1][W][hWin] */
+void orc_radial_matching(const float *in1, const float *in2, int K, int H1, int W,
+                         int hWin, float *out);
+
+/* A6 arg-min / arg-max over the last dim with the centre tie-break.
+ * ref: radial/radial_opticalflow_groundtruth.lua:88-94 (min), opticalflow_model.lua:153-161 (max).
+ * vol [P][N]; idx 1-based; first index wins ties; if best == vol[p][middle-1] idx=middle.
+ * middle<=0 disables the tie-break. */
+void orc_argbest_center(const float *vol, int64_t P, int N, int middle, int take_max,
+                        int64_t *idx, float *best);
+
+/* A7 extractoutput.extractOutput. ref: version2/extract_output.cpp:63-155 (root copy :63-155)
+ * input [H*W][N]; imaxs/scores are left untouched for pixels with nothing > threshold. */
+void orc_extract_output(const float *input, int64_t P, int N, double threshold,
+                        int64_t *imaxs, float *scores);
+/* A8 extractOutputMarginalized. ref: version2/extract_output.cpp:157-255 */
+void orc_extract_output_marginalized(const float *input, int64_t P, int N, double threshold,
+                                     double threshold_acc, int64_t *ret, int64_t *retgd);
+
+/* A9 single-scale decode. ref: radial/radial_opticalflow_groundtruth.lua:97-100,
+ * opticalflow_model.lua:16-34,209-213 */
+void orc_x2yx(const int64_t *idx, int64_t P, int maxh, int maxw, int64_t *y, int64_t *x);
+
+/* A10 multiscale codec, Lua scalar semantics.
+ * ref: opticalflow_model_multiscale.lua:10-52 (yx2xMulti), :83-132 (x2yxMultiNumber) */
+int64_t orc_yx2x_multi(int maxh, int maxw, const int *ratios, int nratios, double y, double x);
+int orc_x2yx_multi_number(int maxh, int maxw, const int *ratios, int nratios, int64_t id,
+                          int64_t *y, int64_t *x);
+int orc_x2yx_multi(int maxh, int maxw, const int *ratios, int nratios, const int64_t *idx,
+                   int64_t P, int64_t *y, int64_t *x);
+int64_t orc_multi_nclasses(int maxh, int maxw, const int *ratios, int nratios);
+/* bug-compatible restatement of the shipped vectorised C body. ref: x2yxMulti2.c:1-95.
+ * ids it never matches leave y/x untouched (as shipped). */
+void orc_x2yx_multi_compat_c(int maxh, int maxw, const int *ratios, int nratios,
+                             const int64_t *idx, int64_t P, int64_t *y, int64_t *x);
+
+/* A2 pieces. ref: opticalflow_model_multiscale.lua:134-173 (getMultiscalePrefilter), :196-229 */
+void orc_downsample_box(const float *img, int C, int H, int W, int r, float *out); /* [C][H/r][W/r] */
+void orc_zero_pad(const float *img, int C, int H, int W, int pl, int pr, int pt, int pb, float *out);
+/* one scale of the pyramid on raw frames: downsample by r, zero-pad by hPatch2-1,
+ * crop frame0 by maxw-1, kxk raw-patch features, SpatialMatching(maxh,maxw).
+ * out [H/r][W/r][maxh][maxw] (native scale, not upsampled) */
+void orc_pyramid_scale_volume(const float *I0, const float *I1, int C, int H, int W, int r,
+                              int kh, int kw, int maxh, int maxw, float *out);
+
+/* A3 per-pixel softmin over N cells: p = softmax(-cost). ref: opticalflow_model_multiscale.lua:270-279 */
+void orc_softmin(const float *cost, int64_t P, int N, float *prob);
+
+/* A2(upsample)+A4+A5: cascade + ring extraction for one finest-scale image.
+ * prob[s] is [H/r_s][W/r_s][maxh][maxw] (native scale); nearest-neighbour upsample to HxW is
+ * implied (pixel (y,x) reads (y/r, x/r)). ref: CascadingAddTable.lua:108-135,
+ * opticalflow_model_multiscale.lua:293-333.  out [H][W][nclasses] */
+int orc_cascade_ring(const float *const *prob, int nratios, const int *ratios, int H, int W,
+                     int maxh, int maxw, float *out);
+/* A4 alone on already-upsampled windows: in[s] [P][maxh][maxw] -> out[s] same. ref: CascadingAddTable.lua:108-135 */
+int orc_cascading_add(const float *const *in, int nratios, const int *ratios, int64_t P,
+                      int maxh, int maxw, float *const *out);
+
+/* A11 centre-paste. ref: opticalflow_model.lua:227-250 */
+void orc_paste_center(const float *src, int h, int w, float *dst, int H, int W);
+
+/* A12 flow -> depth.
+ * (i) ref: test_opticalflow.lua:143-216 `radial` (dot-product quirk :181 replicated unless fix_dot)
+ * flow [2][H][W] (plane0=y, plane1=x), centre (cx,cy) */
+void orc_flow_to_depth_cartesian(const float *flow, int H, int W, float cx, float cy,
+                                 int fix_dot, float *depth, float *conf);
+/* (ii) ref: radial/radial_opticalflow_display.lua:6-58 `flow2depth` */
+void orc_flow_to_depth_radial(const float *rflow, const float *cartidx_conf, int H, int W,
+                              float cx, float cy, float infty, float *depth, float *conf);
+
+/* A13 polar grids. ref: radial/cartesian2polar.lua:4-49 (C2P), :51-89 (P2C) */
+void orc_polar_grid_c2p(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc,
+                        int lpad, int rpad, float rmax, float alpha, float *mask /*[2][hdst][wdst+lpad+rpad]*/);
+void orc_polar_grid_p2c(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc,
+                        float rmax, float alpha, float *mask /*[2][hdst][wdst]*/);
+/* A14 absolute-coordinate bilinear warp (image.warp(img,mask,'bilinear',false)).
+ * ref: radial/cartesian2polar.lua:91-93.  Border policy is un-vendored: this restatement
+ * clamps coordinates to the image (parity unpinned). */
+void orc_warp_bilinear(const float *img, int C, int H, int W, const float *mask, int Hd, int Wd,
+                       float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,255 @@
+"""ctypes/numpy binding of the CPU oracle (oracle/dfe_oracle.c).  Test infrastructure: imported
+by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ODIR, "libdfe_oracle.so")
+
+_lib = None
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build():
+    src = os.path.join(ODIR, "dfe_oracle.c")
+    if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ODIR, "dfe_oracle.h"))):
+        subprocess.check_call(["make", "-C", ODIR, "libdfe_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        l = C.CDLL(SO)
+        sig = {
+            "orc_set_num_threads": (None, [C.c_int]),
+            "orc_get_max_threads": (C.c_int, []),
+            "orc_unfold": (None, [f32p] + [C.c_int] * 5 + [f32p]),
+            "orc_spatial_matching": (None, [f32p, f32p] + [C.c_int] * 5 + [f32p]),
+            "orc_ssd_cost_volume": (None, [f32p, f32p] + [C.c_int] * 7 + [f32p, C.c_int, C.c_int]),
+            "orc_radial_matching": (None, [f32p, f32p] + [C.c_int] * 4 + [f32p]),
+            "orc_argbest_center": (None, [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, i64p, C.c_void_p]),
+            "orc_extract_output": (None, [f32p, C.c_int64, C.c_int, C.c_double, i64p, f32p]),
+            "orc_extract_output_marginalized": (None, [f32p, C.c_int64, C.c_int, C.c_double, C.c_double, i64p, i64p]),
+            "orc_x2yx": (None, [i64p, C.c_int64, C.c_int, C.c_int, i64p, i64p]),
+            "orc_yx2x_multi": (C.c_int64, [C.c_int, C.c_int, i32p, C.c_int, C.c_double, C.c_double]),
+            "orc_x2yx_multi_number": (C.c_int, [C.c_int, C.c_int, i32p, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+            "orc_x2yx_multi": (C.c_int, [C.c_int, C.c_int, i32p, C.c_int, i64p, C.c_int64, i64p, i64p]),
+            "orc_multi_nclasses": (C.c_int64, [C.c_int, C.c_int, i32p, C.c_int]),
+            "orc_x2yx_multi_compat_c": (None, [C.c_int, C.c_int, i32p, C.c_int, i64p, C.c_int64, i64p, i64p]),
+            "orc_downsample_box": (None, [f32p] + [C.c_int] * 4 + [f32p]),
+            "orc_zero_pad": (None, [f32p] + [C.c_int] * 7 + [f32p]),
+            "orc_pyramid_scale_volume": (None, [f32p, f32p] + [C.c_int] * 8 + [f32p]),
+            "orc_softmin": (None, [f32p, C.c_int64, C.c_int, f32p]),
+            "orc_cascade_ring": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+            "orc_cascading_add": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+            "orc_paste_center": (None, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]),
+            "orc_flow_to_depth_cartesian": (None, [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]),
+            "orc_flow_to_depth_radial": (None, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]),
+            "orc_polar_grid_c2p": (None, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
+            "orc_polar_grid_p2c": (None, [C.c_int] * 4 + [C.c_float] * 4 + [f32p]),
+            "orc_warp_bilinear": (None, [f32p] + [C.c_int] * 3 + [f32p, C.c_int, C.c_int, f32p]),
+        }
+        for n, (r, a) in sig.items():
+            f = getattr(l, n)
+            f.restype = r
+            f.argtypes = a
+        _lib = l
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _r(ratios):
+    return np.ascontiguousarray(ratios, dtype=np.int32)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def max_threads():
+    return lib().orc_get_max_threads()
+
+
+def unfold(img, kh, kw):
+    img = _f(img)
+    Cc, H, W = img.shape
+    out = np.empty((Cc * kh * kw, H - kh + 1, W - kw + 1), np.float32)
+    lib().orc_unfold(img, Cc, H, W, kh, kw, out)
+    return out
+
+
+def spatial_matching(in1, in2, maxh, maxw):
+    in1, in2 = _f(in1), _f(in2)
+    K, H1, W1 = in1.shape
+    assert in2.shape == (K, H1 + maxh - 1, W1 + maxw - 1)
+    out = np.empty((H1, W1, maxh, maxw), np.float32)
+    lib().orc_spatial_matching(in1, in2, K, H1, W1, maxh, maxw, out)
+    return out
+
+
+def ssd_cost_volume(I0, I1, kh, kw, hWin, wWin, row0=0, row1=None, out=None):
+    I0, I1 = _f(I0), _f(I1)
+    Cc, H, W = I0.shape
+    Ho, Wo = H - kh + 1 - hWin + 1, W - kw + 1 - wWin + 1
+    if out is None:
+        out = np.zeros((Ho, Wo, hWin, wWin), np.float32)
+    lib().orc_ssd_cost_volume(I0, I1, Cc, H, W, kh, kw, hWin, wWin, out, row0, Ho if row1 is None else row1)
+    return out
+
+
+def radial_matching(in1, in2, hWin):
+    in1, in2 = _f(in1), _f(in2)
+    K, H1, W = in1.shape
+    out = np.empty((H1, W, hWin), np.float32)
+    lib().orc_radial_matching(in1, in2, K, H1, W, hWin, out)
+    return out
+
+
+def argbest_center(vol, middle, take_max):
+    vol = _f(vol)
+    N = vol.shape[-1]
+    P = vol.size // N
+    idx = np.empty(vol.shape[:-1], np.int64)
+    best = np.empty(vol.shape[:-1], np.float32)
+    lib().orc_argbest_center(vol.reshape(P, N), P, N, middle, int(take_max), idx.reshape(-1), best.ctypes.data_as(C.c_void_p))
+    return idx, best
+
+
+def extract_output(inp, threshold, imaxs, scores):
+    """in place, like the reference"""
+    inp = _f(inp)
+    N = inp.shape[-1]
+    P = inp.size // N
+    lib().orc_extract_output(inp.reshape(P, N), P, N, float(threshold), imaxs.reshape(-1), scores.reshape(-1))
+
+
+def extract_output_marginalized(inp, threshold, threshold_acc, ret, retgd):
+    inp = _f(inp)
+    N = inp.shape[-1]
+    P = inp.size // N
+    lib().orc_extract_output_marginalized(inp.reshape(P, N), P, N, float(threshold), float(threshold_acc), ret.reshape(-1), retgd.reshape(-1))
+
+
+def x2yx(idx, maxh, maxw):
+    idx = np.ascontiguousarray(idx, np.int64)
+    y, x = np.empty_like(idx), np.empty_like(idx)
+    lib().orc_x2yx(idx.reshape(-1), idx.size, maxh, maxw, y.reshape(-1), x.reshape(-1))
+    return y, x
+
+
+def yx2x_multi(maxh, maxw, ratios, y, x):
+    r = _r(ratios)
+    return int(lib().orc_yx2x_multi(maxh, maxw, r, len(r), float(y), float(x)))
+
+
+def x2yx_multi_number(maxh, maxw, ratios, i):
+    r = _r(ratios)
+    y, x = C.c_int64(), C.c_int64()
+    rc = lib().orc_x2yx_multi_number(maxh, maxw, r, len(r), int(i), C.byref(y), C.byref(x))
+    return rc, int(y.value), int(x.value)
+
+
+def x2yx_multi(maxh, maxw, ratios, idx):
+    r = _r(ratios)
+    idx = np.ascontiguousarray(idx, np.int64)
+    y, x = np.empty_like(idx), np.empty_like(idx)
+    rc = lib().orc_x2yx_multi(maxh, maxw, r, len(r), idx.reshape(-1), idx.size, y.reshape(-1), x.reshape(-1))
+    return rc, y, x
+
+
+def x2yx_multi_compat_c(maxh, maxw, ratios, idx, fill=0):
+    r = _r(ratios)
+    idx = np.ascontiguousarray(idx, np.int64)
+    y, x = np.full_like(idx, fill), np.full_like(idx, fill)
+    lib().orc_x2yx_multi_compat_c(maxh, maxw, r, len(r), idx.reshape(-1), idx.size, y.reshape(-1), x.reshape(-1))
+    return y, x
+
+
+def multi_nclasses(maxh, maxw, ratios):
+    r = _r(ratios)
+    return int(lib().orc_multi_nclasses(maxh, maxw, r, len(r)))
+
+
+def pyramid_scale_volume(I0, I1, r, kh, kw, maxh, maxw):
+    I0, I1 = _f(I0), _f(I1)
+    Cc, H, W = I0.shape
+    out = np.empty((H // r, W // r, maxh, maxw), np.float32)
+    lib().orc_pyramid_scale_volume(I0, I1, Cc, H, W, r, kh, kw, maxh, maxw, out)
+    return out
+
+
+def softmin(cost):
+    cost = _f(cost)
+    N = cost.shape[-1] if cost.ndim == 2 else cost.shape[-1] * cost.shape[-2]
+    P = cost.size // N
+    out = np.empty_like(cost)
+    lib().orc_softmin(cost.reshape(P, N), P, N, out.reshape(P, N))
+    return out
+
+
+def cascade_ring(probs, ratios, H, W, maxh, maxw):
+    probs = [_f(p) for p in probs]
+    r = _r(ratios)
+    ncls = multi_nclasses(maxh, maxw, ratios)
+    out = np.empty((H, W, ncls), np.float32)
+    arr = (C.c_void_p * len(probs))(*[p.ctypes.data for p in probs])
+    rc = lib().orc_cascade_ring(arr, len(probs), r, H, W, maxh, maxw, out)
+    return rc, out
+
+
+def cascading_add(ins, ratios, maxh, maxw):
+    ins = [_f(p) for p in ins]
+    P = ins[0].size // (maxh * maxw)
+    outs = [np.empty_like(p) for p in ins]
+    r = _r(ratios)
+    a = (C.c_void_p * len(ins))(*[p.ctypes.data for p in ins])
+    b = (C.c_void_p * len(ins))(*[p.ctypes.data for p in outs])
+    rc = lib().orc_cascading_add(a, len(ins), r, P, maxh, maxw, b)
+    return rc, outs
+
+
+def flow_to_depth_cartesian(flow, cx, cy, fix_dot=False):
+    flow = _f(flow)
+    _, H, W = flow.shape
+    d, c = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    lib().orc_flow_to_depth_cartesian(flow, H, W, cx, cy, int(fix_dot), d, c)
+    return d, c
+
+
+def flow_to_depth_radial(rflow, cx, cy, infty):
+    rflow = _f(rflow)
+    H, W = rflow.shape
+    d, c = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    lib().orc_flow_to_depth_radial(rflow, None, H, W, cx, cy, infty, d, c)
+    return d, c
+
+
+def polar_grid_c2p(wsrc, hsrc, wdst, hdst, xc, yc, lpad, rpad, rmax, alpha=1.0):
+    m = np.empty((2, hdst, wdst + lpad + rpad), np.float32)
+    lib().orc_polar_grid_c2p(wsrc, hsrc, wdst, hdst, xc, yc, lpad, rpad, rmax, alpha, m)
+    return m
+
+
+def polar_grid_p2c(wsrc, hsrc, wdst, hdst, xc, yc, rmax, alpha=1.0):
+    m = np.empty((2, hdst, wdst), np.float32)
+    lib().orc_polar_grid_p2c(wsrc, hsrc, wdst, hdst, xc, yc, rmax, alpha, m)
+    return m
+
+
+def warp_bilinear(img, mask):
+    img, mask = _f(img), _f(mask)
+    Cc, H, W = img.shape
+    _, Hd, Wd = mask.shape
+    out = np.empty((Cc, Hd, Wd), np.float32)
+    lib().orc_warp_bilinear(img, Cc, H, W, mask, Hd, Wd, out)
+    return out

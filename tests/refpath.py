@@ -1,0 +1,133 @@
+"""The reference's dense single-scale path composed from oracle calls (numpy), plus the
+synthetic inputs shared by the CPU and GPU tests.  Test infrastructure."""
+import math
+
+import numpy as np
+
+from tests import oracle as orc
+
+
+def middle_index(hWin, wWin):
+    # radial/radial_opticalflow_groundtruth.lua:91
+    return math.ceil(wWin / 2) + wWin * (math.ceil(hWin / 2) - 1)
+
+
+def pad_output(a, wWin, hWin, wKer, hKer):
+    # radial/radial_opticalflow_groundtruth.lua:23-35
+    l = (wWin - 1) // 2 + (wKer - 1) // 2
+    r = math.ceil((wWin - 1) / 2) + math.ceil((wKer - 1) / 2)
+    t = (hWin - 1) // 2 + (hKer - 1) // 2
+    b = math.ceil((hWin - 1) / 2) + math.ceil((hKer - 1) / 2)
+    pad = [(0, 0)] * (a.ndim - 2) + [(t, b), (l, r)]
+    return np.pad(a, pad)
+
+
+def adapt_mask(hWin, wWin, hKer, wKer, mask):
+    # radial/radial_opticalflow_groundtruth.lua:37-63
+    h, w = mask.shape
+    new = np.zeros_like(mask)
+    ls = (wWin - 1) // 2 + (wKer - 1) // 2
+    if ls > 0:
+        new[:, ls:] += mask[:, : w - ls]
+    rs = math.ceil((wWin - 1) / 2) + math.ceil((wKer - 1) / 2)
+    if rs > 0:
+        new[:, : w - rs] += mask[:, rs:]
+    ts = (hWin - 1) // 2 + (hKer - 1) // 2
+    if ts > 0:
+        new[ts:, :] += mask[: h - ts, :]
+    bs = math.ceil((hWin - 1) / 2) + math.ceil((hKer - 1) / 2)
+    if bs > 0:
+        new[: h - bs, :] += mask[bs:, :]
+    return (new > 3.9).astype(np.float32)
+
+
+def dense_flow_oracle(img1, img2, hWin, wWin, hKer, wKer, thr=0.21, via_unfold=False):
+    """compute_cartesian_groundtruth_cross_correlation (radial/radial_opticalflow_groundtruth.lua:66-112)
+    on the oracle. Returns dict(cost, idx, best, fy, fx, scores, imaxs, flowp)."""
+    if via_unfold:  # the literal reference composition: unfold -> crop -> SpatialMatching
+        u1, u2 = orc.unfold(img1, hKer, wKer), orc.unfold(img2, hKer, wKer)
+        t, b = (hWin - 1) // 2, math.ceil((hWin - 1) / 2)
+        l, r = (wWin - 1) // 2, math.ceil((wWin - 1) / 2)
+        u1c = np.ascontiguousarray(u1[:, t : u1.shape[1] - b, l : u1.shape[2] - r])
+        cost = orc.spatial_matching(u1c, u2, hWin, wWin)
+    else:
+        cost = orc.ssd_cost_volume(img1, img2, hKer, wKer, hWin, wWin)
+    Ho, Wo = cost.shape[:2]
+    vol = cost.reshape(Ho, Wo, hWin * wWin)
+    idx, best = orc.argbest_center(vol, middle_index(hWin, wWin), take_max=False)
+    y, x = orc.x2yx(idx, hWin, wWin)
+    scores = np.zeros((Ho, Wo), np.float32)
+    imaxs = np.zeros((Ho, Wo), np.int64)
+    orc.extract_output(vol, thr, imaxs, scores)
+    H, W = img1.shape[1:]
+    mask = adapt_mask(hWin, wWin, hKer, wKer, np.ones((H, W), np.float32))
+    flow = np.stack([y.astype(np.float32), x.astype(np.float32), np.ones((Ho, Wo), np.float32), scores])
+    flowp = pad_output(flow, wWin, hWin, wKer, hKer)
+    flowp[2] *= mask
+    return dict(cost=cost, idx=idx, best=best, fy=y, fx=x, scores=scores, imaxs=imaxs, flowp=flowp)
+
+
+def warp_nearest_offset(im2, flow):
+    """image.warp(im2, flow, 'nearest', true): im1(y,x) = im2(y+flow[0], x+flow[1])
+    (radial/radial_opticalflow_groundtruth.lua:172-175); out-of-frame samples clamp."""
+    C, H, W = im2.shape
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    sy = np.clip(yy + flow[0].astype(np.int64), 0, H - 1)
+    sx = np.clip(xx + flow[1].astype(np.int64), 0, W - 1)
+    return im2[:, sy, sx]
+
+
+def kat_case(case, seed=0, C=30, h=32, w=42):
+    """The four cases of cartesian_groundtruth_cc_testme (radial/radial_opticalflow_groundtruth.lua:170-210).
+    Returns (im1, im2, flowbase, (hKer, wKer, hWin, wWin))."""
+    rng = np.random.default_rng(seed + 101 * case)
+    im2 = rng.random((C, h, w), dtype=np.float32)
+    if case == 0:
+        geo = (1, 1, 12, 15)
+        fb = np.floor(rng.random((2, h, w)) * 12 - 5)
+        noise = 0.0
+    elif case == 1:
+        geo = (1, 1, 17, 15)
+        fb = np.floor(rng.random((2, h, w)) * 15 - 7)
+        noise = 0.0
+    elif case == 2:
+        geo = (3, 3, 17, 17)
+        fb = np.empty((2, h, w))
+        fb[0] = math.floor(rng.random() * 17 - 8 + 0.5)
+        fb[1] = math.floor(rng.random() * 17 - 8 + 0.5)
+        noise = 0.5
+    else:
+        geo = (5, 5, 17, 17)
+        fb = np.empty((2, h, w))
+        fb[0] = math.floor(rng.random() * 17 - 8 + 0.5)
+        fb[1] = math.floor(rng.random() * 17 - 8 + 0.5)
+        noise = 1.0
+    fb = fb.astype(np.float32)
+    im1 = warp_nearest_offset(im2, fb)
+    if noise:
+        im1 = im1 + (rng.standard_normal(im1.shape) * noise).astype(np.float32)
+    return np.ascontiguousarray(im1, np.float32), im2, fb, geo
+
+
+def synth_pair(H, W, C=3, seed=0, max_flow=12, integer=True, noise_sigma=2.0):
+    """Synthetic frame pair of SURVEY 8(d): box-smoothed uint8 noise, planted radial integer flow
+    from an off-centre focus of expansion, re-quantised noise.  frame0(p) = frame1(p + flow(p))."""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, size=(C, H + 4, W + 4)).astype(np.float64)
+    sm = np.zeros((C, H, W))
+    for i in range(5):
+        for j in range(5):
+            sm += base[:, i : i + H, j : j + W]
+    frame1 = np.round(sm / 25.0)
+    cx, cy = W / 2 + 17, H / 2 - 9
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    s = max_flow / max(cx, W - cx, cy, H - cy)
+    flow = np.stack([np.round(s * (yy - cy)), np.round(s * (xx - cx))]).astype(np.float32)
+    frame0 = warp_nearest_offset(frame1, flow)
+    if noise_sigma:
+        frame0 = np.clip(np.round(frame0 + rng.standard_normal(frame0.shape) * noise_sigma), 0, 255)
+    f0 = np.ascontiguousarray(frame0, np.float32)
+    f1 = np.ascontiguousarray(frame1, np.float32)
+    if not integer:
+        f0, f1 = f0 / np.float32(255), f1 / np.float32(255)
+    return f0, f1, flow, (cx, cy)

@@ -1,0 +1,82 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/dfe.h declares; the
+product refuses to run without a device; the product never touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = os.path.join(ROOT, "include", "dfe.h")
+PKG = os.path.join(ROOT, "depth-estimation_amd")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dfe_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound(dfe):
+    from depth_estimation_amd import _lib
+
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    l = dfe.lib()
+    for s in syms:
+        assert hasattr(l, s), "libdfe.so does not export %s" % s
+        assert s in _lib.PROTOTYPES, "no ctypes prototype for %s" % s
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (dfe_[a-z0-9_]+)", nm))
+    assert set(syms) <= exported
+    assert exported - set(syms) == set(), "exported but undeclared: %s" % (exported - set(syms))
+
+
+def test_library_is_gfx950_only():
+    from depth_estimation_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_no_device_fails_loudly(dfe):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dfe.DfeError) as e:
+        dfe.Context(0)
+    assert "no CPU fallback" in str(e.value)
+    with pytest.raises(dfe.DfeError):
+        dfe.nn.SpatialMatching(3, 3).forward([torch.zeros(2, 4, 4), torch.zeros(2, 6, 6)])
+
+
+def test_host_scalar_codec_matches_oracle(dfe, oracle):
+    # dfe_yx2x_multi / dfe_x2yx_multi_number are host-side (no device work): check against the oracle
+    for maxh, maxw, ratios in [(8, 8, [1, 2, 4]), (4, 4, [1, 2, 4, 8]), (16, 16, [1, 2, 4, 8]), (8, 8, [1, 2])]:
+        geo = dict(maxh=maxh, maxw=maxw, ratios=ratios, multiscale=True)
+        n = oracle.multi_nclasses(maxh, maxw, ratios)
+        r, nr = dfe._lib.ratios_array(ratios)
+        assert dfe.lib().dfe_multi_nclasses(maxh, maxw, r, nr) == n
+        for i in range(1, n + 1):
+            rc, y, x = oracle.x2yx_multi_number(maxh, maxw, ratios, i)
+            assert dfe.x2yxMultiNumber(geo, i) == (y, x)
+            assert dfe.yx2xMulti(geo, y, x) == i == oracle.yx2x_multi(maxh, maxw, ratios, y, x)
+        with pytest.raises(AssertionError):
+            dfe.x2yxMultiNumber(geo, n + 1)
+        assert dfe.getMiddleIndex(geo) == oracle.yx2x_multi(maxh, maxw, ratios, 0, 0)
+    assert dfe.getMiddleIndex(dict(maxh=17, maxw=17)) == 9 + 17 * 8
+    assert dfe.getMiddleIndex(dict(maxh=16, maxw=16)) == 8 + 16 * 7
+
+
+def test_product_does_not_reference_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".lua", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"dfe_oracle|libdfe_oracle|from tests|import tests|oracle/", txt):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, "product files reference the oracle: %s" % bad

@@ -1,0 +1,355 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes --
+through size-independent properties.
+
+Bars: integer-valued frames (uint8 values held in fp32) and every integer/index output are
+BIT-EXACT.  Float frames: the reference-order kernel is bit-exact too; the tiled kernel sums in a
+different order, so its cost volume is held to |gpu-cpu| <= 1e-5*|cpu| + 1e-6*max|cpu| (COST_RTOL /
+COST_ATOL_FRAC below) and its arg-min may differ only where the two best costs are within that band."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle as orc
+from tests import refpath as rp
+
+pytestmark = pytest.mark.gpu
+
+COST_RTOL = 1e-5
+COST_ATOL_FRAC = 1e-6
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "golden_v1.npz")
+
+
+def T(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def cost_close(gpu, cpu):
+    tol = COST_RTOL * np.abs(cpu) + COST_ATOL_FRAC * np.abs(cpu).max()
+    return np.abs(gpu.astype(np.float64) - cpu) <= tol
+
+
+def tie_aware_equal(idx_gpu, idx_cpu, cost_cpu):
+    """indices equal, or the gpu's pick is within the tolerance band of the cpu's best cost"""
+    vol = cost_cpu.reshape(idx_cpu.shape + (-1,))
+    pick = np.take_along_axis(vol, (idx_gpu[..., None] - 1), -1)[..., 0]
+    best = np.take_along_axis(vol, (idx_cpu[..., None] - 1), -1)[..., 0]
+    ok = (idx_gpu == idx_cpu) | (np.abs(pick - best) <= 2 * (COST_RTOL * np.abs(best) + COST_ATOL_FRAC * np.abs(vol).max()))
+    return ok
+
+
+# ------------------------------------------------------------------ cost volume, tiled kernel
+@pytest.mark.parametrize(
+    "H,W,C,k,hWin,wWin",
+    [
+        (80, 100, 3, 7, 33, 33),   # the judged configuration's kernel/window on a small frame
+        (67, 46, 3, 7, 33, 33),    # exactly one tile high (Ho=29) and one tile wide (Wo=8)
+        (70, 60, 3, 7, 17, 17),    # config 1 window
+        (64, 72, 3, 7, 16, 16),    # even window (tests/time_matching.lua uses 16x16)
+        (60, 64, 3, 7, 8, 8),      # multiscale window: exactly one wave of displacements
+        (75, 90, 1, 7, 17, 13),    # luminance frames, non-square window
+        (50, 56, 3, 5, 17, 17),
+        (40, 44, 3, 3, 9, 11),
+    ],
+)
+def test_cost_volume_tiled_bit_exact_on_integer_frames(dfe, cuda, H, W, C, k, hWin, wWin):
+    f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=H + W, max_flow=min(hWin, wWin) // 2 - 1)
+    cpu = orc.ssd_cost_volume(f0, f1, k, k, hWin, wWin)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(2)
+    try:
+        out = dfe.nn.SSDCostVolume(hWin, wWin, k, k).forward([T(f0, cuda), T(f1, cuda)])
+        assert ctx.last_kernel() == "ssd_cv_tiled_kernel"
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    gpu = out.cpu().numpy()
+    assert gpu.shape == cpu.shape
+    assert np.array_equal(gpu, cpu)
+
+
+def test_cost_volume_tiled_float_frames_within_tolerance(dfe, cuda):
+    f0, f1, _, _ = rp.synth_pair(80, 100, C=3, seed=2, integer=False)
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(2)
+    try:
+        gpu_t = dfe.nn.SSDCostVolume(33, 33, 7, 7).forward([T(f0, cuda), T(f1, cuda)])
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    gpu = gpu_t.cpu().numpy()
+    assert cost_close(gpu, cpu).all()
+    mid = rp.middle_index(33, 33)
+    idx_cpu, _ = orc.argbest_center(cpu.reshape(cpu.shape[0], cpu.shape[1], -1), mid, False)
+    idx = torch.empty(cpu.shape[:2], dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_argbest_center(ctx.handle, gpu_t.data_ptr(), idx.numel(), 33 * 33, mid, 0, idx.data_ptr(), None))
+    ok = tie_aware_equal(idx.cpu().numpy(), idx_cpu, cpu)
+    assert ok.all()
+    # and the launch geometry must not matter: same result twice, bitwise
+    ctx.set_cost_volume_kernel(2)
+    try:
+        again = dfe.nn.SSDCostVolume(33, 33, 7, 7).forward([T(f0, cuda), T(f1, cuda)]).cpu().numpy()
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    assert np.array_equal(gpu, again)
+
+
+# ------------------------------------------------------------------ reference-order kernel: bit-exact on floats
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_cost_volume_ref_kernel_bit_exact_on_floats(dfe, cuda, case):
+    im1, im2, _, (hK, wK, hW, wW) = rp.kat_case(case)
+    cpu = orc.ssd_cost_volume(im1, im2, hK, wK, hW, wW)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(1)
+    try:
+        gpu = dfe.nn.SSDCostVolume(hW, wW, hK, wK).forward([T(im1, cuda), T(im2, cuda)]).cpu().numpy()
+        assert ctx.last_kernel() == "ssd_cv_ref_kernel"
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    assert np.array_equal(gpu, cpu)
+
+
+def test_auto_dispatch_falls_back_when_frame_smaller_than_a_tile(dfe, cuda):
+    f0, f1, _, _ = rp.synth_pair(30, 40, C=3, seed=1, max_flow=2)   # Ho = 30-6-8 = 16 < 29
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 9, 9)
+    ctx = dfe.get_ctx(0)
+    gpu = dfe.nn.SSDCostVolume(9, 9, 7, 7).forward([T(f0, cuda), T(f1, cuda)]).cpu().numpy()
+    assert ctx.last_kernel() == "ssd_cv_ref_kernel"
+    assert np.array_equal(gpu, cpu)
+    ctx.set_cost_volume_kernel(2)
+    try:
+        with pytest.raises(dfe.DfeError) as e:
+            dfe.nn.SSDCostVolume(9, 9, 7, 7).forward([T(f0, cuda), T(f1, cuda)])
+        assert e.value.code == -5
+    finally:
+        ctx.set_cost_volume_kernel(0)
+
+
+# ------------------------------------------------------------------ nn.SpatialMatching / SpatialRadialMatching
+def test_spatial_matching_module_bit_exact(dfe, cuda):
+    rng = np.random.default_rng(0)
+    # tests/time_matching.lua geometry scaled down: K=10 features, 16x16 window
+    K, H1, W1, mh, mw = 10, 21, 33, 16, 16
+    in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    m = dfe.nn.SpatialMatching(mh, mw, False)
+    out = m.forward([T(in1, cuda), T(in2, cuda)])
+    assert tuple(out.shape) == (H1, W1, mh, mw) and m.output is out
+    assert np.array_equal(out.cpu().numpy(), orc.spatial_matching(in1, in2, mh, mw))
+    with pytest.raises(ValueError):
+        m.forward([T(in1, cuda), T(in2[:, :-1], cuda)])
+    with pytest.raises(TypeError):
+        m.forward([T(in1, cuda).double(), T(in2, cuda).double()])
+
+
+def test_spatial_radial_matching_module_bit_exact(dfe, cuda):
+    rng = np.random.default_rng(1)
+    K, H1, W, hWin = 10, 40, 64, 15   # radial/train_radial_opticalflow.lua:27-29 defaults: 10 features, hWin=15
+    in1 = rng.standard_normal((K, H1, W)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + hWin - 1, W)).astype(np.float32)
+    out = dfe.nn.SpatialRadialMatching(hWin).forward([T(in1, cuda), T(in2, cuda)])
+    cpu = orc.radial_matching(in1, in2, hWin)
+    assert np.array_equal(out.cpu().numpy(), cpu)
+    # consumer: test:min(3) - 1  (radial/train_radial_opticalflow.lua:166-167)
+    assert np.array_equal(out.argmin(2).cpu().numpy(), cpu.argmin(2))
+
+
+# ------------------------------------------------------------------ dense path end to end (KAT)
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_kat_planted_flow_recovered_on_gpu(dfe, cuda, case):
+    im1, im2, fb, (hK, wK, hW, wW) = rp.kat_case(case)
+    gp = dict(type="cross-correlation", params=dict(hWin=hW, wWin=wW, hKer=hK, wKer=wK))
+    flow = dfe.compute_cartesian_groundtruth_cross_correlation(gp, T(im1, cuda), T(im2, cuda)).cpu().numpy()
+    assert flow.shape == (4,) + im1.shape[1:]
+    assert flow[2].sum() > 0
+    assert np.abs((fb - flow[:2]) * flow[2]).sum() == 0   # radial/radial_opticalflow_groundtruth.lua:186-192
+    ref = rp.dense_flow_oracle(im1, im2, hW, wW, hK, wK)["flowp"]
+    assert np.array_equal(flow[:3], ref[:3])
+    assert np.allclose(flow[3], ref[3], rtol=1e-5, atol=1e-5)
+
+
+def test_fused_flow_entry_bit_exact_on_integer_frames(dfe, cuda):
+    f0, f1, flow, _ = rp.synth_pair(96, 128, C=3, seed=9, max_flow=7, noise_sigma=0)
+    ref = rp.dense_flow_oracle(f0, f1, 17, 17, 7, 7)
+    Ho, Wo = ref["idx"].shape
+    ctx = dfe.get_ctx(0)
+    idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
+    fy, fx = torch.empty_like(best), torch.empty_like(best)
+    scores = torch.full((Ho, Wo), -2.0, device=cuda)
+    imaxs = torch.full((Ho, Wo), -5, dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, T(f0, cuda).data_ptr(), T(f1, cuda).data_ptr(), 3, 96, 128, 7, 7, 17, 17, 0.21,
+                                        idx.data_ptr(), best.data_ptr(), fy.data_ptr(), fx.data_ptr(), scores.data_ptr(), imaxs.data_ptr()))
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.array_equal(best.cpu().numpy(), ref["best"])
+    assert np.array_equal(fy.cpu().numpy(), ref["fy"]) and np.array_equal(fx.cpu().numpy(), ref["fx"])
+    sc, im = np.full((Ho, Wo), -2.0, np.float32), np.full((Ho, Wo), -5, np.int64)
+    orc.extract_output(ref["cost"].reshape(Ho, Wo, -1), 0.21, im, sc)
+    assert np.array_equal(imaxs.cpu().numpy(), im) and np.array_equal(scores.cpu().numpy(), sc)
+    # noise-free planted flow is recovered wherever the source patch stayed inside the frame
+    t = 8 + 3
+    inner = (slice(t, 96 - t), slice(t, 128 - t))
+    got_y = np.pad(ref["fy"], ((t, t), (t, t)))[inner]
+    assert (np.abs(got_y - flow[0][inner]) <= 0).mean() > 0.9
+
+
+# ------------------------------------------------------------------ per-pixel consumers
+def test_argbest_center_device(dfe, cuda):
+    rng = np.random.default_rng(5)
+    for N, P in [(9, 7), (64, 300), (289, 129), (1089, 70), (160, 1000)]:
+        vol = rng.integers(0, 6, size=(P, N)).astype(np.float32)   # many exact ties
+        vol[0] = 3.0
+        mid = N // 2 + 1
+        ctx = dfe.get_ctx(0)
+        for take_max in (0, 1):
+            for middle in (mid, 0):
+                idx = torch.empty(P, dtype=torch.int64, device=cuda)
+                best = torch.empty(P, dtype=torch.float32, device=cuda)
+                ctx.check(dfe.lib().dfe_argbest_center(ctx.handle, T(vol, cuda).data_ptr(), P, N, middle, take_max, idx.data_ptr(), best.data_ptr()))
+                ei, eb = orc.argbest_center(vol, middle, take_max)
+                assert np.array_equal(idx.cpu().numpy(), ei) and np.array_equal(best.cpu().numpy(), eb)
+
+
+@pytest.mark.parametrize("N", [9, 64, 160, 289, 1089])
+@pytest.mark.parametrize("thr", [0.11, 0.21, 0.0])
+def test_extract_output_device(dfe, cuda, N, thr):
+    rng = np.random.default_rng(N)
+    H, W = 13, 17
+    x = rng.random((H, W, N)).astype(np.float32)
+    x = x / x.sum(-1, keepdims=True) * rng.choice([1.0, 4.0, 40.0], size=(H, W, 1)).astype(np.float32)
+    x[0, 0] = 0.0                # nothing above threshold -> untouched
+    x[0, 1, :5] = 0.5            # exact ties among the kept values
+    x[0, 2, N - 1] = 0.9         # the hit is the very last cell
+    scores = torch.full((H, W), -3.0, device=cuda)
+    imaxs = torch.full((H, W), -7, dtype=torch.int64, device=cuda)
+    dfe.extractoutput.extractOutput(T(x, cuda), scores, thr, imaxs)
+    es, ei = np.full((H, W), -3.0, np.float32), np.full((H, W), -7, np.int64)
+    orc.extract_output(x, thr, ei, es)
+    assert np.array_equal(imaxs.cpu().numpy(), ei)
+    assert np.array_equal(scores.cpu().numpy(), es)
+    ret = torch.full((H, W), -7, dtype=torch.int64, device=cuda)
+    gd = torch.full((H, W), 9, dtype=torch.int64, device=cuda)
+    dfe.extractoutput.extractOutputMarginalized(T(x, cuda), thr, 0.8, ret, gd)
+    er, eg = np.full((H, W), -7, np.int64), np.full((H, W), 9, np.int64)
+    orc.extract_output_marginalized(x, thr, 0.8, er, eg)
+    assert np.array_equal(ret.cpu().numpy(), er) and np.array_equal(gd.cpu().numpy(), eg)
+
+
+def test_extractoutput_argument_checks(dfe, cuda):
+    x = torch.zeros((4, 5, 9), device=cuda)
+    with pytest.raises(TypeError):
+        dfe.extractoutput.extractOutput(x.double(), torch.zeros((4, 5), device=cuda), 0.1, torch.zeros((4, 5), dtype=torch.int64, device=cuda))
+    with pytest.raises(ValueError):
+        dfe.extractoutput.extractOutput(x, torch.zeros((4, 4), device=cuda), 0.1, torch.zeros((4, 5), dtype=torch.int64, device=cuda))
+    # empty input is a no-op, not an error
+    dfe.extractoutput.extractOutput(torch.zeros((0, 5, 9), device=cuda), torch.zeros((0, 5), device=cuda), 0.1,
+                                    torch.zeros((0, 5), dtype=torch.int64, device=cuda))
+
+
+@pytest.mark.parametrize("maxh,maxw,ratios", [(8, 8, [1, 2, 4]), (4, 4, [1, 2, 4, 8]), (16, 16, [1, 2, 4, 8]), (8, 8, [1, 2]), (8, 8, [1])])
+def test_x2yx_multi_device(dfe, cuda, maxh, maxw, ratios):
+    geo = dict(maxh=maxh, maxw=maxw, ratios=ratios, multiscale=True)
+    n = orc.multi_nclasses(maxh, maxw, ratios)
+    rng = np.random.default_rng(n)
+    ids = np.concatenate([np.arange(1, n + 1), rng.integers(1, n + 1, size=1000)]).astype(np.int64).reshape(-1, 8)[: (n + 1000) // 8]
+    rety, retx = dfe.x2yxMulti(geo, T(ids, cuda))
+    _, ey, ex = orc.x2yx_multi(maxh, maxw, ratios, ids)
+    assert np.array_equal(rety.cpu().numpy(), ey) and np.array_equal(retx.cpu().numpy(), ex)
+    # round trip through the scalar encoder (tests/test_multiscale.lua:78-80)
+    for i in (1, n // 2, n):
+        y, x = dfe.x2yxMulti(geo, i)
+        assert dfe.yx2xMulti(geo, y, x) == i
+    bad = ids.copy()
+    bad[0, 0] = n + 1
+    with pytest.raises(dfe.DfeError):
+        dfe.x2yxMulti(geo, T(bad, cuda))
+    if len(ratios) > 1:
+        cy, cx = dfe.x2yxMulti2(geo, T(ids, cuda), compat_c=True)
+        oy, ox = orc.x2yx_multi_compat_c(maxh, maxw, ratios, ids, fill=0)
+        assert np.array_equal(cy.cpu().numpy(), oy) and np.array_equal(cx.cpu().numpy(), ox)
+
+
+def test_x2yx_and_process_output_single_scale(dfe, cuda):
+    rng = np.random.default_rng(2)
+    for maxh, maxw in [(17, 17), (16, 16), (12, 15)]:
+        geo = dict(maxh=maxh, maxw=maxw, multiscale=False, hImg=40, wImg=50, output_extraction_method="max")
+        H, W = 40 - maxh - 6 + 2, 50 - maxw - 6 + 2
+        prob = rng.integers(0, 4, size=(H, W, maxh * maxw)).astype(np.float32)
+        ret = dfe.processOutput(geo, T(prob, cuda), True)
+        mid = dfe.getMiddleIndex(geo)
+        ei, _ = orc.argbest_center(prob, mid, True)
+        ey, ex = orc.x2yx(ei, maxh, maxw)
+        assert np.array_equal(ret["index"].cpu().numpy(), ei)
+        assert np.array_equal(ret["y"].cpu().numpy(), ey) and np.array_equal(ret["x"].cpu().numpy(), ex)
+        full = ret["full"].cpu().numpy()
+        ho, wo = (40 - H) // 2, (50 - W) // 2
+        assert np.array_equal(full[0, ho : ho + H, wo : wo + W], ey.astype(np.float32))
+        assert full[:, :ho].sum() == 0 and full[:, :, :wo].sum() == 0
+        ty, tx = dfe.x2yx(geo, T(ei, cuda))
+        assert np.array_equal(ty.cpu().numpy(), (ei - 1) // maxw + 1) and np.array_equal(tx.cpu().numpy(), (ei - 1) % maxw + 1)
+
+
+# ------------------------------------------------------------------ golden fixtures
+def test_golden_fixtures_on_gpu(dfe, cuda):
+    g = np.load(GOLD)
+    hK, wK, hW, wW = [int(v) for v in g["kat3_geo"]]
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(1)
+    try:
+        out = dfe.nn.SSDCostVolume(hW, wW, hK, wK).forward([T(g["kat3_im1"], cuda), T(g["kat3_im2"], cuda)]).cpu().numpy()
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    assert np.array_equal(out, g["kat3_cost"])
+    out = dfe.nn.SSDCostVolume(9, 9, 7, 7).forward([T(g["int_f0"], cuda), T(g["int_f1"], cuda)])
+    assert ctx.last_kernel() == "ssd_cv_tiled_kernel"
+    assert np.array_equal(out.cpu().numpy(), g["int_cost"])
+    Ho, Wo = g["int_idx"].shape
+    idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_argbest_center(ctx.handle, out.data_ptr(), Ho * Wo, 81, rp.middle_index(9, 9), 0, idx.data_ptr(), None))
+    assert np.array_equal(idx.cpu().numpy(), g["int_idx"])
+    ids = torch.arange(1, 161, dtype=torch.int64, device=cuda)
+    geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4])
+    y, x = dfe.x2yxMulti2(geo, ids)
+    assert np.array_equal(y.cpu().numpy(), g["codec_8_8_124_y"]) and np.array_equal(x.cpu().numpy(), g["codec_8_8_124_x"])
+
+
+# ------------------------------------------------------------------ full size (BASELINE configs[1]): properties
+def test_full_vga_cost_volume_properties(dfe, cuda):
+    """640x480, C=3, 7x7 patch, 33x33 window: (a) tiled == reference-order kernel bitwise on integer
+    frames (two independent formulations, 1.16 GB each); (b) oracle agreement on a band of rows;
+    (c) cost(I,I) is zero exactly at the centre cell; (d) the planted flow is the arg-min."""
+    H, W, k, win = 480, 640, 7, 33
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=0, max_flow=12, noise_sigma=0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx = dfe.get_ctx(0)
+    op = dfe.nn.SSDCostVolume(win, win, k, k)
+    ctx.set_cost_volume_kernel(2)
+    try:
+        tiled = op.forward([t0, t1])
+        assert ctx.last_kernel() == "ssd_cv_tiled_kernel"
+        ctx.set_cost_volume_kernel(1)
+        ref = op.forward([t0, t1])
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    assert tuple(tiled.shape) == (442, 602, 33, 33)
+    assert torch.equal(tiled, ref)
+    del ref
+    rows = (0, 3, 200, 203, 439, 442)
+    for r0, r1 in zip(rows[::2], rows[1::2]):
+        cpu = np.zeros((442, 602, 33, 33), np.float32)[r0:r1] * 0
+        band = orc.ssd_cost_volume(f0[:, r0 : r1 + 38], f1[:, r0 : r1 + 38], k, k, win, win)
+        assert np.array_equal(tiled[r0:r1].cpu().numpy(), band)
+    mid = rp.middle_index(win, win)
+    idx = torch.empty((442, 602), dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_argbest_center(ctx.handle, tiled.data_ptr(), idx.numel(), win * win, mid, 0, idx.data_ptr(), None))
+    y, x = dfe.x2yx(dict(maxh=win, maxw=win), idx)
+    y, x = (y - 17).cpu().numpy(), (x - 17).cpu().numpy()     # 1-based cell -> centred displacement
+    inner = (slice(12, 442 - 12), slice(12, 602 - 12))
+    py, px = flow[0][19:-19, 19:-19], flow[1][19:-19, 19:-19]
+    assert ((y == py) & (x == px))[inner].mean() > 0.97   # smooth-texture ties aside, the plant is recovered
+    del tiled
+    same = op.forward([t1, t1])
+    centre = same.reshape(442, 602, -1)[:, :, mid - 1]
+    assert float(centre.abs().max()) == 0.0 and float(same.min()) == 0.0

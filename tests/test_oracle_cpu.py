@@ -1,0 +1,241 @@
+"""CPU suite (-m "not gpu"): pins the oracle against the reference's own data-free known-answer
+tests and the committed golden fixtures.  No GPU, no /root/reference access."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle as orc
+from tests import refpath as rp
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# --- cartesian_groundtruth_cc_testme (radial/radial_opticalflow_groundtruth.lua:170-210) ----------
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+@pytest.mark.parametrize("via_unfold", [False, True])
+def test_kat_planted_flow_recovered(case, via_unfold):
+    im1, im2, fb, (hK, wK, hW, wW) = rp.kat_case(case)
+    res = rp.dense_flow_oracle(im1, im2, hW, wW, hK, wK, via_unfold=via_unfold)
+    flow = res["flowp"]
+    diff = (fb - flow[:2]) * flow[2]
+    assert flow.shape == (4,) + im1.shape[1:]
+    assert flow[2].sum() > 0
+    assert np.abs(diff).sum() == 0  # :186-192
+
+
+def test_unfold_matches_fused_volume_bitwise():
+    # A0+A1 fused restatement == the literal unfold -> crop -> SpatialMatching composition
+    im1, im2, _, (hK, wK, hW, wW) = rp.kat_case(3)
+    a = rp.dense_flow_oracle(im1, im2, hW, wW, hK, wK, via_unfold=False)["cost"]
+    b = rp.dense_flow_oracle(im1, im2, hW, wW, hK, wK, via_unfold=True)["cost"]
+    assert np.array_equal(a, b)
+
+
+def test_even_window_asymmetric_range():
+    # hWin=12 -> displacements -5..+6; decode of first / last class
+    y, x = orc.x2yx(np.array([1, 12 * 15], np.int64), 12, 15)
+    assert (y[0], x[0]) == (-5, -7) and (y[1], x[1]) == (6, 7)
+
+
+# --- SpatialMatching == brute-force SSD (tests/test_multiscale.lua:135-166) ----------------------
+def test_matching_equals_bruteforce_ssd():
+    rng = np.random.default_rng(3)
+    K, H1, W1, mh, mw = 5, 6, 7, 4, 3
+    in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    out = orc.spatial_matching(in1, in2, mh, mw)
+    for y in range(H1):
+        for x in range(W1):
+            best, ib, jb = 1e25, 0, 0
+            for i in range(mh):
+                for j in range(mw):
+                    s = float(((in1[:, y, x].astype(np.float64) - in2[:, y + i, x + j]) ** 2).sum())
+                    assert abs(out[y, x, i, j] - s) <= 1e-5 * max(1.0, s)
+                    if s < best:
+                        best, ib, jb = s, i, j
+            m = int(out[y, x].reshape(-1).argmin())
+            assert (m // mw, m % mw) == (ib, jb)  # :161-165
+
+
+def test_radial_matching_is_vertical_only():
+    rng = np.random.default_rng(4)
+    K, H1, W, hw = 4, 9, 11, 5
+    in1 = rng.standard_normal((K, H1, W)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + hw - 1, W)).astype(np.float32)
+    out = orc.radial_matching(in1, in2, hw)
+    ref = np.stack([((in1 - in2[:, d : d + H1]) ** 2).sum(0) for d in range(hw)], -1)
+    assert np.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+# --- centre tie-break (radial/radial_opticalflow_groundtruth.lua:88-94) -------------------------
+def test_argbest_center_tie_break_and_first_wins():
+    N = 9
+    vol = np.array([[3, 1, 5, 1, 1, 7, 1, 9, 9],      # min 1 at cells 2,4,5,7 (1-based); centre=5 ties -> 5
+                    [3, 1, 5, 1, 2, 7, 1, 9, 9],      # centre (2) is not the min -> first min = 2
+                    [0, 0, 0, 0, 0, 0, 0, 0, 0]], np.float32)
+    idx, best = orc.argbest_center(vol, 5, take_max=False)
+    assert idx.tolist() == [5, 2, 5] and best.tolist() == [1, 1, 0]
+    idx, _ = orc.argbest_center(vol, 5, take_max=True)
+    assert idx.tolist() == [8, 8, 5]
+    idx, _ = orc.argbest_center(vol, 0, take_max=False)  # override disabled
+    assert idx.tolist() == [2, 2, 1]
+
+
+# --- extractOutput: hand-derived from extract_output.cpp:63-155 ---------------------------------
+def test_extract_output_hand_vector():
+    v = np.array([[0.05, 0.15, 0.12, 0.05, 0.9, 0.25, 0.2, 0.225, 0.3],   # thr .11 -> M=8: keeps .15 .12 .9 .25 .2 .225 .3
+                  [0.0, 0.05, 0.1, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0]], np.float32)  # nothing above -> untouched
+    imaxs = np.full(2, -7, np.int64)
+    scores = np.full(2, -3.0, np.float32)
+    orc.extract_output(v, 0.11, imaxs, scores)
+    srt = sorted([0.15, 0.12, 0.9, 0.25, 0.2, 0.225, 0.3], reverse=True) + [0.0]
+    expect = sum(np.cumsum(np.array(srt, np.float32), dtype=np.float32).astype(np.float64))
+    assert imaxs.tolist() == [5, -7]
+    assert scores[1] == -3.0
+    assert abs(scores[0] - expect) < 1e-6
+    # thr >= .2 -> M=4, scan stops after the 4th hit (.9 .25 .225 .3 in index order; .2 is not > .2f? it is > 0.2 as float)
+    imaxs[:] = -7
+    scores[:] = -3
+    orc.extract_output(v, 0.21, imaxs, scores)
+    kept = [0.9, 0.25, 0.225, 0.3]
+    srt = sorted(kept, reverse=True)
+    expect = sum(np.cumsum(np.array(srt, np.float32), dtype=np.float32).astype(np.float64))
+    assert imaxs[0] == 5 and abs(scores[0] - expect) < 1e-6
+
+
+def test_extract_output_tie_order_follows_network():
+    # equal keys never swap (sortswap uses strict >): with 4 equal values the index that ends up
+    # first is the one the fixed network leaves in slot 0, i.e. the first kept.
+    v = np.array([[0.5, 0.5, 0.5, 0.5, 0.1]], np.float32)
+    imaxs = np.zeros(1, np.int64)
+    scores = np.zeros(1, np.float32)
+    orc.extract_output(v, 0.3, imaxs, scores)
+    assert imaxs[0] == 1 and abs(scores[0] - (0.5 + 1.0 + 1.5 + 2.0)) < 1e-6
+    v = np.array([[0.4, 0.5, 0.5, 0.45, 0.1]], np.float32)   # network: (0,2)(1,3)(0,1)(2,3)(1,2)
+    orc.extract_output(v, 0.3, imaxs, scores)
+    assert imaxs[0] == 3  # after (0,2) swap slot0 holds index 3 (value .5); (0,1): .5 > .5 false -> stays
+
+
+def test_extract_marginalized():
+    v = np.array([[0.3, 0.3, 0.0, 0.0], [0.0, 0.0, 0.0, 0.0]], np.float32)
+    ret = np.full(2, -1, np.int64)
+    gd = np.full(2, 5, np.int64)
+    orc.extract_output_marginalized(v, 0.25, 0.8, ret, gd)
+    assert ret.tolist() == [1, -1] and gd.tolist() == [1, 0]   # acc = .3+.6+.6+.6 = 2.1 >= .8
+
+
+# --- multiscale codec (tests/test_multiscale.lua:57-80) -----------------------------------------
+GEOS = [(8, 8, [1, 2]), (8, 8, [1, 2, 4]), (4, 4, [1, 2, 4, 8]), (16, 16, [1, 2, 4, 8]), (8, 8, [1])]
+
+
+@pytest.mark.parametrize("maxh,maxw,ratios", GEOS)
+def test_codec_round_trip(maxh, maxw, ratios):
+    mh, mw = maxh * ratios[-1], maxw * ratios[-1]
+    for i in range(-math.ceil(mh / 2) + 1, mh // 2 + 1):
+        for j in range(-math.ceil(mw / 2) + 1, mw // 2 + 1):
+            rc, y, x = orc.x2yx_multi_number(maxh, maxw, ratios, orc.yx2x_multi(maxh, maxw, ratios, i, j))
+            assert rc == 0
+            tol = None
+            for r in ratios:
+                if abs(i) < maxh * r and abs(j) < maxw * r:
+                    tol = r
+            assert abs(y - i) < tol and abs(x - j) < tol   # :61-71
+    maxx = maxh * maxw
+    for k in range(1, len(ratios)):
+        maxx += maxh * maxw * (1 - (ratios[k - 1] / ratios[k]) ** 2)
+    assert orc.multi_nclasses(maxh, maxw, ratios) == int(maxx)
+    for i in range(1, int(maxx) + 1):
+        rc, y, x = orc.x2yx_multi_number(maxh, maxw, ratios, i)
+        assert rc == 0 and orc.yx2x_multi(maxh, maxw, ratios, y, x) == i   # :78-80
+    assert orc.x2yx_multi_number(maxh, maxw, ratios, int(maxx) + 1)[0] != 0
+    assert orc.x2yx_multi_number(maxh, maxw, ratios, 0)[0] != 0
+
+
+def test_codec_known_values_and_compat():
+    # (8,8,{1,2,4}): 160 classes, middleIndex 28, id 65 -> (-6,-6), reach -12..+16
+    assert orc.multi_nclasses(8, 8, [1, 2, 4]) == 160
+    assert orc.yx2x_multi(8, 8, [1, 2, 4], 0, 0) == 28
+    assert orc.x2yx_multi_number(8, 8, [1, 2, 4], 65)[1:] == (-6, -6)
+    assert orc.x2yx_multi_number(8, 8, [1, 2, 4], 113)[1:] == (-12, -12)
+    assert orc.x2yx_multi_number(8, 8, [1, 2, 4], 160)[1:] == (16, 16)
+    # the shipped vectorised C body diverges (x2yxMulti2.c): id 65 -> (-3,-3), ids 151..160 never written
+    ids = np.arange(1, 161, dtype=np.int64)
+    y, x = orc.x2yx_multi_compat_c(8, 8, [1, 2, 4], ids, fill=-999)
+    assert (y[64], x[64]) == (-3, -3)
+    assert (y[150:] == -999).all() and (x[150:] == -999).all()
+
+
+# --- cascade (CascadingAddTable.lua:108-135, tests/test_multiscale.lua:169-193 with HEAD's sum) --
+def test_cascading_add_matches_definition():
+    rng = np.random.default_rng(7)
+    ratios, mh, mw, P = [1, 2, 4], 8, 8, 5
+    ins = [rng.random((P, mh, mw), dtype=np.float32) for _ in ratios]
+    rc, outs = orc.cascading_add(ins, ratios, mh, mw)
+    assert rc == 0
+    cy, cx = math.ceil(mh / 2), math.ceil(mw / 2)
+    assert np.array_equal(outs[-1], ins[-1])
+    for i in range(len(ratios)):
+        s = np.zeros((P, mh, mw), np.float64)
+        for ii in range(-cy + 1, cy + 1):
+            for jj in range(-cx + 1, cx + 1):
+                for j in range(i, len(ratios)):
+                    r = ratios[j] // ratios[i]
+                    s[:, ii + cy - 1, jj + cx - 1] += ins[j][:, math.ceil(ii / r) + cy - 1, math.ceil(jj / r) + cx - 1]
+        assert np.allclose(outs[i], s, atol=1e-5)   # :176-186 (sum, not mean: HEAD)
+    rc, _ = orc.cascading_add([np.zeros((1, 2, 2), np.float32)] * 2, [1, 2], 2, 2)
+    assert rc != 0   # CascadingAddTable.lua:121-124 incompatibility error
+
+
+def test_ring_layout_matches_codec():
+    # class k of the ring-extracted vector must be the cascade cell that x2yxMultiNumber(k) decodes to
+    ratios, mh, mw, H, W = [1, 2, 4], 8, 8, 4, 8
+    probs = []
+    for s, r in enumerate(ratios):
+        a = np.zeros((H // r, W // r, mh, mw), np.float32)
+        for ty in range(mh):
+            for tx in range(mw):
+                a[:, :, ty, tx] = 1000 * (s + 1) + 10 * ty + tx   # encodes (scale, cell)
+        probs.append(a)
+    # disable accumulation effects: compare on the coarsest-only contribution by zeroing finer scales' adds
+    rc, out = orc.cascade_ring(probs, ratios, H, W, mh, mw)
+    assert rc == 0 and out.shape == (H, W, 160)
+    rc2, casc = orc.cascading_add([np.repeat(np.repeat(p, r, 0), r, 1).reshape(-1, mh, mw) for p, r in zip(probs, ratios)], ratios, mh, mw)
+    for k in range(1, 161):
+        _, y, x = orc.x2yx_multi_number(mh, mw, ratios, k)
+        s = 0 if k <= 64 else (1 if k <= 112 else 2)
+        ty, tx = y // ratios[s] + math.ceil(mh / 2) - 1, x // ratios[s] + math.ceil(mw / 2) - 1
+        assert out[0, 0, k - 1] == casc[s][0, ty, tx]
+
+
+# --- flow -> depth ------------------------------------------------------------------------------
+def test_flow_to_depth_cartesian_quirk():
+    H, W = 4, 6
+    flow = np.zeros((2, H, W), np.float32)
+    flow[0] = 1.0   # dy
+    flow[1] = 0.5   # dx
+    d, c = orc.flow_to_depth_cartesian(flow, W / 2, H / 2)
+    dn = math.sqrt(1.25)
+    assert abs(d[0, 0] - min(math.sqrt(9 + 4) / dn, W / 2)) < 1e-5
+    assert c[0, 0] == (1.0 if (-3 * 0.5 + 1.0) > 0.125 else 0.0)   # px*dx + dy*dy (sic), test_opticalflow.lua:181
+    d2, c2 = orc.flow_to_depth_cartesian(np.zeros((2, H, W), np.float32), W / 2, H / 2)
+    assert (d2 == W / 2).all() and (c2 == 1).all()
+
+
+# --- golden fixtures ----------------------------------------------------------------------------
+def test_golden_fixtures_reproduce():
+    path = os.path.join(GOLD, "golden_v1.npz")
+    assert os.path.exists(path), "run tests/golden/make_golden.py"
+    g = np.load(path)
+    im1, im2, _, (hK, wK, hW, wW) = rp.kat_case(3, seed=5, C=3, h=24, w=28)
+    assert np.array_equal(g["kat3_im1"], im1)
+    res = rp.dense_flow_oracle(im1, im2, hW, wW, hK, wK)
+    for k in ("cost", "idx", "scores", "imaxs"):
+        assert np.array_equal(g["kat3_" + k], res[k]), k
+    ids = np.arange(1, 161, dtype=np.int64)
+    _, y, x = orc.x2yx_multi(8, 8, [1, 2, 4], ids)
+    assert np.array_equal(g["codec_8_8_124_y"], y) and np.array_equal(g["codec_8_8_124_x"], x)
+    yc, xc = orc.x2yx_multi_compat_c(8, 8, [1, 2, 4], ids, fill=-999)
+    assert np.array_equal(g["codec_compat_y"], yc) and np.array_equal(g["codec_compat_x"], xc)
