@@ -64,8 +64,9 @@ def cpu_baseline(f0, f1, k, hWin, wWin, cx, cy, budget_s=12.0):
         orc.flow_to_depth_cartesian(flow, cx, cy)
         return time.perf_counter() - t
 
-    t2 = run(2)
-    rows = int(max(2, min(Ho, round(2 * budget_s / max(t2, 1e-6)))))
+    run(1)  # start the OpenMP team
+    t8 = run(8)
+    rows = int(max(8, min(Ho, round(8 * budget_s / max(t8, 1e-6)))))
     t = run(rows)
     mpix = (H * W * rows / Ho) / t / 1e6
     return {

@@ -16,7 +16,7 @@ c_i32p = C.POINTER(C.c_int)
 # name -> (restype, argtypes); must list every symbol include/dfe.h declares
 PROTOTYPES = {
     "dfe_version": (C.c_int, []),
-    "dfe_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dfe_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "dfe_ctx_destroy": (None, [C.c_void_p]),
     "dfe_last_error": (C.c_char_p, [C.c_void_p]),
     "dfe_ctx_synchronize": (C.c_int, [C.c_void_p]),
@@ -48,6 +48,7 @@ PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_double] + [C.c_void_p] * 6,
     ),
+    "dfe_set_scratch_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dfe_flow_tail": (

@@ -9,10 +9,12 @@ _ctxs = {}
 class Context:
     """Owns a dfe_ctx bound to a HIP device and stream (include/dfe.h: dfe_ctx_create)."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, own_stream=False):
+        """stream: a hipStream_t as an integer (0/None = the default stream, torch's default);
+        own_stream=True makes the ctx create a private non-blocking stream instead."""
         l = lib()
         h = C.c_void_p()
-        rc = l.dfe_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        rc = l.dfe_ctx_create(int(device), C.c_void_p(stream) if stream else None, 1 if own_stream else 0, C.byref(h))
         if rc != DFE_OK:
             raise DfeError(rc, l.dfe_last_error(None).decode())
         self.handle = h

@@ -32,7 +32,7 @@ extern "C" {
 
 int dfe_version(void) { return 100; }
 
-int dfe_ctx_create(int device, void *stream, dfe_ctx **out) {
+int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     if (!out) return dfe_fail(nullptr, DFE_E_ARG, "dfe_ctx_create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -50,8 +50,8 @@ int dfe_ctx_create(int device, void *stream, dfe_ctx **out) {
         return dfe_fail(nullptr, DFE_E_UNSUPPORTED, "device %d is %s; libdfe ships gfx950 code only", device, prop.gcnArchName);
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
+    if (!own_stream) {
+        ctx->stream = (hipStream_t)stream;   // NULL = the default stream
     } else {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete ctx; return dfe_fail(nullptr, DFE_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -120,6 +120,13 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
 }
 
 const char *dfe_last_kernel(const dfe_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
+
+int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, bytes >= ((size_t)1 << 20), DFE_E_ARG, "scratch limit %zu below 1 MiB", bytes);
+    ctx->scratch_limit = bytes;
+    return DFE_OK;
+}
 
 int dfe_profile_enable(dfe_ctx *ctx, int on) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");

@@ -15,6 +15,7 @@ struct dfe_ctx {
     const char *last_kernel = "";
     void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)
     size_t scratch_bytes = 0;
+    size_t scratch_limit = (size_t)16 << 30;   // cost-volume bands are sized to fit (dfe_set_scratch_limit)
     int *dflag = nullptr;             // one device int for error flags raised by kernels
     char err[512] = {0};
     // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)

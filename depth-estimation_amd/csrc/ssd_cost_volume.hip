@@ -314,10 +314,11 @@ int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     return cv_frames_dispatch(ctx, I0, I1, C, H, W, (long long)H * W, kh, kw, hWin, wWin, out);
 }
 
-// rows of the output volume that fit a <= 1 GiB scratch band
-static int band_rows(int Ho, int Wo, int D) {
+// rows of the output volume that fit one scratch band (ctx->scratch_limit, 16 GiB by default:
+// one launch per pair up to 1080p/33x33; 288 GB of HBM make the whole volume the natural unit)
+static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D) {
     long long row_bytes = (long long)Wo * D * sizeof(float);
-    long long band = (1ll << 30) / row_bytes;
+    long long band = (long long)ctx->scratch_limit / row_bytes;
     if (band < 1) band = 1;
     if (band > Ho) band = Ho;
     return (int)band;
@@ -335,7 +336,7 @@ int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int 
                 H, W, kh, kw, hWin, wWin);
     DFE_REQUIRE(ctx, (scores == nullptr) == (imaxs == nullptr), DFE_E_ARG, "dfe_ssd_flow_f32: scores and imaxs go together");
     const int D = hWin * wWin;
-    const int band = band_rows(Ho, Wo, D);
+    const int band = band_rows(ctx, Ho, Wo, D);
     void *scr = nullptr;
     int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
     if (rc) return rc;
@@ -372,7 +373,7 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     const int pad_t = (H - Ho) / 2, pad_l = (W - Wo) / 2;
     DFE_HIP(ctx, hipMemsetAsync(flow, 0, 2 * HW * sizeof(float), ctx->stream));
     if (scores) DFE_HIP(ctx, hipMemsetAsync(scores, 0, HW * sizeof(float), ctx->stream));
-    const int band = band_rows(Ho, Wo, D);
+    const int band = band_rows(ctx, Ho, Wo, D);
     void *scr = nullptr;
     int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
     if (rc) return rc;

@@ -42,8 +42,10 @@ typedef struct dfe_ctx dfe_ctx;
 
 /* ---- context, memory --------------------------------------------------- */
 int dfe_version(void);
-/* stream == NULL: the ctx creates its own non-blocking stream; otherwise the caller's hipStream_t */
-int dfe_ctx_create(int device, void *stream, dfe_ctx **out);
+/* own_stream != 0: the ctx creates (and owns) a private non-blocking stream, `stream` is ignored;
+ * own_stream == 0: work is enqueued on the caller's hipStream_t `stream` (NULL = the HIP default
+ * stream, which is what torch's default stream is) so it is ordered with the caller's other work */
+int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out);
 void dfe_ctx_destroy(dfe_ctx *ctx);
 const char *dfe_last_error(const dfe_ctx *ctx); /* ctx may be NULL: last creation error */
 int dfe_ctx_synchronize(dfe_ctx *ctx);
@@ -59,6 +61,9 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
 /* name of the kernel the last cost-volume call launched (static string) */
 const char *dfe_last_kernel(const dfe_ctx *ctx);
 
+/* upper bound for the ctx scratch arena that holds a materialised cost volume inside the one-call
+ * pipelines (default 16 GiB); larger volumes are processed in bands of output rows */
+int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 /* per-launch HIP-event timing of the cost-volume kernel on the ctx stream (bench.py's roofline):
  * enable, run, then read the summed kernel time and launch count (read synchronises and resets) */
 int dfe_profile_enable(dfe_ctx *ctx, int on);
@@ -161,7 +166,7 @@ int dfe_flow_to_depth_cartesian(dfe_ctx *ctx, const float *flow, int H, int W, f
  *   test_opticalflow.lua:349-355 flow -> depth) for the single-scale raw-patch matcher.
  * flow [2][H][W], scores [H][W], depth [H][W], depth_conf [H][W]: full-frame, zero outside the
  * centre-pasted Ho x Wo region (opticalflow_model.lua:227-249).  The cost volume is materialised
- * in ctx scratch (<= 1 GiB bands) by dfe_ssd_cost_volume_f32's kernel and consumed by dfe_flow_tail. */
+ * in ctx scratch (bands of output rows within dfe_set_scratch_limit) by dfe_ssd_cost_volume_f32's kernel and consumed by dfe_flow_tail. */
 int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
                             int k, int hWin, int wWin, float foe_x, float foe_y,
                             double extract_threshold, float *flow, float *scores, float *depth,

@@ -27,7 +27,7 @@ out.update(codec_8_8_124_y=y, codec_8_8_124_x=x)
 yc, xc = orc.x2yx_multi_compat_c(8, 8, [1, 2, 4], ids, fill=-999)
 out.update(codec_compat_y=yc, codec_compat_x=xc)
 # integer-valued frame pair (bit-exact regime) with 7x7 patch, 9x9 window
-f0, f1, flow, foe = rp.synth_pair(40, 48, C=3, seed=11, max_flow=3)
+f0, f1, flow, foe = rp.synth_pair(48, 56, C=3, seed=11, max_flow=3)
 r = rp.dense_flow_oracle(f0, f1, 9, 9, 7, 7)
 out.update(int_f0=f0, int_f1=f1, int_cost=r["cost"], int_idx=r["idx"], int_scores=r["scores"], int_imaxs=r["imaxs"])
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
