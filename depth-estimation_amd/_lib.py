@@ -26,6 +26,7 @@ PROTOTYPES = {
     "dfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),
     "dfe_ssd_cost_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "dfe_spatial_matching_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),

@@ -31,6 +31,10 @@ class Context:
         """0 auto, 1 reference-order kernel, 2 tiled kernel only."""
         self.check(lib().dfe_set_cost_volume_kernel(self.handle, int(mode)))
 
+    def set_cost_volume_tile(self, tyq):
+        """0 = tile height chosen per shape; 2..5 forces it (tuning / tests)."""
+        self.check(lib().dfe_set_cost_volume_tile(self.handle, int(tyq)))
+
     def last_kernel(self):
         return lib().dfe_last_kernel(self.handle).decode()
 

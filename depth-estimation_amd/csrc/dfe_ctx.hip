@@ -1,5 +1,6 @@
 // dfe_ctx.hip -- context, error text, device memory helpers of the C ABI (include/dfe.h).
 #include "dfe_internal.h"
+#include <cstdlib>
 
 static thread_local char g_create_err[512] = "";
 
@@ -50,6 +51,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
         return dfe_fail(nullptr, DFE_E_UNSUPPORTED, "device %d is %s; libdfe ships gfx950 code only", device, prop.gcnArchName);
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
+    ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (!own_stream) {
         ctx->stream = (hipStream_t)stream;   // NULL = the default stream
     } else {
@@ -116,6 +118,13 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
     DFE_REQUIRE(ctx, mode >= 0 && mode <= 2, DFE_E_ARG, "cost-volume kernel mode %d not in 0..2", mode);
     ctx->cv_mode = mode;
+    return DFE_OK;
+}
+
+int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, tyq == 0 || (tyq >= 2 && tyq <= 5), DFE_E_ARG, "tile height code %d not 0 or 2..5", tyq);
+    ctx->cv_tyq = tyq;
     return DFE_OK;
 }
 

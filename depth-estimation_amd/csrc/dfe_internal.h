@@ -12,6 +12,8 @@ struct dfe_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cv_mode = 0;                  // dfe_set_cost_volume_kernel
+    int cv_tyq = 0;                   // 0 = pick the tile height per shape; 2..5 = force (tuning / tests)
+    int ncu = 256;                    // compute units of the device
     const char *last_kernel = "";
     void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)
     size_t scratch_bytes = 0;

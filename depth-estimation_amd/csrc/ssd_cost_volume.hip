@@ -147,25 +147,47 @@ template <int N, int OFF = 0> __device__ __forceinline__ void uload(cfptr p, flo
 struct CvTiledArgs {
     int H, W, hWin, wWin, Ho, Wo;
     long long plane;   // channel plane stride in elements (H*W of the full frame, also for row bands)
-    int pitch;   // LDS row pitch in pixels
-    int lrows;   // LDS rows = TYQ*K + hWin - 1
-    int lcols;   // staged columns = TX + K - 1 + wWin - 1
+    int pitch;         // LDS row pitch in pixels
+    int lrows;         // LDS rows = ROWS + hWin - 1
+    int lcols;         // staged columns = TX + K - 1 + wWin - 1
+    int stage_off;     // byte offset of the store-exchange stage inside dynamic LDS
 };
 
 extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 
-// TYQ*K image rows are swept per tile -> TY = TYQ*K-(K-1) output rows.
-template <int C, int K, int TX, int TYQ, int NW>
+
+// global_store_dword with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset:
+// no VALU address arithmetic per store.  Nothing in the kernel reads what it stores, and stores
+// need no wait before s_endpgm, so the compiler's vmcnt bookkeeping is not involved.
+__device__ __forceinline__ void store_uniform_base(const void *base, unsigned lane_bytes, float v) {
+    asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_bytes), "v"(v), "s"(base) : "memory");
+}
+
+// Rows are swept in groups of U (the unroll that makes every ring index static):
+//   K == 7: U = 6, vertical sum as the fixed tree ((H0+H1)+(H2+H3))+((H4+H5)+H6) kept as a ring of six
+//           pair sums P_r = H_r + H_{r+1}  -> 4 adds per output;
+//   else  : U = K, ring of K horizontal sums added oldest-first -> K-1 adds per output.
+// Either way the association is fixed relative to the output pixel, so results do not depend on tiling.
+template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K; };
+
+// A block owns NT horizontally adjacent TX-pixel tiles (one staged frame-1 tile for all of them) and
+// TY = U*NQ-(K-1) output rows; its NT*nchunks (tile, 64-displacement chunk) tasks are dealt to NW waves,
+// which then run independently (no barrier after the staging one).
+template <int C, int K, int TX, int NT, int NW, int NQ>
 __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
                                                                float *__restrict__ out, CvTiledArgs p) {
     using px_t = typename Px<C>::type;
-    constexpr int TY = TYQ * K - (K - 1);
+    constexpr int U = VUnroll<K>::value;
+    constexpr int ROWS = U * NQ;
+    constexpr int TY = ROWS - (K - 1);
+    constexpr int GX = NT * TX;
+    constexpr int NE = TX + K - 1;
     px_t *lds = reinterpret_cast<px_t *>(dfe_smem);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0n = blockIdx.x * TX, y0n = blockIdx.y * TY;           // nominal origin: what this tile stores
-    const int x0 = min(x0n, p.Wo - TX), y0 = min(y0n, p.Ho - TY);      // shifted origin: what it computes
+    const int x0n = blockIdx.x * GX, y0n = blockIdx.y * TY;           // nominal origin
+    const int x0 = min(x0n, p.Wo - GX), y0 = min(y0n, p.Ho - TY);      // shifted inwards at the frame edge
     const long long HW = p.plane;
 
     // ---- stage the frame-1 tile: rows y0.., cols x0.. (always inside the frame, see header) ----
@@ -183,54 +205,107 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 
     const int D = p.hWin * p.wWin;
     const int nchunks = (D + 63) >> 6;
+    const int ntasks = NT * nchunks;
     const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
-    for (int chunk = wave; chunk < nchunks; chunk += NW) {
+    for (int task = wave; task < ntasks; task += NW) {
+        const int tile = task / nchunks;                       // wave-uniform
+        const int chunk = task - tile * nchunks;
+        const int xt = x0 + tile * TX;                         // first output column of this task
         const int d = chunk * 64 + lane;
-        if (d < D) {   // one divergent region per chunk (only the last chunk is partial): no per-store branch
+        if (d < D) {   // one divergent region per task (only the last chunk is partial)
             const int dy = d / p.wWin, dx = d - dy * p.wWin;
-            const px_t *lp = lds + dy * p.pitch + dx;
-            const unsigned dbytes = (unsigned)d * 4u;   // 32-bit lane offset -> saddr+voffset stores
+            const px_t *lp = lds + dy * p.pitch + dx + tile * TX;
+            const unsigned dbytes = (unsigned)d * 4u;
 
-            float ring[K][TX];
+            // frame-0 rows come through the scalar cache; row r+1 is requested right after row r's
+            // squared differences are done, so its latency hides behind the box sums and stores, and no
+            // SMEM load is in flight while LDS results are waited for (SMEM returns out of order, which
+            // would force a full lgkmcnt(0) drain per LDS read).
+            const long long a_base = (long long)(y0 + oy) * p.W + (xt + ox);
+            float av[C][NE];
 #pragma unroll
-            for (int i = 0; i < K; ++i)
-#pragma unroll
-                for (int x = 0; x < TX; ++x) ring[i][x] = 0.f;
+            for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + c * HW), av[c]);
 
-            for (int q = 0; q < TYQ; ++q) {
+            float ring[U][TX];     // K==7: pair sums P; else: horizontal sums H
+            float hprev[TX];
 #pragma unroll
-                for (int m = 0; m < K; ++m) {
-                    const int r = q * K + m;
-                    cfptr a = (cfptr)(I0 + (long long)(y0 + oy + r) * p.W + (x0 + ox));   // wave-uniform
+            for (int x = 0; x < TX; ++x) {
+                hprev[x] = 0.f;
+#pragma unroll
+                for (int i = 0; i < U; ++i) ring[i][x] = 0.f;
+            }
+
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int m = 0; m < U; ++m) {
+                    const int r = q * U + m;
                     const px_t *lr = lp + r * p.pitch;
-                    float av[C][TX + K - 1];
+                    float e[NE];
+                    // LDS reads in NB batches: each batch is issued whole before any of it is consumed
+                    constexpr int NB = (NE > 8) ? 2 : 1;
+                    constexpr int BS = (NE + NB - 1) / NB;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) uload<TX + K - 1>(a + c * HW, av[c]);
-                    float e[TX + K - 1];
+                    for (int bb = 0; bb < NB; ++bb) {
+                        px_t b[BS];
 #pragma unroll
-                    for (int s = 0; s < TX + K - 1; ++s) {
-                        float a3[C];
+                        for (int s = 0; s < BS; ++s)
+                            if (bb * BS + s < NE) b[s] = lr[bb * BS + s];
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (C == 3) {
+                            // a (free) use of .w keeps each read a 16-B ds_read_b128 instead of the slower b96
 #pragma unroll
-                        for (int c = 0; c < C; ++c) a3[c] = av[c][s];
-                        px_t b = lr[s];
-                        if constexpr (C == 3) asm volatile("" ::"v"(b.w));   // keep the 16-B read (b128, not the slower b96)
-                        e[s] = sqdiff<C>(a3, b);
+                            for (int s = 0; s < BS; ++s)
+                                if (bb * BS + s < NE) asm volatile("" ::"v"(b[s].w));
+                        }
+#pragma unroll
+                        for (int s = 0; s < BS; ++s) {
+                            if (bb * BS + s < NE) {
+                                float a3[C];
+#pragma unroll
+                                for (int c = 0; c < C; ++c) a3[c] = av[c][bb * BS + s];
+                                e[bb * BS + s] = sqdiff<C>(a3, b[s]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    hsum<K, TX>(e, ring[m]);
-                    if (q > 0 || m == K - 1) {
-                        const int y = y0 + r - (K - 1);
-                        if (y >= y0n) {
+                    {   // next row's frame-0 values (row index clamped to the frame: the row after the
+                        // last one is requested but never used)
+                        const int rn = min(y0 + oy + r + 1, p.H - 1) - (y0 + oy);
+                        cfptr an = (cfptr)(I0 + a_base + (long long)rn * p.W);
 #pragma unroll
-                            for (int x = 0; x < TX; ++x) {
-                                // oldest row first: association fixed relative to the output pixel
-                                float v = ring[(m + 1) % K][x];
+                        for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    float h[TX];
+                    hsum<K, TX>(e, h);
+                    const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
+                    const int y = y0 + r - (K - 1);
+                    const bool store_row = emit && y >= y0n;                          // wave-uniform
+                    const char *orow = (const char *)(out + ((long long)y * p.Wo + xt) * D);
+                    if constexpr (K == 7) {
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) {
+                            if (store_row) {
+                                float v = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
+                                store_uniform_base(orow + (long long)x * D * 4, dbytes, v);
+                            }
+                        }
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) {
+                            ring[(m + 5) % 6][x] = hprev[x] + h[x];   // P_{r-1}; its slot held P_{r-7}, consumed last row
+                            hprev[x] = h[x];
+                        }
+                    } else {
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) ring[m][x] = h[x];
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) {
+                            if (store_row) {
+                                float v = ring[(m + 1) % K][x];   // oldest row first
 #pragma unroll
                                 for (int i = 2; i <= K; ++i) v += ring[(m + i) % K][x];
-                                if (x0 + x >= x0n) {
-                                    char *op = (char *)(out + ((long long)y * p.Wo + (x0 + x)) * D);   // wave-uniform
-                                    *(float *)(op + dbytes) = v;
-                                }
+                                store_uniform_base(orow + (long long)x * D * 4, dbytes, v);
                             }
                         }
                     }
@@ -240,36 +315,96 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
     }
 }
 
-template <int C, int K, int TX, int TYQ, int NW>
-static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin,
-                           int wWin, float *out, bool *handled) {
-    constexpr int TY = TYQ * K - (K - 1);
+// geometry of one tiled launch
+struct CvTilePlan {
+    int TY, GX, lrows, lcols, pitch, nblocks, bpc;
+    size_t lds_bytes;
+    double score;   // fraction of the chip-time doing useful output rows (higher is better), 0 = not launchable
+};
+
+template <int C, int K, int TX, int NT, int NW>
+static CvTilePlan plan_cv_tiled(int NQ, int Ho, int Wo, int hWin, int wWin, int ncu) {
     using px_t = typename Px<C>::type;
+    constexpr int U = VUnroll<K>::value;
+    CvTilePlan pl{};
+    const int rows = U * NQ;
+    pl.TY = rows - (K - 1);
+    pl.GX = NT * TX;
+    pl.lrows = rows + hWin - 1;
+    pl.lcols = pl.GX + K - 1 + wWin - 1;
+    const int M = Px<C>::bank_mod;
+    pl.pitch = pl.lcols;                             // smallest pitch >= lcols with pitch == wWin (mod M):
+    while ((pl.pitch - wWin) % M != 0) ++pl.pitch;   // keeps a wave that spans several dy rows conflict-free
+    pl.lds_bytes = (size_t)pl.lrows * pl.pitch * sizeof(px_t);
+    pl.score = 0;
+    if (pl.TY < 1 || Ho < pl.TY || Wo < pl.GX || pl.lds_bytes > 160 * 1024) return pl;
+    pl.nblocks = dfe_cdiv(Wo, pl.GX) * dfe_cdiv(Ho, pl.TY);
+    int bpc = (int)((160 * 1024) / pl.lds_bytes);          // resident blocks per CU: LDS ...
+    int by_waves = 4 / ((NW + 3) / 4);                      // ... and <= 128 VGPRs -> 4 waves/SIMD, ceil(NW/4) per block
+    if (bpc > by_waves) bpc = by_waves;
+    if (bpc < 1) bpc = 1;
+    pl.bpc = bpc;
+    long long slots = (long long)ncu * bpc;
+    long long rounds = (pl.nblocks + slots - 1) / slots;
+    double fill = (double)pl.nblocks / (double)(rounds * slots);       // tail quantisation
+    // The kernel is bound by its store stream, not by its arithmetic (measured: halving the useful rows
+    // per swept row does not slow it down), so row reuse only enters as a tie-breaker.
+    double halo = 0.9 + 0.1 * (double)pl.TY / (double)rows;
+    int D = hWin * wWin, nch = (D + 63) / 64, ntasks = NT * nch;
+    double deal = (double)ntasks / (double)(((ntasks + NW - 1) / NW) * NW);   // idle waves in the last task round
+    double occ = bpc * NW >= 16 ? 1.0 : (bpc * NW) / 16.0;             // too few waves cannot hide latency
+    pl.score = fill * halo * deal * occ;
+    return pl;
+}
+
+template <int C, int K, int TX, int NT, int NW, int NQ>
+static int launch_cv_tiled_one(dfe_ctx *ctx, const CvTilePlan &pl, const float *I0, const float *I1, int H, int W,
+                               long long plane, int hWin, int wWin, float *out) {
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
-    *handled = false;
-    if (Ho < TY || Wo < TX) return DFE_OK;
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
-    a.lrows = TYQ * K + hWin - 1;
-    a.lcols = TX + K - 1 + wWin - 1;
-    const int M = Px<C>::bank_mod;
-    int pitch = a.lcols;                        // smallest pitch >= lcols with pitch == wWin (mod M)
-    while ((pitch - wWin) % M != 0) ++pitch;
-    a.pitch = pitch;
-    size_t lds_bytes = (size_t)a.lrows * pitch * sizeof(px_t);
-    if (lds_bytes > 160 * 1024) return DFE_OK;  // window too large for one tile: caller falls back
-    auto kern = ssd_cv_tiled_kernel<C, K, TX, TYQ, NW>;
-    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
+    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.stage_off = 0;
+    auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    dim3 grid(dfe_cdiv(Wo, pl.GX), dfe_cdiv(Ho, pl.TY));
     {
         DfeProfScope prof(ctx);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, ctx->stream, I0, I1, out, a);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), pl.lds_bytes, ctx->stream, I0, I1, out, a);
     }
     DFE_LAUNCH_CHECK(ctx);
     ctx->last_kernel = "ssd_cv_tiled_kernel";
-    *handled = true;
     return DFE_OK;
+}
+
+// picks the block shape -- (NT=4 tiles, 8 waves) or (NT=1, 6 waves), NQ in 2..5 row groups -- that wastes
+// the least chip-time for this frame, then launches it
+template <int C, int K, int TX>
+static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin,
+                           int wWin, float *out, bool *handled) {
+    const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+    *handled = false;
+    int best = 0;
+    CvTilePlan bp{};
+    for (int nq = 2; nq <= 5; ++nq) {
+        if (ctx->cv_tyq && nq != ctx->cv_tyq) continue;
+        CvTilePlan p4 = plan_cv_tiled<C, K, TX, 4, 8>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
+        if (p4.score > bp.score) { bp = p4; best = 40 + nq; }
+        CvTilePlan p1 = plan_cv_tiled<C, K, TX, 1, 6>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
+        if (p1.score > bp.score) { bp = p1; best = 10 + nq; }
+    }
+    if (!best) return DFE_OK;   // no tile fits: caller falls back
+    *handled = true;
+    switch (best) {
+        case 42: return launch_cv_tiled_one<C, K, TX, 4, 8, 2>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 43: return launch_cv_tiled_one<C, K, TX, 4, 8, 3>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 44: return launch_cv_tiled_one<C, K, TX, 4, 8, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 45: return launch_cv_tiled_one<C, K, TX, 4, 8, 5>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 12: return launch_cv_tiled_one<C, K, TX, 1, 6, 2>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 13: return launch_cv_tiled_one<C, K, TX, 1, 6, 3>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 14: return launch_cv_tiled_one<C, K, TX, 1, 6, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        default: return launch_cv_tiled_one<C, K, TX, 1, 6, 5>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -282,10 +417,10 @@ static int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, in
     if (ctx->cv_mode != 1 && kh == kw) {
         bool handled = false;
         int rc = DFE_OK;
-        if (C == 3 && kh == 7) rc = launch_cv_tiled<3, 7, 8, 5, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
-        else if (C == 1 && kh == 7) rc = launch_cv_tiled<1, 7, 8, 5, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
-        else if (C == 3 && kh == 5) rc = launch_cv_tiled<3, 5, 8, 6, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
-        else if (C == 3 && kh == 3) rc = launch_cv_tiled<3, 3, 8, 8, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
+        if (C == 3 && kh == 7) rc = launch_cv_tiled<3, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
+        else if (C == 1 && kh == 7) rc = launch_cv_tiled<1, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
+        else if (C == 3 && kh == 5) rc = launch_cv_tiled<3, 5, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
+        else if (C == 3 && kh == 3) rc = launch_cv_tiled<3, 3, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);
         if (rc != DFE_OK || handled) return rc;
     }
     if (ctx->cv_mode == 2)

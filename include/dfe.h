@@ -58,6 +58,9 @@ int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* s
  * (bit-identical float summation order to the CPU path), 2 = force the tiled fast kernel
  * (DFE_E_UNSUPPORTED from the op when the shape has no fast kernel) */
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
+/* tile height of the tiled kernel: 0 = chosen per shape (default); 2..5 = force TYQ (a tile sweeps
+ * TYQ*k image rows), for tuning and for testing every instantiation */
+int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* name of the kernel the last cost-volume call launched (static string) */
 const char *dfe_last_kernel(const dfe_ctx *ctx);
 

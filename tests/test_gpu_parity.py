@@ -70,6 +70,26 @@ def test_cost_volume_tiled_bit_exact_on_integer_frames(dfe, cuda, H, W, C, k, hW
     assert np.array_equal(gpu, cpu)
 
 
+@pytest.mark.parametrize("tyq", [2, 3, 4, 5])
+def test_cost_volume_every_tile_height_bit_exact(dfe, cuda, tyq):
+    # every TYQ instantiation, on a frame whose last tile row/column is shifted (Ho, Wo not multiples)
+    H, W = 83, 71
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=tyq, max_flow=7)
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 17, 17)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(2)
+    ctx.set_cost_volume_tile(tyq)
+    try:
+        out = torch.full(cpu.shape, -1.0, device=cuda)
+        t0, t1 = T(f0, cuda), T(f1, cuda)
+        ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, 17, 17, out.data_ptr()))
+        assert ctx.last_kernel() == "ssd_cv_tiled_kernel"
+    finally:
+        ctx.set_cost_volume_kernel(0)
+        ctx.set_cost_volume_tile(0)
+    assert np.array_equal(out.cpu().numpy(), cpu)
+
+
 def test_cost_volume_tiled_float_frames_within_tolerance(dfe, cuda):
     f0, f1, _, _ = rp.synth_pair(80, 100, C=3, seed=2, integer=False)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
@@ -112,7 +132,7 @@ def test_cost_volume_ref_kernel_bit_exact_on_floats(dfe, cuda, case):
 
 
 def test_auto_dispatch_falls_back_when_frame_smaller_than_a_tile(dfe, cuda):
-    f0, f1, _, _ = rp.synth_pair(30, 40, C=3, seed=1, max_flow=2)   # Ho = 30-6-8 = 16 < 29
+    f0, f1, _, _ = rp.synth_pair(19, 40, C=3, seed=1, max_flow=2)   # Ho = 19-6-8 = 5 < the smallest tile (6 rows)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 9, 9)
     ctx = dfe.get_ctx(0)
     gpu = dfe.nn.SSDCostVolume(9, 9, 7, 7).forward([T(f0, cuda), T(f1, cuda)]).cpu().numpy()
