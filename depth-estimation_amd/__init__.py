@@ -12,6 +12,8 @@ no CPU fallback -- a missing library or device raises.
     x2yx, yx2x, yx2xMulti, x2yxMulti, x2yxMulti2, getMiddleIndex, getOutputConfidences,
     processOutput                                       (opticalflow_model*.lua)
     unfold, compute_cartesian_groundtruth_cross_correlation  (radial/radial_opticalflow_groundtruth.lua)
+    nn.CascadingAddTable, getModelMultiscale            (CascadingAddTable.lua, opticalflow_model_multiscale.lua)
+    getC2PMask, getP2CMask, cartesian2polar, flow2depth (radial/cartesian2polar.lua, radial_opticalflow_display.lua)
 """
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
@@ -30,6 +32,8 @@ from .opticalflow_model import (  # noqa: F401
     getOutputConfidences,
     processOutput,
 )
+from .multiscale import CascadingAddTable, MultiscaleModel, getModelMultiscale  # noqa: F401
+from .radial import getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth  # noqa: F401
 from .groundtruth import (  # noqa: F401
     unfold,
     cross_correlation_pad_output,

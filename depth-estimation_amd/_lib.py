@@ -61,6 +61,15 @@ PROTOTYPES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_double] + [C.c_void_p] * 4,
     ),
+    "dfe_downsample_box_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "dfe_pyramid_scale_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "dfe_softmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "dfe_cascading_add_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dfe_cascade_ring_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p] + [C.c_int] * 5 + [C.c_void_p]),
+    "dfe_polar_grid_c2p_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dfe_polar_grid_p2c_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_float] * 4 + [C.c_void_p]),
+    "dfe_warp_bilinear_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dfe_flow_to_depth_radial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

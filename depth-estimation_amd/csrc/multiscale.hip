@@ -1,0 +1,257 @@
+// multiscale.hip -- A2..A5: pyramid volumes, per-scale softmin, CascadingAddTable, ring extraction.
+//   replaces: getMultiscalePrefilter / SpatialPyramid geometry  opticalflow_model_multiscale.lua:134-229
+//             cascad_preproc (Minus -> SoftMax)                  opticalflow_model_multiscale.lua:270-279
+//             nn.CascadingAddTable:updateOutput                  CascadingAddTable.lua:108-135
+//             the "middle remover" + JoinTable + SmartReshape    opticalflow_model_multiscale.lua:293-333
+// The reference materialises the x r nearest-neighbour upsampling of every coarse volume and ~15 full
+// H x W x 64 temporaries; here volumes stay at native scale and one kernel per finest pixel gathers its
+// window from each scale, cascades and ring-selects in LDS, writing only the H x W x nclasses result.
+#include "dfe_internal.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kWaves = 4;
+
+// ---- nn.SpatialDownSampling(r,r): mean of r x r blocks (row-major accumulation, then * 1/(r*r)) ----
+__global__ void downsample_box_kernel(const float *__restrict__ img, int C, int H, int W, int r, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int Ho = H / r, Wo = W / r;
+    const long long total = (long long)C * Ho * Wo;
+    const float inv = 1.0f / (float)(r * r);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(e % Wo);
+        long long t = e / Wo;
+        int y = (int)(t % Ho), c = (int)(t / Ho);
+        float s = 0.f;
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) s = s + img[((long long)c * H + y * r + i) * W + x * r + j];
+        out[e] = s * inv;
+    }
+}
+
+// ---- nn.SpatialZeroPadding(l,r,t,b) with non-negative pads --------------------------------------
+__global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int W, int pl, int pt, int Hp, int Wp,
+                                float *__restrict__ out) {
+    const long long total = (long long)C * Hp * Wp;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(e % Wp);
+        long long t = e / Wp;
+        int y = (int)(t % Hp), c = (int)(t / Hp);
+        int sy = y - pt, sx = x - pl;
+        out[e] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? img[((long long)c * H + sy) * W + sx] : 0.f;
+    }
+}
+
+// ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
+__global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__restrict__ cost, long long P, int N,
+                                                             float *__restrict__ prob) {
+    const int lane = threadIdx.x & 63;
+    for (long long p = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6); p < P; p += (long long)gridDim.x * kWaves) {
+        const float *c = cost + p * N;
+        float *o = prob + p * N;
+        float m = -INFINITY;
+        for (int n = lane; n < N; n += 64) m = fmaxf(m, -c[n]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            float e = expf(-c[n] - m);
+            o[n] = e;
+            s += e;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        const float inv = 1.0f / s;
+        for (int n = lane; n < N; n += 64) o[n] *= inv;
+    }
+}
+
+struct CascadeGeom {
+    int nratios, maxh, maxw, H, W;
+    int ratios[DFE_MAX_RATIOS];
+    int d[DFE_MAX_RATIOS];      // ring width of scale s >= 1
+    int base[DFE_MAX_RATIOS];   // 0-based class offset of scale s in the joined vector
+    int ncls;
+    const float *in[DFE_MAX_RATIOS];
+    float *out_scale[DFE_MAX_RATIOS];   // A4-only mode: per-scale outputs [P][maxh][maxw]
+};
+
+// out_s = in_s + replicate_q(crop(out_{s+1}, dh, dw)), coarse -> fine, in one wave's LDS window buffers.
+// CascadingAddTable.lua:117-132: dh = maxh*(r2-r)/(2*r2), q = r2/r.
+template <bool RING>
+__global__ __launch_bounds__(kWaves * 64) void cascade_kernel(CascadeGeom g, float *__restrict__ out) {
+    extern __shared__ float sh[];
+    const int N = g.maxh * g.maxw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float *cur = sh + (size_t)w * 2 * N, *prev = cur + N;
+    const long long P = (long long)g.H * g.W;
+    for (long long p = (long long)blockIdx.x * kWaves + w; p < P; p += (long long)gridDim.x * kWaves) {
+        const int y = (int)(p / g.W), x = (int)(p - (long long)y * g.W);
+        for (int s = g.nratios - 1; s >= 0; --s) {
+            const int r = g.ratios[s];
+            // RING: inputs at native scale, nearest-neighbour upsampling = index (y/r, x/r); else full-res inputs
+            const float *src = RING ? g.in[s] + ((long long)(y / r) * (g.W / r) + x / r) * N : g.in[s] + p * N;
+            if (s == g.nratios - 1) {
+                for (int n = lane; n < N; n += 64) cur[n] = src[n];
+            } else {
+                const int r2 = g.ratios[s + 1], q = r2 / r;
+                const int dh = g.maxh * (r2 - r) / (2 * r2), dw = g.maxw * (r2 - r) / (2 * r2);
+                for (int n = lane; n < N; n += 64) {
+                    int a = n / g.maxw, b = n - a * g.maxw;
+                    cur[n] = src[n] + prev[(dh + a / q) * g.maxw + dw + b / q];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (RING) {
+                float *o = out + p * g.ncls + g.base[s];
+                if (s == 0) {
+                    for (int n = lane; n < N; n += 64) o[n] = cur[n];
+                } else {   // ring blocks in the order top, left, right, bottom  (opticalflow_model_multiscale.lua:301-315)
+                    const int d = g.d[s], mh = g.maxh, mw = g.maxw;
+                    for (int n = lane; n < N; n += 64) {
+                        int a = n / mw, b = n - a * mw, idx = -1;
+                        if (a < d) idx = a * mw + b;
+                        else if (a >= mh - d) idx = d * mw + 2 * (mh - 2 * d) * d + (a - (mh - d)) * mw + b;
+                        else if (b < d) idx = d * mw + (a - d) * d + b;
+                        else if (b >= mw - d) idx = d * mw + (mh - 2 * d) * d + (a - d) * d + (b - (mw - d));
+                        if (idx >= 0) o[idx] = cur[n];
+                    }
+                }
+            } else {
+                float *o = g.out_scale[s] + p * N;
+                for (int n = lane; n < N; n += 64) o[n] = cur[n];
+            }
+            float *t = cur; cur = prev; prev = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int ring_width(int maxw, int r, int rprev) { return (int)floor((double)maxw * (r - rprev) / (2.0 * r) + 0.5); }
+
+int fill_cascade(dfe_ctx *ctx, CascadeGeom &g, const int *ratios, int nratios, int maxh, int maxw) {
+    DFE_REQUIRE(ctx, ratios && nratios >= 1 && nratios <= DFE_MAX_RATIOS, DFE_E_ARG, "nratios=%d not in 1..%d", nratios, DFE_MAX_RATIOS);
+    DFE_REQUIRE(ctx, maxh > 0 && maxw > 0, DFE_E_ARG, "maxh=%d maxw=%d must be positive", maxh, maxw);
+    g.nratios = nratios; g.maxh = maxh; g.maxw = maxw;
+    int base = 0;
+    for (int i = 0; i < nratios; ++i) {
+        DFE_REQUIRE(ctx, ratios[i] > 0, DFE_E_ARG, "ratios[%d]=%d", i, ratios[i]);
+        g.ratios[i] = ratios[i];
+        g.d[i] = i ? ring_width(maxw, ratios[i], ratios[i - 1]) : 0;
+        g.base[i] = base;
+        base += i ? 2 * g.d[i] * maxw + 2 * (maxh - 2 * g.d[i]) * g.d[i] : maxh * maxw;
+        if (i + 1 < nratios) {   // CascadingAddTable.lua:121-124
+            int r = ratios[i], r2 = ratios[i + 1];
+            DFE_REQUIRE(ctx, r2 % r == 0 && (maxh * (r2 - r)) % (2 * r2) == 0 && (maxw * (r2 - r)) % (2 * r2) == 0, DFE_E_SHAPE,
+                        "nn.CascadingAddTable: ratios and input sizes not compatible");
+        }
+    }
+    g.ncls = base;
+    return DFE_OK;
+}
+
+int grid1d(long long n, int per_block) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfe_downsample_box_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, int r, float *out) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, img && out && C > 0 && r > 0 && H >= r && W >= r, DFE_E_ARG, "dfe_downsample_box_f32: bad argument");
+    hipLaunchKernelGGL(downsample_box_kernel, dim3(grid1d((long long)C * (H / r) * (W / r), 256)), dim3(256), 0, ctx->stream, img, C, H, W,
+                       r, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int r, int kh, int kw,
+                                 int maxh, int maxw, float *out) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, I0 && I1 && out, DFE_E_ARG, "dfe_pyramid_scale_volume_f32: NULL tensor");
+    DFE_REQUIRE(ctx, C > 0 && r > 0 && kh > 0 && kw > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_pyramid_scale_volume_f32: bad size");
+    DFE_REQUIRE(ctx, H % r == 0 && W % r == 0, DFE_E_SHAPE,
+                "dfe_pyramid_scale_volume_f32: frame %dx%d is not a multiple of ratio %d (opticalflow_model_multiscale.lua:238-243)", H, W, r);
+    const int Hs = H / r, Ws = W / r;
+    const int hp = maxh - 1 + kh - 1, wp = maxw - 1 + kw - 1;   // hPatch2-1 (:136-141)
+    const int pt = hp / 2, pl = wp / 2;
+    const int Hp = Hs + hp, Wp = Ws + wp;
+    const size_t nd = (size_t)C * Hs * Ws, np = (size_t)C * Hp * Wp;
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, (2 * nd + 2 * np) * sizeof(float), &scr);
+    if (rc) return rc;
+    float *d0 = (float *)scr, *d1 = d0 + nd, *p0 = d1 + nd, *p1 = p0 + np;
+    const float *s0 = I0, *s1 = I1;
+    if (r > 1) {
+        hipLaunchKernelGGL(downsample_box_kernel, dim3(grid1d((long long)nd, 256)), dim3(256), 0, ctx->stream, I0, C, H, W, r, d0);
+        hipLaunchKernelGGL(downsample_box_kernel, dim3(grid1d((long long)nd, 256)), dim3(256), 0, ctx->stream, I1, C, H, W, r, d1);
+        s0 = d0; s1 = d1;
+    }
+    hipLaunchKernelGGL(zero_pad_kernel, dim3(grid1d((long long)np, 256)), dim3(256), 0, ctx->stream, s0, C, Hs, Ws, pl, pt, Hp, Wp, p0);
+    hipLaunchKernelGGL(zero_pad_kernel, dim3(grid1d((long long)np, 256)), dim3(256), 0, ctx->stream, s1, C, Hs, Ws, pl, pt, Hp, Wp, p1);
+    DFE_LAUNCH_CHECK(ctx);
+    // frame-0 crop floor/ceil((maxw-1)/2) (:198-202) is the oy/ox offset of the cost-volume op
+    return cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, kh, kw, maxh, maxw, out);
+}
+
+int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, P >= 0 && N > 0, DFE_E_SHAPE, "dfe_softmin_f32: P=%lld N=%d", (long long)P, N);
+    if (P == 0) return DFE_OK;
+    DFE_REQUIRE(ctx, cost && prob, DFE_E_ARG, "dfe_softmin_f32: NULL tensor");
+    hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), 0, ctx->stream, cost, (long long)P, N, prob);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw,
+                         float *out) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    CascadeGeom g;
+    int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
+    if (rc) return rc;
+    DFE_REQUIRE(ctx, prob && out && H > 0 && W > 0, DFE_E_ARG, "dfe_cascade_ring_f32: bad argument");
+    for (int s = 0; s < nratios; ++s) {
+        DFE_REQUIRE(ctx, prob[s], DFE_E_ARG, "dfe_cascade_ring_f32: prob[%d] is NULL", s);
+        DFE_REQUIRE(ctx, H % ratios[s] == 0 && W % ratios[s] == 0, DFE_E_SHAPE, "dfe_cascade_ring_f32: %dx%d not a multiple of ratio %d", H, W, ratios[s]);
+        g.in[s] = prob[s];
+        g.out_scale[s] = nullptr;
+    }
+    g.H = H; g.W = W;
+    size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
+    DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_ring_f32: window %dx%d too large", maxh, maxw);
+    hipLaunchKernelGGL(cascade_kernel<true>, dim3(grid1d((long long)H * W, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios, int64_t P, int maxh, int maxw,
+                          float *const *out) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    CascadeGeom g;
+    int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
+    if (rc) return rc;
+    DFE_REQUIRE(ctx, in && out && P >= 0, DFE_E_ARG, "dfe_cascading_add_f32: bad argument");
+    if (P == 0) return DFE_OK;
+    for (int s = 0; s < nratios; ++s) {
+        DFE_REQUIRE(ctx, in[s] && out[s], DFE_E_ARG, "dfe_cascading_add_f32: tensor %d is NULL", s);
+        g.in[s] = in[s];
+        g.out_scale[s] = out[s];
+    }
+    DFE_REQUIRE(ctx, P <= 0x7fffffff, DFE_E_SHAPE, "dfe_cascading_add_f32: P too large");
+    g.H = 1; g.W = (int)P;
+    size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
+    DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascading_add_f32: window %dx%d too large", maxh, maxw);
+    hipLaunchKernelGGL(cascade_kernel<false>, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, (float *)nullptr);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+}  // extern "C"

@@ -411,7 +411,7 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
 // C ABI
 // ------------------------------------------------------------------------------------------
 // H is the number of frame rows visible to this call (a row band of a taller frame when plane > H*W)
-static int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
+int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                               int kw, int hWin, int wWin, float *out) {
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
     if (ctx->cv_mode != 1 && kh == kw) {

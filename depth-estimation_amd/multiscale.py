@@ -1,0 +1,96 @@
+"""Multiscale matcher with the reference's names (opticalflow_model_multiscale.lua, CascadingAddTable.lua)
+for the raw-patch (identity filter) case: pyramid volumes -> softmin -> cascade -> ring extraction."""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, ratios_array
+from .context import get_ctx, ptr
+from .nn import Module
+from .opticalflow_model import _g
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class CascadingAddTable(Module):
+    """nn.CascadingAddTable(ratios, trainable, single_beta) -- CascadingAddTable.lua:7-135 (forward).
+    HEAD sums plainly: the Mul2 gains and the Power normaliser are commented out (:29,46,61), so
+    `trainable` / `single_beta` do not change updateOutput."""
+
+    def __init__(self, ratios, trainable=True, single_beta=False):
+        super().__init__()
+        self.ratios = [int(r) for r in ratios]
+        self.trainable = trainable
+
+    def updateOutput(self, input):
+        for t in input:
+            if t.dim() != 3:
+                raise ValueError("nn.CascadingAddTable: input must be a table of 3D-tensors (HxW) x Kh x Kw")  # :109-112
+        if len(input) != len(self.ratios):
+            raise ValueError("nn.CascadingAddTable: input and ratios must have the same size")  # :114-116
+        ins = [t.contiguous() for t in input]
+        P, maxh, maxw = ins[0].shape
+        for t in ins:
+            if t.dtype != torch.float32 or tuple(t.shape) != (P, maxh, maxw):
+                raise ValueError("nn.CascadingAddTable: inputs must be FloatTensors of one size")
+        outs = [torch.empty_like(t) for t in ins]
+        ctx = get_ctx(ins[0])
+        r, n = ratios_array(self.ratios)
+        ctx.check(lib().dfe_cascading_add_f32(ctx.handle, _ptr_array(ins), r, n, P, maxh, maxw, _ptr_array(outs)))
+        self.output = outs
+        return outs
+
+
+class MultiscaleModel(Module):
+    """What getModelMultiscale(geometry, full_image=true, prefiltered=false):forward({I0, I1}) computes in
+    inference mode for the identity patch filter (opticalflow_model_multiscale.lua:175-333): returns the
+    hImg x wImg x nclasses tensor that processOutput consumes.  Also keeps the per-scale cost volumes
+    (`self.volumes`, native scale) and probabilities (`self.probs`)."""
+
+    def __init__(self, geometry):
+        super().__init__()
+        self.geometry = geometry
+        g = geometry
+        ratios = [int(r) for r in _g(g, "ratios")]
+        assert ratios[0] == 1  # :182
+        rmax = ratios[-1]
+        for r in ratios:  # :183-188
+            k = rmax - r
+            assert (_g(g, "maxh") * k) % 2 == 0 and (_g(g, "maxw") * k) % 2 == 0
+        self.ratios = ratios
+
+    def updateOutput(self, input):
+        g = self.geometry
+        i0, i1 = input
+        i0, i1 = i0.contiguous(), i1.contiguous()
+        Cc, H, W = i0.shape
+        maxh, maxw, kh, kw = _g(g, "maxh"), _g(g, "maxw"), _g(g, "hKernel"), _g(g, "wKernel")
+        rmax = self.ratios[-1]
+        if H % rmax or W % rmax:
+            raise ValueError("frame %dx%d must be a multiple of the coarsest ratio %d" % (H, W, rmax))  # :238-243 pads; not needed here
+        ctx = get_ctx(i0)
+        l = lib()
+        N = maxh * maxw
+        self.volumes, self.probs = [], []
+        for r in self.ratios:
+            vol = torch.empty((H // r, W // r, maxh, maxw), dtype=torch.float32, device=i0.device)
+            ctx.check(l.dfe_pyramid_scale_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, r, kh, kw, maxh, maxw, ptr(vol)))
+            prob = torch.empty_like(vol)
+            ctx.check(l.dfe_softmin_f32(ctx.handle, ptr(vol), vol.numel() // N, N, ptr(prob)))
+            self.volumes.append(vol)
+            self.probs.append(prob)
+        rr, n = ratios_array(self.ratios)
+        ncls = l.dfe_multi_nclasses(maxh, maxw, rr, n)
+        out = torch.empty((H, W, ncls), dtype=torch.float32, device=i0.device)
+        ctx.check(l.dfe_cascade_ring_f32(ctx.handle, _ptr_array(self.probs), rr, n, H, W, maxh, maxw, ptr(out)))
+        self.output = out
+        return out
+
+
+def getModelMultiscale(geometry, full_image=True, prefiltered=False):
+    """opticalflow_model_multiscale.lua:175 (inference mode, identity patch filter)."""
+    if prefiltered:
+        raise NotImplementedError("prefiltered (learned filter) inputs are next-row N1")
+    return MultiscaleModel(geometry)

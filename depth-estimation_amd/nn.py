@@ -97,3 +97,11 @@ class SSDCostVolume(Module):
         )
         self.output = out
         return out
+
+
+def __getattr__(name):  # nn.CascadingAddTable lives in multiscale.py (it needs the codec helpers)
+    if name == "CascadingAddTable":
+        from .multiscale import CascadingAddTable
+
+        return CascadingAddTable
+    raise AttributeError(name)

@@ -175,6 +175,54 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
                             double extract_threshold, float *flow, float *scores, float *depth,
                             float *depth_conf);
 
+/* ---- A2: one pyramid scale on raw frames ------------------------------------------------- */
+/* replaces: per-ratio branch of getMultiscalePrefilter + matcher opticalflow_model_multiscale.lua:134-173,196-229
+ *   (raw-patch identity filter): box down-sample by r, zero-pad by hPatch2-1 = (maxh-1)+(kh-1) split
+ *   floor/ceil, crop frame 0 by maxw-1, SpatialMatching(maxh,maxw).  out [H/r][W/r][maxh][maxw] at native
+ *   scale (the x r nearest-neighbour upsampling is applied by the consumer's indexing). */
+int dfe_downsample_box_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, int r, float *out);
+int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
+                                 int r, int kh, int kw, int maxh, int maxw, float *out);
+
+/* ---- A3: nn.Minus -> nn.SoftMax over the window cells ------------------------------------ */
+/* replaces: cascad_preproc opticalflow_model_multiscale.lua:270-279.  cost, prob [P][N]. */
+int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob);
+
+/* ---- A4: nn.CascadingAddTable:updateOutput ------------------------------------------------ */
+/* replaces: CascadingAddTable.lua:108-135.  in[s], out[s]: [P][maxh][maxw] for each of the nratios
+ *   scales (arrays of device pointers on the HOST).  out[n-1] = in[n-1];
+ *   out[i] = in[i] + replicate(crop(out[i+1])).  DFE_E_SHAPE with the reference's message when ratios
+ *   and window size are not compatible (:121-124). */
+int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios,
+                          int64_t P, int maxh, int maxw, float *const *out);
+
+/* ---- A2(upsample)+A4+A5: cascade and ring extraction for a whole frame --------------------- */
+/* replaces: nearest upsampling of SpatialPyramid + CascadingAddTable + the "middle remover" +
+ *   JoinTable(2) + SmartReshape(hImg,wImg,-2), opticalflow_model_multiscale.lua:227-229,285-333.
+ *   prob[s] [H/r_s][W/r_s][maxh][maxw] (native scale).  out [H][W][nclasses]. */
+int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios,
+                         int H, int W, int maxh, int maxw, float *out);
+
+/* ---- A13 / A14: polar grids and bilinear warp ------------------------------------------------ */
+/* replaces: getC2PMask radial/cartesian2polar.lua:4-49.  mask [2][hdst][wdst+lpadding+rpadding]. */
+int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter,
+                           float ycenter, int lpadding, int rpadding, float rmax, float alpha,
+                           float *mask);
+/* replaces: getP2CMask radial/cartesian2polar.lua:51-89.  mask [2][hdst][wdst]. */
+int dfe_polar_grid_p2c_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter,
+                           float ycenter, float rmax, float alpha, float *mask);
+/* replaces: cartesian2polar(img, mask) = image.warp(img, mask, 'bilinear', false)
+ *   radial/cartesian2polar.lua:91-93.  img [C][H][W], mask [2][Hd][Wd] (plane 0 = y, 1 = x, absolute,
+ *   0-based), out [C][Hd][Wd]; coordinates outside the image are clamped. */
+int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const float *mask,
+                          int Hd, int Wd, float *out);
+
+/* ---- A12(ii): radial flow -> depth --------------------------------------------------------- */
+/* replaces: flow2depth radial/radial_opticalflow_display.lua:6-58.  rflow [H][W] scalar radial flow;
+ *   depth = (d/f or infty)/infty where |p-c| > 10, conf = 0 inside that radius. */
+int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, float xcenter,
+                             float ycenter, float infty, float *depth, float *conf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,187 @@
+"""GPU suite, rows A2-A5 (multiscale) and A12(ii)/A13/A14 (radial) against the oracle.
+Bars: cost volumes of integer-valued frames bit-exact at every scale (box means of uint8 values are
+exact in fp32); cascade adds are bit-exact given equal inputs; softmin within 1e-6 absolute of the
+oracle's exact-expf softmax (SOFT_ATOL); polar grids / warp / depth within 1 ulp-ish float tolerance
+(device libm vs glibc), stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle as orc
+from tests import refpath as rp
+
+pytestmark = pytest.mark.gpu
+SOFT_ATOL = 1e-6
+
+
+def T(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+@pytest.mark.parametrize("r", [1, 2, 4])
+def test_pyramid_scale_volume_bit_exact(dfe, cuda, r):
+    H, W, C, k, mh, mw = 96, 128, 3, 7, 8, 8
+    f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=r, max_flow=6)
+    cpu = orc.pyramid_scale_volume(f0, f1, r, k, k, mh, mw)
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    out = torch.empty((H // r, W // r, mh, mw), device=cuda)
+    ctx.check(dfe.lib().dfe_pyramid_scale_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, r, k, k, mh, mw, out.data_ptr()))
+    if r == 1:
+        assert np.array_equal(out.cpu().numpy(), cpu)
+    else:
+        # box means are multiples of 1/r^2: squared differences no longer fit 24 bits, so the tiled kernel's
+        # summation order shows up in the last bits (tolerance of the float contract); the reference-order
+        # kernel stays bit-exact
+        g = out.cpu().numpy()
+        assert (np.abs(g - cpu) <= 1e-5 * np.abs(cpu) + 1e-6 * np.abs(cpu).max()).all()
+        ctx.set_cost_volume_kernel(1)
+        try:
+            ctx.check(dfe.lib().dfe_pyramid_scale_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, r, k, k, mh, mw, out.data_ptr()))
+        finally:
+            ctx.set_cost_volume_kernel(0)
+        assert np.array_equal(out.cpu().numpy(), cpu)
+    if r > 1:
+        ds = torch.empty((C, H // r, W // r), device=cuda)
+        ctx.check(dfe.lib().dfe_downsample_box_f32(ctx.handle, t0.data_ptr(), C, H, W, r, ds.data_ptr()))
+        ref = f0.reshape(C, H // r, r, W // r, r).astype(np.float64).mean((2, 4)).astype(np.float32)
+        assert np.array_equal(ds.cpu().numpy(), ref)
+    with pytest.raises(dfe.DfeError):
+        ctx.check(dfe.lib().dfe_pyramid_scale_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H - 1, W, 2, k, k, mh, mw, out.data_ptr()))
+
+
+def test_softmin_within_tolerance(dfe, cuda):
+    rng = np.random.default_rng(0)
+    for N in (64, 16, 160, 289):
+        cost = (rng.random((500, N)) * rng.choice([1.0, 50.0, 5000.0], size=(500, 1))).astype(np.float32)
+        ref = orc.softmin(cost)
+        ctx = dfe.get_ctx(0)
+        tc = T(cost, cuda)
+        out = torch.empty_like(tc)
+        ctx.check(dfe.lib().dfe_softmin_f32(ctx.handle, tc.data_ptr(), 500, N, out.data_ptr()))
+        g = out.cpu().numpy()
+        assert np.abs(g - ref).max() <= SOFT_ATOL
+        assert np.allclose(g.sum(1), 1.0, atol=1e-5)
+        assert np.array_equal(g.argmax(1), cost.argmin(1)) or np.abs(np.sort(g, 1)[:, -1] - np.sort(g, 1)[:, -2]).min() < 1e-6
+
+
+@pytest.mark.parametrize("ratios,mh,mw", [([1, 2, 4], 8, 8), ([1, 2], 8, 8), ([1, 2, 4, 8], 4, 4), ([1, 2, 4, 8], 16, 16), ([1], 8, 8)])
+def test_cascading_add_table_module_bit_exact(dfe, cuda, ratios, mh, mw):
+    rng = np.random.default_rng(len(ratios) + mh)
+    P = 37
+    ins = [rng.random((P, mh, mw), dtype=np.float32) for _ in ratios]
+    rc, ref = orc.cascading_add(ins, ratios, mh, mw)
+    assert rc == 0
+    m = dfe.nn.CascadingAddTable(ratios)
+    outs = m.forward([T(a, cuda) for a in ins])
+    assert m.output is outs and len(outs) == len(ratios)
+    for o, e in zip(outs, ref):
+        assert np.array_equal(o.cpu().numpy(), e)
+
+
+def test_cascading_add_table_errors(dfe, cuda):
+    m = dfe.nn.CascadingAddTable([1, 2])
+    with pytest.raises(ValueError, match="3D-tensors"):
+        m.forward([torch.zeros((4, 8, 8, 1), device=cuda), torch.zeros((4, 8, 8), device=cuda)])
+    with pytest.raises(ValueError, match="same size"):
+        m.forward([torch.zeros((4, 8, 8), device=cuda)])
+    with pytest.raises(dfe.DfeError, match="not compatible"):   # CascadingAddTable.lua:121-124
+        m.forward([torch.zeros((4, 2, 2), device=cuda), torch.zeros((4, 2, 2), device=cuda)])
+
+
+@pytest.mark.parametrize("ratios,mh,mw", [([1, 2, 4], 8, 8), ([1, 2, 4, 8], 4, 4)])
+def test_cascade_ring_bit_exact_and_layout(dfe, cuda, ratios, mh, mw):
+    rng = np.random.default_rng(mh)
+    H, W = 16, 24
+    probs = [rng.random((H // r, W // r, mh, mw), dtype=np.float32) for r in ratios]
+    rc, ref = orc.cascade_ring(probs, ratios, H, W, mh, mw)
+    assert rc == 0
+    ctx = dfe.get_ctx(0)
+    tp = [T(p, cuda) for p in probs]
+    out = torch.empty(ref.shape, device=cuda)
+    import ctypes as C
+    arr = (C.c_void_p * len(tp))(*[t.data_ptr() for t in tp])
+    r, n = dfe._lib.ratios_array(ratios)
+    ctx.check(dfe.lib().dfe_cascade_ring_f32(ctx.handle, arr, r, n, H, W, mh, mw, out.data_ptr()))
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_multiscale_model_end_to_end(dfe, cuda):
+    """cfg2b geometry scaled down: k=7, maxh=maxw=8, ratios {1,2,4}: model:forward -> processOutput."""
+    H, W = 96, 128
+    geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4], multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=4, max_flow=10, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)   # keeps softmin informative; still exact multiples of 1/64
+    model = dfe.getModelMultiscale(geo)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(1)   # reference summation order: the softmin of raw SSDs amplifies last-bit cost differences
+    try:
+        out = model.forward([T(f0, cuda), T(f1, cuda)])
+    finally:
+        ctx.set_cost_volume_kernel(0)
+    assert tuple(out.shape) == (H, W, 160)
+    vols = [orc.pyramid_scale_volume(f0, f1, r, 7, 7, 8, 8) for r in geo["ratios"]]
+    for v, e in zip(model.volumes, vols):
+        assert np.array_equal(v.cpu().numpy(), e)
+    probs = [orc.softmin(v.reshape(-1, 64)).reshape(v.shape) for v in vols]
+    rc, ref = orc.cascade_ring(probs, geo["ratios"], H, W, 8, 8)
+    g = out.cpu().numpy()
+    assert np.abs(g - ref).max() <= 3 * SOFT_ATOL   # three scales summed
+    ret = dfe.processOutput(geo, out, True)
+    mid = dfe.getMiddleIndex(geo)
+    assert mid == 28
+    ei, _ = orc.argbest_center(ref, mid, True)
+    gi = ret["index"].cpu().numpy()
+    top2 = np.sort(ref, -1)[..., -2:]
+    assert ((gi == ei) | (top2[..., 1] - top2[..., 0] <= 1e-5)).all()   # tie-aware
+    _, ey, ex = orc.x2yx_multi(8, 8, geo["ratios"], gi)
+    assert np.array_equal(ret["y"].cpu().numpy(), ey) and np.array_equal(ret["x"].cpu().numpy(), ex)
+    # the planted flow is recovered up to the scale's step (tests/test_multiscale.lua:61-71 tolerance rule)
+    inner = (slice(24, H - 24), slice(24, W - 24))
+    tol = np.where(np.maximum(np.abs(flow[0]), np.abs(flow[1])) <= 3, 1, np.where(np.maximum(np.abs(flow[0]), np.abs(flow[1])) <= 6, 2, 4))
+    ok = (np.abs(ey - flow[0]) < tol + 1) & (np.abs(ex - flow[1]) < tol + 1)
+    assert ok[inner].mean() > 0.9
+
+
+def test_polar_grids_and_warp(dfe, cuda):
+    wsrc, hsrc, wdst, hdst = 128, 96, 100, 60
+    e2 = (70.5, 40.25)
+    rmax = dfe.getRMax(hsrc, wsrc, e2)
+    assert rmax == math.floor(math.sqrt(max(e2[0] ** 2 + e2[1] ** 2, (wsrc - e2[0]) ** 2 + e2[1] ** 2, e2[0] ** 2 + (hsrc - e2[1]) ** 2, (wsrc - e2[0]) ** 2 + (hsrc - e2[1]) ** 2)))
+    m = dfe.getC2PMask(wsrc, hsrc, wdst, hdst, e2[0], e2[1], 8, 8, rmax).cpu().numpy()
+    ref = orc.polar_grid_c2p(wsrc, hsrc, wdst, hdst, e2[0], e2[1], 8, 8, rmax)
+    assert m.shape == ref.shape == (2, hdst, wdst + 16)
+    assert np.allclose(m, ref, rtol=0, atol=2e-5)   # float result of double sin/cos: <= 1 ulp at |v| < 256
+    assert np.array_equal(m[:, :, :8], m[:, :, wdst : wdst + 8]) and np.array_equal(m[:, :, wdst + 8 :], m[:, :, 8:16])   # circular pad :42-47
+    p = dfe.getP2CMask(wdst, hdst, wsrc, hsrc, e2[0], e2[1], rmax).cpu().numpy()
+    pref = orc.polar_grid_p2c(wdst, hdst, wsrc, hsrc, e2[0], e2[1], rmax)
+    assert np.allclose(p, pref, rtol=0, atol=2e-5)
+    rng = np.random.default_rng(0)
+    img = rng.random((3, hsrc, wsrc), dtype=np.float32)
+    mt = T(ref, cuda)
+    w = dfe.cartesian2polar(T(img, cuda), mt).cpu().numpy()
+    wref = orc.warp_bilinear(img, ref)
+    assert np.allclose(w, wref, rtol=0, atol=1e-6)
+    # C2P then P2C reproduces the image away from the centre and the rim (cartesian2polar_testme idea, :95-106)
+    pol = dfe.cartesian2polar(T(img, cuda), dfe.getC2PMask(wsrc, hsrc, 720, 400, e2[0], e2[1], 0, 0, rmax))
+    back = dfe.cartesian2polar(pol, dfe.getP2CMask(720, 400, wsrc, hsrc, e2[0], e2[1], rmax)).cpu().numpy()
+    yy, xx = np.mgrid[0:hsrc, 0:wsrc]
+    rr = np.hypot(xx - e2[0], yy - e2[1])
+    ring = (rr > 12) & (rr < rmax - 3)
+    assert np.abs(back - img)[:, ring].mean() < 0.08
+
+
+def test_flow2depth_radial(dfe, cuda):
+    rng = np.random.default_rng(1)
+    H, W = 60, 80
+    f = (rng.random((H, W)) * 3).astype(np.float32)
+    f[5, 5] = 0.05
+    networkp = dict(hImg=H, wImg=W)
+    center = (33.0, 27.0)
+    d, c = dfe.flow2depth(networkp, T(f, cuda), center, 0.65)
+    infty = dfe.getRMax(H, W, center) * 0.65
+    ed, ec = orc.flow_to_depth_radial(f, center[0], center[1], infty)
+    assert np.allclose(d.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(c.cpu().numpy(), ec)
+    assert ec[27, 33] == 0 and ed[27, 33] == 0 and abs(ed[5, 5] - 1.0) < 1e-6
