@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdfe.so")
+LIB_PATH = os.environ.get("DFE_LIB") or os.path.join(_HERE, "libdfe.so")  # DFE_LIB: tuning builds only
 
 DFE_OK = 0
 DFE_MAX_RATIOS = 10

@@ -52,6 +52,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("DFE_CV_ROWSPAN")) ctx->cv_rowspan = atoi(e);   // tuning: auto mode prefers the row-span kernel
     if (!own_stream) {
         ctx->stream = (hipStream_t)stream;   // NULL = the default stream
     } else {
@@ -116,14 +117,14 @@ int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
-    DFE_REQUIRE(ctx, mode >= 0 && mode <= 2, DFE_E_ARG, "cost-volume kernel mode %d not in 0..2", mode);
+    DFE_REQUIRE(ctx, mode >= 0 && mode <= 3, DFE_E_ARG, "cost-volume kernel mode %d not in 0..3", mode);
     ctx->cv_mode = mode;
     return DFE_OK;
 }
 
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
-    DFE_REQUIRE(ctx, tyq == 0 || (tyq >= 2 && tyq <= 5), DFE_E_ARG, "tile height code %d not 0 or 2..5", tyq);
+    DFE_REQUIRE(ctx, tyq == 0 || (tyq >= 2 && tyq <= 6), DFE_E_ARG, "tile height code %d not 0 or 2..6", tyq);
     ctx->cv_tyq = tyq;
     return DFE_OK;
 }

@@ -12,6 +12,8 @@ struct dfe_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int cv_mode = 0;                  // dfe_set_cost_volume_kernel
+    int cv_chunk0 = 0;                // tiled kernel covers chunks >= this (set by the row-image launcher for its tail)
+    int cv_rowspan = 0;               // auto mode prefers the row-span kernel where it applies
     int cv_tyq = 0;                   // 0 = pick the tile height per shape; 2..5 = force (tuning / tests)
     int ncu = 256;                    // compute units of the device
     const char *last_kernel = "";
@@ -22,6 +24,7 @@ struct dfe_ctx {
     char err[512] = {0};
     // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)
     bool profile = false;
+    int prof_depth = 0;               // only the outermost DfeProfScope records (a launcher may nest another)
     std::vector<hipEvent_t> prof_events;   // start/stop pairs, resolved by dfe_profile_read
 };
 
@@ -29,13 +32,13 @@ struct dfe_ctx {
 struct DfeProfScope {
     dfe_ctx *ctx;
     explicit DfeProfScope(dfe_ctx *c) : ctx(c) {
-        if (ctx->profile) {
+        if (ctx->profile && ctx->prof_depth++ == 0) {
             hipEvent_t e;
             if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, ctx->stream); ctx->prof_events.push_back(e); }
         }
     }
     ~DfeProfScope() {
-        if (ctx->profile && (ctx->prof_events.size() & 1)) {
+        if (ctx->profile && --ctx->prof_depth == 0 && (ctx->prof_events.size() & 1)) {
             hipEvent_t e;
             if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, ctx->stream); ctx->prof_events.push_back(e); }
         }

@@ -6,7 +6,7 @@
 
 namespace {
 
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;   // one wave per pixel; 4 waves per block
 
 // ---- A6 ------------------------------------------------------------------------------------
 // replaces: m,idx = output:min(3) + centre override, radial/radial_opticalflow_groundtruth.lua:88-94;
@@ -247,7 +247,10 @@ struct TailOut {
     int row_off;         // output-row offset of this band
 };
 
-template <int M>
+// NCH = compile-time bound on ceil(N/64): all of a pixel's loads are issued before the first is consumed
+// (one wave keeps up to NCH x 256 B in flight), then min / first-wins arg-min over registers; the
+// first-M-above-threshold scan walks the same registers in index order and normally stops after one chunk.
+template <int M, int NCH>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void flow_tail_kernel(const float *__restrict__ vol, long long Pband, int N,
                                                                        int hWin, int wWin, int middle, double threshold,
                                                                        TailOut o) {
@@ -258,22 +261,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void flow_tail_kernel(const fl
     const bool want_extract = o.scores != nullptr;
     for (long long p = (long long)blockIdx.x * kWavesPerBlock + w; p < Pband; p += (long long)gridDim.x * kWavesPerBlock) {
         const float *v = vol + p * N;
+        float t[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            t[c] = (k < N) ? v[k] : 0.f;
+        }
+        const float centre = (middle > 0) ? v[middle - 1] : 0.f;   // wave-uniform address
         if (lane < 8) { sh_v[w][lane] = 0.f; sh_i[w][lane] = 0.f; }
-        float b = 0.f;
-        int bi = 0x7fffffff;
-        int n = 0;
-        for (int base = 0; base < N; base += 64) {
-            int k = base + lane;
-            bool in = k < N;
-            float t = in ? v[k] : 0.f;
-            if (in && (bi == 0x7fffffff || t < b)) { b = t; bi = k; }
-            if (want_extract && n < M) {
-                bool hit = in && ((double)t > threshold);
-                unsigned long long mask = __ballot(hit);
-                int rank = n + __popcll(mask & ((1ull << lane) - 1ull));
-                if (hit && rank < M) { sh_v[w][rank] = t; sh_i[w][rank] = (float)(k + 1); }
-                n += __popcll(mask);
-            }
+        float b = t[0];            // lane < N always holds for chunk 0 when N >= 64; guarded below otherwise
+        int bi = (lane < N) ? lane : 0x7fffffff;
+#pragma unroll
+        for (int c = 1; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < N && (bi == 0x7fffffff || t[c] < b)) { b = t[c]; bi = k; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -282,11 +283,25 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void flow_tail_kernel(const fl
             bool take = (oi != 0x7fffffff) && ((bi == 0x7fffffff) || (ob < b) || (ob == b && oi < bi));
             if (take) { b = ob; bi = oi; }
         }
+        if (want_extract) {
+            int n = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (n < M && c * 64 < N) {                       // wave-uniform
+                    const int k = c * 64 + lane;
+                    bool hit = (k < N) && ((double)t[c] > threshold);
+                    unsigned long long mask = __ballot(hit);
+                    int rank = n + __popcll(mask & ((1ull << lane) - 1ull));
+                    if (hit && rank < M) { sh_v[w][rank] = t[c]; sh_i[w][rank] = (float)(k + 1); }
+                    n += __popcll(mask);
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         if (lane == 0) {
             long long id = (long long)bi + 1;
-            if (middle > 0 && b == v[middle - 1]) id = middle;
+            if (middle > 0 && b == centre) id = middle;
             const long long pg = o.p_off + p;
             if (o.idx) o.idx[pg] = id;
             if (o.best) o.best[pg] = b;
@@ -527,13 +542,15 @@ int dfe_flow_tail(dfe_ctx *ctx, const float *vol, int rows, int Wo, int hWin, in
     const long long Pb = (long long)rows * Wo;
     const int N = hWin * wWin;
     const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);   // radial/radial_opticalflow_groundtruth.lua:91
+    DFE_REQUIRE(ctx, N <= 64 * 36, DFE_E_UNSUPPORTED, "dfe_flow_tail: window %dx%d has more than 2304 cells", hWin, wWin);
     int grid = grid_for(Pb, kWavesPerBlock);
-    if (threshold < 0.2)
-        hipLaunchKernelGGL(flow_tail_kernel<8>, dim3(grid), dim3(kWavesPerBlock * 64), 0, ctx->stream, vol, Pb, N, hWin, wWin,
-                           middle, threshold, o);
-    else
-        hipLaunchKernelGGL(flow_tail_kernel<4>, dim3(grid), dim3(kWavesPerBlock * 64), 0, ctx->stream, vol, Pb, N, hWin, wWin,
-                           middle, threshold, o);
+    const bool m8 = threshold < 0.2;   // extract_output.cpp:83-85
+#define DFE_TAIL(MM, NCH) hipLaunchKernelGGL((flow_tail_kernel<MM, NCH>), dim3(grid), dim3(kWavesPerBlock * 64), 0, ctx->stream, vol, Pb, N, hWin, wWin, middle, threshold, o)
+    if (N <= 64 * 2) { if (m8) DFE_TAIL(8, 2); else DFE_TAIL(4, 2); }
+    else if (N <= 64 * 5) { if (m8) DFE_TAIL(8, 5); else DFE_TAIL(4, 5); }
+    else if (N <= 64 * 18) { if (m8) DFE_TAIL(8, 18); else DFE_TAIL(4, 18); }
+    else { if (m8) DFE_TAIL(8, 36); else DFE_TAIL(4, 36); }
+#undef DFE_TAIL
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

@@ -150,10 +150,18 @@ struct CvTiledArgs {
     int pitch;         // LDS row pitch in pixels
     int lrows;         // LDS rows = ROWS + hWin - 1
     int lcols;         // staged columns = TX + K - 1 + wWin - 1
-    int stage_off;     // byte offset of the store-exchange stage inside dynamic LDS
+    int chunk0;        // tiled kernel: first 64-displacement chunk it covers (0 = all; the row-image kernel hands it the tail)
+    int stage_off;     // row-span kernel: byte offset of the store-exchange stage inside dynamic LDS
+    int stage_len;     // row-span kernel: floats per stage buffer
 };
 
 extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
+
+// Tuning-only ablation bits (tools/ablate.sh builds side libraries with -DDFE_ABLATE=n; the product build
+// leaves it 0): 1 = no global stores, 2 = no LDS reads inside the row loop, 4 = no SMEM inside the row loop.
+#ifndef DFE_ABLATE
+#define DFE_ABLATE 0
+#endif
 
 
 // global_store_dword with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset:
@@ -205,12 +213,13 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 
     const int D = p.hWin * p.wWin;
     const int nchunks = (D + 63) >> 6;
-    const int ntasks = NT * nchunks;
+    const int ncover = nchunks - p.chunk0;                       // chunks this launch covers
+    const int ntasks = NT * ncover;
     const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
     for (int task = wave; task < ntasks; task += NW) {
-        const int tile = task / nchunks;                       // wave-uniform
-        const int chunk = task - tile * nchunks;
+        const int tile = task / ncover;                          // wave-uniform
+        const int chunk = p.chunk0 + task - tile * ncover;
         const int xt = x0 + tile * TX;                         // first output column of this task
         const int d = chunk * 64 + lane;
         if (d < D) {   // one divergent region per task (only the last chunk is partial)
@@ -235,6 +244,11 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 #pragma unroll
                 for (int i = 0; i < U; ++i) ring[i][x] = 0.f;
             }
+            px_t abl_px[(NE + 1) / 2 + 1];
+            if (DFE_ABLATE & 2) {
+#pragma unroll
+                for (int s = 0; s < (NE + 1) / 2 + 1; ++s) abl_px[s] = lp[s];
+            }
 
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
                         px_t b[BS];
 #pragma unroll
                         for (int s = 0; s < BS; ++s)
-                            if (bb * BS + s < NE) b[s] = lr[bb * BS + s];
+                            if (bb * BS + s < NE) b[s] = (DFE_ABLATE & 2) ? abl_px[s] : lr[bb * BS + s];
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (C == 3) {
                             // a (free) use of .w keeps each read a 16-B ds_read_b128 instead of the slower b96
@@ -273,15 +287,17 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
                         // last one is requested but never used)
                         const int rn = min(y0 + oy + r + 1, p.H - 1) - (y0 + oy);
                         cfptr an = (cfptr)(I0 + a_base + (long long)rn * p.W);
+                        if (!(DFE_ABLATE & 4)) {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
+                            for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     float h[TX];
                     hsum<K, TX>(e, h);
                     const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
                     const int y = y0 + r - (K - 1);
-                    const bool store_row = emit && y >= y0n;                          // wave-uniform
+                    const bool store_row = emit && y >= y0n && (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f);   // wave-uniform
                     const char *orow = (const char *)(out + ((long long)y * p.Wo + xt) * D);
                     if constexpr (K == 7) {
 #pragma unroll
@@ -364,7 +380,8 @@ static int launch_cv_tiled_one(dfe_ctx *ctx, const CvTilePlan &pl, const float *
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
-    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.stage_off = 0;
+    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.stage_off = 0; a.stage_len = 0;
+    a.chunk0 = ctx->cv_chunk0;
     auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     dim3 grid(dfe_cdiv(Wo, pl.GX), dfe_cdiv(Ho, pl.TY));
@@ -408,13 +425,257 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
 }
 
 // ------------------------------------------------------------------------------------------
+// row-image kernel: 16 adjacent chunks of a tile row leave through an LDS image as whole cache lines
+// ------------------------------------------------------------------------------------------
+// The tiled kernel above hides its arithmetic completely (160 us of compute at VGA) but is bound by its
+// store pattern: 256-B pieces whose neighbours are written later reach 2.9 TB/s, line-aligned contiguous
+// bursts 5.7 TB/s.  Here one block = one TX-pixel tile and 16 waves = the first 16
+// chunks (1024 displacements) of every pixel, one chunk per thread exactly as above.  Per swept row each wave
+// deposits its 64 x TX values into a double-buffered LDS image whose float index is congruent to the
+// global float index mod 32; after one barrier the block copies the TX runs of 4 KB out as 128-B-aligned,
+// 1-KB-per-wave dwordx4 bursts (head/tail fragments of < 32 floats by dword stores), while the next row is
+// already being computed.  Displacement chunks >= 16 (65 of the 1089 cells at 33x33) are written by a
+// second launch of the tiled kernel restricted to those chunks.
+template <int C, int K, int TX, int NQ>
+__global__ __launch_bounds__(1024) void ssd_cv_rowspan_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
+                                                              float *__restrict__ out, CvTiledArgs p) {
+    using px_t = typename Px<C>::type;
+    constexpr int NW = 16;
+    constexpr int U = VUnroll<K>::value;
+    constexpr int ROWS = U * NQ;
+    constexpr int TY = ROWS - (K - 1);
+    constexpr int NE = TX + K - 1;
+    constexpr int RUN = NW * 64;                 // floats per pixel covered by the block
+    constexpr int SL = RUN + 32;                 // stage stride per pixel (multiple of 32 floats)
+    constexpr int NBUF = 3;                      // row images in flight
+    px_t *lds = reinterpret_cast<px_t *>(dfe_smem);
+    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);   // [NBUF][TX][SL], 128-B aligned
+    int *flags = reinterpret_cast<int *>(stage + NBUF * TX * SL);       // [0..NBUF) deposits, [NBUF..2NBUF) copies done
+    int er = 0;                                  // emitted-row ordinal of this block (wave-uniform)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0n = blockIdx.x * TX, y0n = blockIdx.y * TY;
+    const int x0 = min(x0n, p.Wo - TX), y0 = min(y0n, p.Ho - TY);
+    const long long HW = p.plane;
+
+    for (int r = wave; r < p.lrows; r += NW) {
+        const float *src = I1 + (long long)(y0 + r) * p.W + x0;
+        for (int s = lane; s < p.lcols; s += 64) {
+            if constexpr (C == 1) {
+                lds[r * p.pitch + s] = src[s];
+            } else {
+                lds[r * p.pitch + s] = make_float4(src[s], src[HW + s], src[2 * HW + s], 0.f);
+            }
+        }
+    }
+    if (tid < 2 * NBUF) flags[tid] = 0;
+    __syncthreads();
+
+    const int D = p.hWin * p.wWin;
+    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
+    const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
+
+    const int d = wave * 64 + lane;              // < 1024 <= D by the launch condition
+    const int dy = d / p.wWin, dx = d - dy * p.wWin;
+    const px_t *lp = lds + dy * p.pitch + dx;
+
+    float av[C][NE];
+#pragma unroll
+    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + c * HW), av[c]);
+
+    float ring[U][TX], hprev[TX];
+#pragma unroll
+    for (int x = 0; x < TX; ++x) {
+        hprev[x] = 0.f;
+#pragma unroll
+        for (int i = 0; i < U; ++i) ring[i][x] = 0.f;
+    }
+
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
+            const int r = q * U + m;
+            const px_t *lr = lp + r * p.pitch;
+            float e[NE];
+            constexpr int NB = (NE > 8) ? 2 : 1;
+            constexpr int BS = (NE + NB - 1) / NB;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                px_t b[BS];
+#pragma unroll
+                for (int s = 0; s < BS; ++s)
+                    if (bb * BS + s < NE) b[s] = (DFE_ABLATE & 16) ? lp[s] : lr[bb * BS + s];
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C == 3) {
+#pragma unroll
+                    for (int s = 0; s < BS; ++s)
+                        if (bb * BS + s < NE) asm volatile("" ::"v"(b[s].w));   // keep ds_read_b128
+                }
+#pragma unroll
+                for (int s = 0; s < BS; ++s) {
+                    if (bb * BS + s < NE) {
+                        float a3[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) a3[c] = av[c][bb * BS + s];
+                        e[bb * BS + s] = sqdiff<C>(a3, b[s]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const int rn = min(y0 + oy + r + 1, p.H - 1) - (y0 + oy);
+                cfptr an = (cfptr)(I0 + a_base + (long long)rn * p.W);
+#pragma unroll
+                for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float h[TX], v[TX];
+            hsum<K, TX>(e, h);
+            if constexpr (K == 7) {
+#pragma unroll
+                for (int x = 0; x < TX; ++x) {
+                    v[x] = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
+                    ring[(m + 5) % 6][x] = hprev[x] + h[x];
+                    hprev[x] = h[x];
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < TX; ++x) ring[m][x] = h[x];
+#pragma unroll
+                for (int x = 0; x < TX; ++x) {
+                    float t = ring[(m + 1) % K][x];
+#pragma unroll
+                    for (int i = 2; i <= K; ++i) t += ring[(m + i) % K][x];
+                    v[x] = t;
+                }
+            }
+            const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
+            const int y = y0 + r - (K - 1);
+            if (emit && y >= y0n) {                                          // block-uniform
+                const long long G0 = ((long long)y * p.Wo + x0) * D;         // global float index of pixel 0's run
+                const int a0 = (int)(G0 & 31);
+                const int buf = er % NBUF, gen = er / NBUF;
+                float *st = stage + buf * (TX * SL);
+                // (1) the image buffer must have been copied out NBUF rows ago
+                for (int spin = 0; *(volatile int *)&flags[NBUF + buf] < gen && spin < (1 << 18); ++spin)   // bounded: a
+                    __builtin_amdgcn_s_sleep(1);                                                      // broken protocol must not hang the GPU
+                asm volatile("" ::: "memory");
+                // (2) deposit: run x starts at global float G0 + x*D; its image at st + x*SL + ((a0 + x*D) & 31)
+#pragma unroll
+                for (int x = 0; x < TX; ++x) st[x * SL + ((a0 + x * D) & 31) + d] = v[x];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // my deposits have landed in LDS ...
+                if (lane == 0) atomicAdd(&flags[buf], 1);                    // ... before I am counted
+                // (3) ONE wave, rotating with the row, streams the whole image out: 8 runs of 4 KB as line-aligned
+                // 1-KB dwordx4 bursts in consecutive instructions (5.2-5.4 TB/s pattern, tools/ubench/stores6.hip;
+                // the same bytes written by all 16 waves at once after a barrier reach only ~3.3 TB/s).  The other
+                // waves go on with the next row and may run up to NBUF-1 rows ahead of the copier.
+                if (wave == (er & (NW - 1))) {
+                    for (int spin = 0; *(volatile int *)&flags[buf] < NW * (gen + 1) && spin < (1 << 18); ++spin)
+                        __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    if (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f) {
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) {
+                            const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
+                            const int nbody4 = ((RUN - head) >> 5) << 3;     // float4 pieces in whole 128-B lines (248 or 256)
+                            const float *sr = st + x * SL + ax;
+                            float *gr = out + G0 + (long long)x * D;
+                            const float4 *sb = reinterpret_cast<const float4 *>(sr + head);
+                            float4 *gb = reinterpret_cast<float4 *>(gr + head);
+                            float4 t4[4];
+#pragma unroll
+                            for (int it = 0; it < 4; ++it)
+                                if (it * 64 + lane < nbody4) t4[it] = sb[it * 64 + lane];
+                            // head / tail fragments (< 32 floats each): lanes 0..31 head, 32..63 tail
+                            const int tail0 = head + nbody4 * 4, ntail = RUN - tail0;
+                            float tf = 0.f;
+                            const bool fh = lane < 32 && lane < head, ft = lane >= 32 && lane - 32 < ntail;
+                            if (fh) tf = sr[lane];
+                            if (ft) tf = sr[tail0 + lane - 32];
+#pragma unroll
+                            for (int it = 0; it < 4; ++it)
+                                if (it * 64 + lane < nbody4) gb[it * 64 + lane] = t4[it];
+                            if (fh) gr[lane] = tf;
+                            if (ft) gr[tail0 + lane - 32] = tf;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // all image reads done ...
+                    if (lane == 0) *(volatile int *)&flags[NBUF + buf] = gen + 1;   // ... the buffer is free again
+                }
+                ++er;
+            }
+        }
+    }
+}
+
+template <int C, int K, int TX, int NQ>
+static int launch_cv_rowspan_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
+                                 float *out, bool *handled) {
+    using px_t = typename Px<C>::type;
+    constexpr int U = VUnroll<K>::value;
+    constexpr int ROWS = U * NQ, TY = ROWS - (K - 1);
+    static_assert(TX == 8, "the copy-out deals TX*256 float4 slots to 1024 threads");
+    const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+    const int D = hWin * wWin;
+    *handled = false;
+    if (D < 1024 || Ho < TY || Wo < TX) return DFE_OK;   // needs 16 full chunks per pixel
+    CvTiledArgs a;
+    a.plane = plane;
+    a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
+    a.lrows = ROWS + hWin - 1;
+    a.lcols = TX + K - 1 + wWin - 1;
+    const int M = Px<C>::bank_mod;
+    a.pitch = a.lcols;
+    while ((a.pitch - wWin) % M != 0) ++a.pitch;
+    size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
+    a.stage_off = (int)((tile_bytes + 127) / 128 * 128);
+    a.stage_len = TX * (1024 + 32);
+    a.chunk0 = 0;
+    size_t lds_bytes = a.stage_off + (size_t)3 * a.stage_len * sizeof(float) + 64;   // NBUF images + flag words
+    if (lds_bytes > 160 * 1024) return DFE_OK;
+    auto kern = ssd_cv_rowspan_kernel<C, K, TX, NQ>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a);
+        if (D > 1024) {   // the remaining displacement chunks, scattered-piece pattern (6 % of the bytes at 33x33)
+            const int save_mode = ctx->cv_mode, save_tyq = ctx->cv_tyq;
+            ctx->cv_chunk0 = 16; ctx->cv_mode = 2; ctx->cv_tyq = 0;
+            int rc = cv_frames_dispatch(ctx, I0, I1, C, H, W, plane, K, K, hWin, wWin, out);
+            ctx->cv_chunk0 = 0; ctx->cv_mode = save_mode; ctx->cv_tyq = save_tyq;
+            if (rc) return rc;
+        }
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = "ssd_cv_rowspan_kernel";
+    *handled = true;
+    return DFE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 // H is the number of frame rows visible to this call (a row band of a taller frame when plane > H*W)
 int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                               int kw, int hWin, int wWin, float *out) {
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
-    if (ctx->cv_mode != 1 && kh == kw) {
+    if ((ctx->cv_mode == 3 || (ctx->cv_mode == 0 && ctx->cv_rowspan)) && kh == kw && C == 3 && kh == 7) {
+        bool handled = false;
+        int rc;
+        switch (ctx->cv_tyq) {
+            case 3: rc = launch_cv_rowspan_one<3, 7, 8, 3>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            case 4: rc = launch_cv_rowspan_one<3, 7, 8, 4>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            case 6: rc = launch_cv_rowspan_one<3, 7, 8, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            default: rc = launch_cv_rowspan_one<3, 7, 8, 5>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+        }
+        if (rc != DFE_OK || handled) return rc;
+        if (ctx->cv_mode == 3)
+            return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no row-span cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);
+    }
+    if (ctx->cv_mode != 1 && ctx->cv_mode != 3 && kh == kw) {
         bool handled = false;
         int rc = DFE_OK;
         if (C == 3 && kh == 7) rc = launch_cv_tiled<3, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled);

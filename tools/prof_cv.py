@@ -7,7 +7,7 @@ from tests import refpath as rp
 from bench import WORKLOADS
 wl = sys.argv[1] if len(sys.argv) > 1 else "vga"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else int(os.environ.get("CV_MODE", "2"))
 H, W, C, k, hW, wW = WORKLOADS[wl]
 f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=0)
 dev = torch.device("cuda:0")

@@ -14,8 +14,9 @@ for wl in (sys.argv[1:] or ["vga"]):
     t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
     out = torch.empty((H - k - hW + 2, W - k - wW + 2, hW, wW), device=dev)
     balg = algorithmic_bytes(H, W, Cc, k, hW, wW)
-    ctx.set_cost_volume_kernel(2)
-    for tyq in (0, 2, 3, 4, 5):
+    mode = int(os.environ.get("CV_MODE", "2"))
+    ctx.set_cost_volume_kernel(mode)
+    for tyq in ((0, 3, 4, 5, 6) if mode == 3 else (0, 2, 3, 4, 5)):
         ctx.set_cost_volume_tile(tyq)
         for _ in range(3):
             ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hW, wW, out.data_ptr()))
@@ -27,6 +28,6 @@ for wl in (sys.argv[1:] or ["vga"]):
         ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(ms), C.byref(n)))
         ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
         t = ms.value / n.value
-        print("%s tyq=%d  %.1f us  %.0f GB/s  %.1f%% of 8TB/s" % (wl, tyq, t * 1e3, balg / t / 1e6, balg / t / 1e6 / 80))
+        print("%s mode=%d tyq=%d  %.1f us  %.0f GB/s  %.1f%% of 8TB/s" % (wl, mode, tyq, t * 1e3, balg / t / 1e6, balg / t / 1e6 / 80))
     ctx.set_cost_volume_tile(0)
     del out
