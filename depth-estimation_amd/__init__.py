@@ -34,6 +34,7 @@ from .opticalflow_model import (  # noqa: F401
 )
 from .multiscale import CascadingAddTable, MultiscaleModel, getModelMultiscale  # noqa: F401
 from .radial import getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth  # noqa: F401
+from .glue import SmartReshape, FunctionWrapper, Mul2, Log2, OutputExtractor, postProcessImage, enlargeMask  # noqa: F401
 from .groundtruth import (  # noqa: F401
     unfold,
     cross_correlation_pad_output,

@@ -217,6 +217,8 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
     const int ntasks = NT * ncover;
     const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
+    // (Keeping sibling waves on the same row with an s_barrier per row was tried -- adjacent pieces then reach
+    // L2 closer together -- and measured 4 % slower end to end; the waves run free.)
     for (int task = wave; task < ntasks; task += NW) {
         const int tile = task / ncover;                          // wave-uniform
         const int chunk = p.chunk0 + task - tile * ncover;
@@ -447,11 +449,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowspan_kernel(const float *__res
     constexpr int NE = TX + K - 1;
     constexpr int RUN = NW * 64;                 // floats per pixel covered by the block
     constexpr int SL = RUN + 32;                 // stage stride per pixel (multiple of 32 floats)
-    constexpr int NBUF = 3;                      // row images in flight
     px_t *lds = reinterpret_cast<px_t *>(dfe_smem);
-    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);   // [NBUF][TX][SL], 128-B aligned
-    int *flags = reinterpret_cast<int *>(stage + NBUF * TX * SL);       // [0..NBUF) deposits, [NBUF..2NBUF) copies done
-    int er = 0;                                  // emitted-row ordinal of this block (wave-uniform)
+    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);   // [2][TX][SL], 128-B aligned
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -470,7 +469,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowspan_kernel(const float *__res
             }
         }
     }
-    if (tid < 2 * NBUF) flags[tid] = 0;
     __syncthreads();
 
     const int D = p.hWin * p.wWin;
@@ -556,55 +554,41 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowspan_kernel(const float *__res
             if (emit && y >= y0n) {                                          // block-uniform
                 const long long G0 = ((long long)y * p.Wo + x0) * D;         // global float index of pixel 0's run
                 const int a0 = (int)(G0 & 31);
-                const int buf = er % NBUF, gen = er / NBUF;
-                float *st = stage + buf * (TX * SL);
-                // (1) the image buffer must have been copied out NBUF rows ago
-                for (int spin = 0; *(volatile int *)&flags[NBUF + buf] < gen && spin < (1 << 18); ++spin)   // bounded: a
-                    __builtin_amdgcn_s_sleep(1);                                                      // broken protocol must not hang the GPU
-                asm volatile("" ::: "memory");
-                // (2) deposit: run x starts at global float G0 + x*D; its image at st + x*SL + ((a0 + x*D) & 31)
+                float *st = stage + (r & 1) * (TX * SL);
+                // run x starts at global float G0 + x*D; its image starts at st + x*SL + ((a0 + x*D) & 31)
 #pragma unroll
                 for (int x = 0; x < TX; ++x) st[x * SL + ((a0 + x * D) & 31) + d] = v[x];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // my deposits have landed in LDS ...
-                if (lane == 0) atomicAdd(&flags[buf], 1);                    // ... before I am counted
-                // (3) ONE wave, rotating with the row, streams the whole image out: 8 runs of 4 KB as line-aligned
-                // 1-KB dwordx4 bursts in consecutive instructions (5.2-5.4 TB/s pattern, tools/ubench/stores6.hip;
-                // the same bytes written by all 16 waves at once after a barrier reach only ~3.3 TB/s).  The other
-                // waves go on with the next row and may run up to NBUF-1 rows ahead of the copier.
-                if (wave == (er & (NW - 1))) {
-                    for (int spin = 0; *(volatile int *)&flags[buf] < NW * (gen + 1) && spin < (1 << 18); ++spin)
-                        __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                    if (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f) {
+                // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
+                // global stores to be acknowledged before every barrier and serialise stores with compute.
+                // One barrier per row is enough with two images: a wave re-deposits into image (r&1) only
+                // after the barrier of row r+1, which every wave reaches after its copy-out of row r.
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f) {
+                    // body: TX runs x 256 float4 slots, two per thread; a wave covers 1 KB of one run
 #pragma unroll
-                        for (int x = 0; x < TX; ++x) {
-                            const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
-                            const int nbody4 = ((RUN - head) >> 5) << 3;     // float4 pieces in whole 128-B lines (248 or 256)
-                            const float *sr = st + x * SL + ax;
-                            float *gr = out + G0 + (long long)x * D;
-                            const float4 *sb = reinterpret_cast<const float4 *>(sr + head);
-                            float4 *gb = reinterpret_cast<float4 *>(gr + head);
-                            float4 t4[4];
-#pragma unroll
-                            for (int it = 0; it < 4; ++it)
-                                if (it * 64 + lane < nbody4) t4[it] = sb[it * 64 + lane];
-                            // head / tail fragments (< 32 floats each): lanes 0..31 head, 32..63 tail
-                            const int tail0 = head + nbody4 * 4, ntail = RUN - tail0;
-                            float tf = 0.f;
-                            const bool fh = lane < 32 && lane < head, ft = lane >= 32 && lane - 32 < ntail;
-                            if (fh) tf = sr[lane];
-                            if (ft) tf = sr[tail0 + lane - 32];
-#pragma unroll
-                            for (int it = 0; it < 4; ++it)
-                                if (it * 64 + lane < nbody4) gb[it * 64 + lane] = t4[it];
-                            if (fh) gr[lane] = tf;
-                            if (ft) gr[tail0 + lane - 32] = tf;
+                    for (int k2 = 0; k2 < (TX * 256) / 1024; ++k2) {
+                        const int slot = tid + 1024 * k2;
+                        const int x = slot >> 8, j = slot & 255;             // x is wave-uniform
+                        const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
+                        const int nbody4 = ((RUN - head) >> 5) << 3;         // float4 pieces in whole 128-B lines
+                        if (j < nbody4) {
+                            const float4 *sb = reinterpret_cast<const float4 *>(st + x * SL + ax + head);
+                            float4 *gb = reinterpret_cast<float4 *>(out + G0 + (long long)x * D + head);
+                            gb[j] = sb[j];
                         }
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // all image reads done ...
-                    if (lane == 0) *(volatile int *)&flags[NBUF + buf] = gen + 1;   // ... the buffer is free again
+                    // fragments: lanes 0..31 of wave x write run x's head, lanes 32..63 its tail (each < 32 floats)
+                    if (wave < TX && !(DFE_ABLATE & 32)) {
+                        const int x = wave;
+                        const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
+                        const int nbody = ((RUN - head) >> 5) << 5;
+                        const int tail0 = head + nbody, ntail = RUN - tail0;
+                        const float *sr = st + x * SL + ax;
+                        float *gr = out + G0 + (long long)x * D;
+                        if (lane < 32) { if (lane < head) gr[lane] = sr[lane]; }
+                        else if (lane - 32 < ntail) gr[tail0 + lane - 32] = sr[tail0 + lane - 32];
+                    }
                 }
-                ++er;
             }
         }
     }
@@ -633,7 +617,7 @@ static int launch_cv_rowspan_one(dfe_ctx *ctx, const float *I0, const float *I1,
     a.stage_off = (int)((tile_bytes + 127) / 128 * 128);
     a.stage_len = TX * (1024 + 32);
     a.chunk0 = 0;
-    size_t lds_bytes = a.stage_off + (size_t)3 * a.stage_len * sizeof(float) + 64;   // NBUF images + flag words
+    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
     auto kern = ssd_cv_rowspan_kernel<C, K, TX, NQ>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -104,4 +104,8 @@ def __getattr__(name):  # nn.CascadingAddTable lives in multiscale.py (it needs 
         from .multiscale import CascadingAddTable
 
         return CascadingAddTable
+    if name in ("SmartReshape", "FunctionWrapper", "Mul2", "Log2", "OutputExtractor"):
+        from . import glue
+
+        return getattr(glue, name)
     raise AttributeError(name)

@@ -223,6 +223,27 @@ int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, c
 int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, float xcenter,
                              float ycenter, float infty, float *depth, float *conf);
 
+/* ---- A16: postProcessImage(input, mask, winsize, method) ------------------------------------ */
+/* replaces: the inline-C `fmax` (mode) and `fmed` (median) filters and their Lua wrapper
+ *   opticalflow_model.lua:323-472.  flow, out [2][H][W] (plane 0 = y, 1 = x), mask [H][W].
+ *   method 0 = 'max': floor(flow+0.5), shift by the global minimum m, most frequent (vx,vy) of the masked
+ *   k x k window (lowest code on ties), + m everywhere (the untouched border becomes m, as shipped :440);
+ *   DFE_E_ARG when the rounded range exceeds the reference's 16 x 16 histogram.  method 1: per-component
+ *   masked median tmp[n/2]; DFE_E_ARG when k*k > 32 (the reference's buffer).  Windows run over
+ *   i < H-k, j < W-k as shipped.  Synchronises (method 0 reads the range back). */
+int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask, int H, int W,
+                              int winsize, int method, float *out);
+
+/* ---- A17: enlargeMask(mask, ix, iy), in place ------------------------------------------------- */
+/* replaces: depth_estimation_api.lua:76-132. */
+int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy);
+
+/* ---- A18: nn.OutputExtractor:updateOutput (soft arg-max) -------------------------------------- */
+/* replaces: OutputExtractor.lua:21-35 (used by output_extraction_method = 'mean', opticalflow_model.lua:115-116).
+ *   input [P][maxh*maxw] -> x [P] = sum p*j, y [P] = sum p*i with 1-based cell coordinates. */
+int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw,
+                             float *x, float *y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -598,3 +598,107 @@ void orc_warp_bilinear(const float *img, int C, int H, int W, const float *mask,
             }
         }
 }
+
+/* ---- A16 --------------------------------------------------------------- */
+static int cmp_float(const void *a_, const void *b_) { /* ref: opticalflow_model.lua:328-340 */
+    float a = *(const float *)a_, b = *(const float *)b_;
+    return a == b ? 0 : (a < b ? -1 : 1);
+}
+int orc_postprocess_image(const float *flow, const float *mask, int H, int W, int k, int method, float *out) {
+    const size_t HW = (size_t)H * W;
+    const int halfk = k / 2;
+    memset(out, 0, sizeof(float) * 2 * HW);
+    if (method == 0) {
+        /* inputR = floor(input+0.5); m = inputR:min(); fmax(inputR-m, ...); output = output + m  (:436-440) */
+        float *R = (float *)malloc(sizeof(float) * 2 * HW);
+        float m = 0.f, mx = 0.f;
+        for (size_t i = 0; i < 2 * HW; ++i) {
+            R[i] = floorf(flow[i] + 0.5f);
+            if (i == 0 || R[i] < m) m = R[i];
+            if (i == 0 || R[i] > mx) mx = R[i];
+        }
+        if (mx - m > 15.f) { free(R); return -1; }   /* the reference's tmp[256] / ROWSIZE=16 would overflow */
+        for (int i = 0; i < H - k; ++i)
+            for (int j = 0; j < W - k; ++j) {
+                int tmp[256];
+                memset(tmp, 0, sizeof(tmp));
+                for (int ik = i; ik < i + k; ++ik)
+                    for (int jk = j; jk < j + k; ++jk)
+                        if (mask[(size_t)ik * W + jk]) {
+                            int vx = (int)(R[HW + (size_t)ik * W + jk] - m);
+                            int vy = (int)(R[(size_t)ik * W + jk] - m);
+                            ++tmp[vx + 16 * vy];
+                        }
+                int im = 0;
+                for (int l = 0; l < 256; ++l)
+                    if (tmp[l] > tmp[im]) im = l;
+                out[HW + (size_t)(i + halfk) * W + j + halfk] = (float)(im % 16);
+                out[(size_t)(i + halfk) * W + j + halfk] = (float)(im / 16);
+            }
+        for (size_t i = 0; i < 2 * HW; ++i) out[i] += m;
+        free(R);
+        return 0;
+    }
+    if (k * k > 32) return -1;   /* the reference's float tmp[32] would overflow */
+    for (int i = 0; i < H - k; ++i)
+        for (int j = 0; j < W - k; ++j) {
+            float tmp[32], tmp2[32];
+            memset(tmp, 0, sizeof(tmp));
+            memset(tmp2, 0, sizeof(tmp2));
+            int n = 0;
+            for (int ik = i; ik < i + k; ++ik)
+                for (int jk = j; jk < j + k; ++jk)
+                    if (mask[(size_t)ik * W + jk]) {
+                        tmp[n] = flow[(size_t)ik * W + jk];
+                        tmp2[n++] = flow[HW + (size_t)ik * W + jk];
+                    }
+            qsort(tmp, n, sizeof(float), cmp_float);
+            qsort(tmp2, n, sizeof(float), cmp_float);
+            out[HW + (size_t)(i + halfk) * W + j + halfk] = tmp2[n / 2];
+            out[(size_t)(i + halfk) * W + j + halfk] = tmp[n / 2];
+        }
+    return 0;
+}
+
+/* ---- A17 --------------------------------------------------------------- */
+void orc_enlarge_mask(float *mask, int H, int W, int ix, int iy) {
+    /* ref: depth_estimation_api.lua:93-126, literally */
+    for (int i = 0; i < H; ++i) {
+        for (int j = 0; j < W; ++j)
+            if (mask[(size_t)i * W + j] > 0.5) {
+                for (int k = j; k < (j + ix < W ? j + ix : W); ++k) mask[(size_t)i * W + k] = 0.0f;
+                break;
+            }
+        for (int j = W - 1; j >= 0; --j)
+            if (mask[(size_t)i * W + j] > 0.5) {
+                for (int k = j; k >= (j - ix + 1 > 0 ? j - ix + 1 : 0); --k) mask[(size_t)i * W + k] = 0.0f;
+                break;
+            }
+    }
+    for (int j = 0; j < W; ++j) {
+        for (int i = 0; i < H; ++i)
+            if (mask[(size_t)i * W + j] > 0.5) {
+                for (int k = i; k < (i + iy < H ? i + iy : H); ++k) mask[(size_t)k * W + j] = 0.0f;
+                break;
+            }
+        for (int i = H - 1; i >= 0; --i)
+            if (mask[(size_t)i * W + j] > 0.5) {
+                for (int k = i; k >= (i - iy + 1 > 0 ? i - iy + 1 : 0); --k) mask[(size_t)k * W + j] = 0.0f;
+                break;
+            }
+    }
+}
+
+/* ---- A18 --------------------------------------------------------------- */
+void orc_output_extractor(const float *input, int64_t P, int maxh, int maxw, float *x, float *y) {
+    /* ref: OutputExtractor.lua:7-35: xmul[k]=j, ymul[k]=i for k=(i-1)*maxw+j; x = sum(input.*xmul) over dim 3 */
+    int N = maxh * maxw;
+    for (int64_t p = 0; p < P; ++p) {
+        float sx = 0.f, sy = 0.f;
+        for (int k = 0; k < N; ++k) {
+            sx += input[p * N + k] * (float)(k % maxw + 1);
+            sy += input[p * N + k] * (float)(k / maxw + 1);
+        }
+        x[p] = sx; y[p] = sy;
+    }
+}

@@ -136,6 +136,18 @@ void orc_polar_grid_p2c(int wsrc, int hsrc, int wdst, int hdst, float xc, float 
 void orc_warp_bilinear(const float *img, int C, int H, int W, const float *mask, int Hd, int Wd,
                        float *out);
 
+/* A16 postProcessImage(input, mask, winsize, method). ref: opticalflow_model.lua:323-472.
+ * flow [2][H][W] (plane0=y, plane1=x), mask [H][W], out [2][H][W].
+ * method 0 = 'max': mode filter of the rounded flow (fmax :342-386) incl. the +0.5 floor, global-min shift and
+ * the final +m that also lifts the untouched border (:436-440); returns -1 if the rounded range exceeds the
+ * reference's 16x16 histogram.  method 1: per-component masked median (fmed :388-434); -1 if k*k > 32. */
+int orc_postprocess_image(const float *flow, const float *mask, int H, int W, int k, int method, float *out);
+/* A17 enlargeMask(mask, ix, iy), in place. ref: depth_estimation_api.lua:76-132 */
+void orc_enlarge_mask(float *mask, int H, int W, int ix, int iy);
+/* A18 nn.OutputExtractor:updateOutput (soft arg-max expectation). ref: OutputExtractor.lua:21-35.
+ * input [P][maxh*maxw] -> x[P] = sum_k input*j(k), y[P] = sum_k input*i(k), 1-based cell coordinates */
+void orc_output_extractor(const float *input, int64_t P, int maxh, int maxw, float *x, float *y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ def lib():
             "orc_polar_grid_c2p": (None, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
             "orc_polar_grid_p2c": (None, [C.c_int] * 4 + [C.c_float] * 4 + [f32p]),
             "orc_warp_bilinear": (None, [f32p] + [C.c_int] * 3 + [f32p, C.c_int, C.c_int, f32p]),
+            "orc_postprocess_image": (C.c_int, [f32p, f32p] + [C.c_int] * 4 + [f32p]),
+            "orc_enlarge_mask": (None, [f32p] + [C.c_int] * 4),
+            "orc_output_extractor": (None, [f32p, C.c_int64, C.c_int, C.c_int, f32p, f32p]),
         }
         for n, (r, a) in sig.items():
             f = getattr(l, n)
@@ -253,3 +256,25 @@ def warp_bilinear(img, mask):
     out = np.empty((Cc, Hd, Wd), np.float32)
     lib().orc_warp_bilinear(img, Cc, H, W, mask, Hd, Wd, out)
     return out
+
+
+def postprocess_image(flow, mask, k, method):
+    flow, mask = _f(flow), _f(mask)
+    _, H, W = flow.shape
+    out = np.empty_like(flow)
+    rc = lib().orc_postprocess_image(flow, mask, H, W, k, 0 if method == "max" else 1, out)
+    return rc, out
+
+
+def enlarge_mask(mask, ix, iy):
+    m = _f(mask).copy()
+    lib().orc_enlarge_mask(m, m.shape[0], m.shape[1], ix, iy)
+    return m
+
+
+def output_extractor(inp, maxh, maxw):
+    inp = _f(inp)
+    P = inp.size // (maxh * maxw)
+    x, y = np.empty(inp.shape[:-1], np.float32), np.empty(inp.shape[:-1], np.float32)
+    lib().orc_output_extractor(inp.reshape(P, maxh * maxw), P, maxh, maxw, x.reshape(-1), y.reshape(-1))
+    return x, y

@@ -185,3 +185,76 @@ def test_flow2depth_radial(dfe, cuda):
     ed, ec = orc.flow_to_depth_radial(f, center[0], center[1], infty)
     assert np.allclose(d.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(c.cpu().numpy(), ec)
     assert ec[27, 33] == 0 and ed[27, 33] == 0 and abs(ed[5, 5] - 1.0) < 1e-6
+
+
+# ------------------------------------------------------------------ A16 / A17 / A18
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_post_process_image_mode(dfe, cuda, k):
+    rng = np.random.default_rng(k)
+    H, W = 40, 52
+    flow = (rng.integers(-3, 5, size=(2, H, W)) + rng.random((2, H, W)) * 0.8 - 0.4).astype(np.float32)
+    mask = (rng.random((H, W)) > 0.2).astype(np.float32)
+    mask[10:20, 10:20] = 0   # windows with no valid pixel
+    rc, ref = orc.postprocess_image(flow, mask, k, "max")
+    assert rc == 0
+    out = dfe.postProcessImage(T(flow, cuda), T(mask, cuda), k, "max").cpu().numpy()
+    assert np.array_equal(out, ref)
+    m = np.floor(flow + 0.5).min()
+    assert (out[:, 0, :] == m).all()   # the untouched border is lifted by +m, as shipped (opticalflow_model.lua:440)
+    big = flow.copy()
+    big[0, 0, 0] = 40
+    with pytest.raises(dfe.DfeError):
+        dfe.postProcessImage(T(big, cuda), T(mask, cuda), k, "max")
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_post_process_image_median(dfe, cuda, k):
+    rng = np.random.default_rng(10 + k)
+    H, W = 33, 47
+    flow = (rng.standard_normal((2, H, W)) * 4).astype(np.float32)
+    mask = (rng.random((H, W)) > 0.3).astype(np.float32)
+    mask[5:12, 20:30] = 0
+    rc, ref = orc.postprocess_image(flow, mask, k, "med")
+    assert rc == 0
+    out = dfe.postProcessImage(T(flow, cuda), T(mask, cuda), k, "med").cpu().numpy()
+    assert np.array_equal(out, ref)
+    with pytest.raises(dfe.DfeError):
+        dfe.postProcessImage(T(flow, cuda), T(mask, cuda), 7, "med")   # 49 > the reference's 32-value buffer
+
+
+def test_enlarge_mask(dfe, cuda):
+    rng = np.random.default_rng(3)
+    for H, W, ix, iy in [(30, 40, 3, 2), (17, 9, 1, 5), (8, 8, 20, 20)]:
+        mask = (rng.random((H, W)) > 0.35).astype(np.float32)
+        mask[:, 0] = 0
+        mask[3] = 0
+        ref = orc.enlarge_mask(mask, ix, iy)
+        t = T(mask, cuda)
+        r = dfe.enlargeMask(t, ix, iy)
+        assert r is t and np.array_equal(t.cpu().numpy(), ref)
+
+
+def test_glue_modules(dfe, cuda):
+    rng = np.random.default_rng(4)
+    x = T(rng.random((6, 7, 4, 5), dtype=np.float32), cuda)
+    r = dfe.nn.SmartReshape([-1, -2], [-3, -4]).forward(x)   # opticalflow_model.lua:98
+    assert tuple(r.shape) == (42, 20) and torch.equal(r.reshape(6, 7, 4, 5), x)
+    assert tuple(dfe.nn.SmartReshape(-1, 7, -3, 5).forward(x).shape) == (6, 7, 4, 5)
+    with pytest.raises(ValueError, match="don't match"):
+        dfe.nn.SmartReshape(-1, 3).forward(x)
+    fw = dfe.nn.FunctionWrapper(lambda self: setattr(self, "k", 3.0), lambda self, inp: inp * self.k)
+    assert torch.equal(fw.forward(x), x * 3.0)
+    m = dfe.nn.Mul2()
+    m.weight[0] = -0.5
+    assert torch.equal(m.forward(x), x * -0.5)
+    y = x.clone()
+    y[0, 0, 0, 0] = 0.0
+    out = dfe.nn.Log2(1e-10).forward(y)
+    assert float(y[0, 0, 0, 0]) == pytest.approx(1e-10) and torch.allclose(out, y.log())   # input clamped IN PLACE (Log.lua:17)
+    # OutputExtractor: expectation of the 1-based cell coordinates under the probabilities
+    maxh, maxw = 8, 8
+    p = rng.random((9, 11, maxh * maxw), dtype=np.float32)
+    p /= p.sum(-1, keepdims=True)
+    ex, ey = orc.output_extractor(p, maxh, maxw)
+    gx, gy = dfe.nn.OutputExtractor(maxh, maxw).forward(T(p, cuda))
+    assert np.allclose(gx.cpu().numpy(), ex, rtol=0, atol=2e-6) and np.allclose(gy.cpu().numpy(), ey, rtol=0, atol=2e-6)

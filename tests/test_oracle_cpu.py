@@ -239,3 +239,46 @@ def test_golden_fixtures_reproduce():
     assert np.array_equal(g["codec_8_8_124_y"], y) and np.array_equal(g["codec_8_8_124_x"], x)
     yc, xc = orc.x2yx_multi_compat_c(8, 8, [1, 2, 4], ids, fill=-999)
     assert np.array_equal(g["codec_compat_y"], yc) and np.array_equal(g["codec_compat_x"], xc)
+
+
+# --- A16 / A17 / A18 hand-checked -----------------------------------------------------------------
+def test_postprocess_mode_and_median_hand_checked():
+    H, W, k = 6, 7, 3
+    flow = np.zeros((2, H, W), np.float32)
+    flow[0] = 2.0          # y
+    flow[1] = -1.0         # x
+    flow[0, 2, 2] = 5.4    # one outlier inside every 3x3 window around it
+    flow[1, 2, 2] = 3.6
+    mask = np.ones((H, W), np.float32)
+    rc, out = orc.postprocess_image(flow, mask, k, "max")
+    assert rc == 0
+    # windows are anchored at i < H-k, j < W-k and written at (i+1, j+1): rows 1..3, cols 1..4 (as shipped)
+    assert (out[0, 1:4, 1:5] == 2.0).all() and (out[1, 1:4, 1:5] == -1.0).all()
+    assert (out[:, 0, :] == -1.0).all() and (out[:, 4:, :] == -1.0).all()   # untouched border = 0 + m, m = min = -1
+    rc, med = orc.postprocess_image(flow, mask, k, "med")
+    assert rc == 0 and (med[0, 1:4, 1:5] == 2.0).all() and (med[1, 1:4, 1:5] == -1.0).all() and (med[:, 0, :] == 0).all()
+    mask[:] = 0
+    rc, med = orc.postprocess_image(flow, mask, k, "med")
+    assert (med == 0).all()                                                  # n = 0 -> tmp[0] of the zeroed buffer
+    assert orc.postprocess_image(flow, np.ones((H, W), np.float32), 7, "med")[0] != 0   # 49 values > the 32-value buffer
+    flow[0, 0, 0] = 40
+    assert orc.postprocess_image(flow, np.ones((H, W), np.float32), k, "max")[0] != 0   # outside the 16x16 histogram
+
+
+def test_enlarge_mask_hand_checked():
+    m = np.zeros((5, 8), np.float32)
+    m[1:4, 1:7] = 1
+    out = orc.enlarge_mask(m, 2, 1)
+    exp = np.zeros((5, 8), np.float32)
+    exp[2, 3:5] = 1      # rows: 2 px off each side of cols 1..6 -> 3..4; columns: 1 px off top and bottom of rows 1..3 -> 2
+    assert np.array_equal(out, exp)
+
+
+def test_output_extractor_hand_checked():
+    p = np.zeros((1, 6), np.float32)   # 2 x 3 window, all mass on cell (i=2, j=3)
+    p[0, 5] = 1.0
+    x, y = orc.output_extractor(p, 2, 3)
+    assert x[0] == 3.0 and y[0] == 2.0
+    p[:] = 1 / 6
+    x, y = orc.output_extractor(p, 2, 3)
+    assert abs(x[0] - 2.0) < 1e-6 and abs(y[0] - 1.5) < 1e-6
