@@ -67,3 +67,42 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least 
 #define DFE_LAUNCH_CHECK(ctx) DFE_HIP(ctx, hipGetLastError())
 
 static inline int dfe_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+
+// ---- shared by the fused cost-volume epilogue (ssd_cost_volume.hip) and the tail kernels (postops.hip) ----
+// sorting networks of extract_output.cpp:17-61: a comparator swaps value AND index iff v[b] > v[a]
+__device__ __forceinline__ void dfe_sortswap(float *v, float *ix, int a, int b) {
+    if (v[b] > v[a]) {
+        float t = v[b]; v[b] = v[a]; v[a] = t;
+        t = ix[b]; ix[b] = ix[a]; ix[a] = t;
+    }
+}
+__device__ __forceinline__ void dfe_sort4(float *v, float *ix) {   // :27-33
+    dfe_sortswap(v, ix, 0, 2); dfe_sortswap(v, ix, 1, 3); dfe_sortswap(v, ix, 0, 1); dfe_sortswap(v, ix, 2, 3); dfe_sortswap(v, ix, 1, 2);
+}
+__device__ __forceinline__ void dfe_sort8(float *v, float *ix) {   // :35-61
+    dfe_sortswap(v, ix, 0, 1); dfe_sortswap(v, ix, 2, 3); dfe_sortswap(v, ix, 4, 5); dfe_sortswap(v, ix, 6, 7);
+    dfe_sortswap(v, ix, 0, 2); dfe_sortswap(v, ix, 1, 3); dfe_sortswap(v, ix, 4, 6); dfe_sortswap(v, ix, 5, 7);
+    dfe_sortswap(v, ix, 1, 2); dfe_sortswap(v, ix, 5, 6); dfe_sortswap(v, ix, 0, 4); dfe_sortswap(v, ix, 3, 7);
+    dfe_sortswap(v, ix, 1, 5); dfe_sortswap(v, ix, 2, 6);
+    dfe_sortswap(v, ix, 1, 4); dfe_sortswap(v, ix, 3, 6);
+    dfe_sortswap(v, ix, 2, 4); dfe_sortswap(v, ix, 3, 5);
+    dfe_sortswap(v, ix, 3, 4);
+}
+
+// what the cost-volume kernel's fused epilogue leaves behind for flow_finalize_kernel
+#define DFE_LEAD 16   // leading cells of every pixel kept for extractOutput
+struct CvFuseArgs {
+    float2 *part;          // [nchunks][Ptot]: per (chunk, pixel) the chunk's minimum cost and the 0-based index (int bits) of
+                           // the first cell that attains it
+    float *centre;         // [Ptot]: cost of the centre cell
+    float *lead;           // [Ptot][DFE_LEAD]: the pixel's first cells
+    long long Ptot;
+    int cmid, lmid;        // chunk / lane of the centre cell
+    int row_off;           // output-row offset of this launch inside the pair
+};
+int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
+                      const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
+                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded);
+int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled);

@@ -47,24 +47,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void argbest_kernel(const floa
 // replaces: extract_output.cpp:63-155 / :157-255.  The reference scans the N values of a pixel in
 // index order and keeps the first M that exceed the threshold; a wave does the same 64 values at a
 // time with a ballot, so the kept set and its order are identical.
-__device__ __forceinline__ void sortswap(float *v, float *ix, int a, int b) {   // extract_output.cpp:17-26
-    if (v[b] > v[a]) {
-        float t = v[b]; v[b] = v[a]; v[a] = t;
-        t = ix[b]; ix[b] = ix[a]; ix[a] = t;
-    }
-}
-__device__ __forceinline__ void sort4(float *v, float *ix) {   // :27-33
-    sortswap(v, ix, 0, 2); sortswap(v, ix, 1, 3); sortswap(v, ix, 0, 1); sortswap(v, ix, 2, 3); sortswap(v, ix, 1, 2);
-}
-__device__ __forceinline__ void sort8(float *v, float *ix) {   // :35-61
-    sortswap(v, ix, 0, 1); sortswap(v, ix, 2, 3); sortswap(v, ix, 4, 5); sortswap(v, ix, 6, 7);
-    sortswap(v, ix, 0, 2); sortswap(v, ix, 1, 3); sortswap(v, ix, 4, 6); sortswap(v, ix, 5, 7);
-    sortswap(v, ix, 1, 2); sortswap(v, ix, 5, 6); sortswap(v, ix, 0, 4); sortswap(v, ix, 3, 7);
-    sortswap(v, ix, 1, 5); sortswap(v, ix, 2, 6);
-    sortswap(v, ix, 1, 4); sortswap(v, ix, 3, 6);
-    sortswap(v, ix, 2, 4); sortswap(v, ix, 3, 5);
-    sortswap(v, ix, 3, 4);
-}
+// sorting networks: dfe_sort4 / dfe_sort8 in dfe_internal.h (extract_output.cpp:17-61)
+#define sort4 dfe_sort4
+#define sort8 dfe_sort8
 
 template <int M, bool MARG>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void extract_kernel(const float *__restrict__ input, long long P, int N,
@@ -247,6 +232,81 @@ struct TailOut {
     int row_off;         // output-row offset of this band
 };
 
+// Finishes what the fused cost-volume epilogue started; one thread per pixel, everything it normally reads is compact
+// and coalesced (8*nchunks + 4 + 64 bytes per pixel):
+//  A6: the pixel minimum is the minimum of its chunk minima, taken from the FIRST chunk that attains it together
+//      with that chunk's first attaining cell (== the strict '<' scan of the reference); centre override.
+//  A9: decode.  A7: extractOutput looks for the first M values above the threshold among the pixel's first DFE_LEAD
+//      cells (for cost volumes they are there); only if fewer are found does it walk on through the volume in index
+//      order (extract_output.cpp:99-112 stops at M as well).
+template <int M>
+__global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__restrict__ part, const float *__restrict__ centre,
+                                                            const float *__restrict__ lead, int nchunks, long long Ptot,
+                                                            const float *__restrict__ vol, long long Pband, int N, int hWin,
+                                                            int wWin, int middle, double threshold, TailOut o) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < Pband; p += (long long)gridDim.x * blockDim.x) {
+        const long long pg = o.p_off + p;
+        float2 b = part[pg];
+        for (int c = 1; c < nchunks; ++c) {
+            const float2 t = part[(long long)c * Ptot + pg];
+            if (t.x < b.x) b = t;
+        }
+        long long id = (long long)__float_as_int(b.y) + 1;
+        if (middle > 0 && b.x == centre[pg]) id = middle;
+        if (o.idx) o.idx[pg] = id;
+        if (o.best) o.best[pg] = b.x;
+        const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
+        const long long fo = (long long)(y + o.pad_t) * o.pitch + x + o.pad_l;
+        const long long fl = (id - 1) / wWin;
+        if (o.fy) o.fy[fo] = (float)(fl - (hWin - 1) / 2);
+        if (o.fx) o.fx[fo] = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
+        if (o.scores) {
+            float hv[M], hi[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) { hv[j] = 0.f; hi[j] = 0.f; }
+            int n = 0;
+            const float4 *lp = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD);
+#pragma unroll
+            for (int g = 0; g < DFE_LEAD / 4; ++g) {
+                const float4 q = lp[g];
+                const float qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = 4 * g + u;
+                    if (kk < N && n < M && (double)qq[u] > threshold) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j)
+                            if (j == n) { hv[j] = qq[u]; hi[j] = (float)(kk + 1); }
+                        ++n;
+                    }
+                }
+            }
+            if (n < M && N > DFE_LEAD) {   // rare: keep scanning the volume itself
+                const float *v = vol + p * N;
+                for (int kk = DFE_LEAD; kk < N && n < M; ++kk) {
+                    const float t = v[kk];
+                    if ((double)t > threshold) {
+#pragma unroll
+                        for (int j = 0; j < M; ++j)
+                            if (j == n) { hv[j] = t; hi[j] = (float)(kk + 1); }
+                        ++n;
+                    }
+                }
+            }
+            if (hv[0] > 0) {
+                if (M == 4) dfe_sort4(hv, hi); else dfe_sort8(hv, hi);
+                if (o.imaxs) o.imaxs[pg] = (long long)hi[0];
+#pragma unroll
+                for (int j = 1; j < M; ++j) hv[j] += hv[j - 1];
+                double acc = 0;
+#pragma unroll
+                for (int j = 0; j < M; ++j) acc += hv[j];
+                o.scores[o.padded ? fo : pg] = (float)acc;
+            }
+        }
+    }
+}
+
 // NCH = compile-time bound on ceil(N/64): all of a pixel's loads are issued before the first is consumed
 // (one wave keeps up to NCH x 256 B in flight), then min / first-wins arg-min over registers; the
 // first-M-above-threshold scan walks the same registers in index order and normally stops after one chunk.
@@ -315,7 +375,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void flow_tail_kernel(const fl
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { hv[k] = sh_v[w][k]; hi[k] = sh_i[w][k]; }
                 if (hv[0] > 0) {
-                    if (M == 4) sort4(hv, hi); else sort8(hv, hi);
+                    if (M == 4) dfe_sort4(hv, hi); else dfe_sort8(hv, hi);
                     if (o.imaxs) o.imaxs[pg] = (long long)hi[0];
                     for (int k = 1; k < M; ++k) hv[k] += hv[k - 1];
                     double acc = 0;
@@ -379,6 +439,27 @@ int grid_for(long long n, int block) {
 }
 
 }  // namespace
+
+int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
+                      const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
+                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded) {
+    TailOut o;
+    o.idx = (long long *)idx; o.best = best; o.fy = fy; o.fx = fx; o.scores = scores; o.imaxs = (long long *)imaxs;
+    o.Wo = Wo; o.pitch = pitch; o.pad_t = pad_t; o.pad_l = pad_l; o.padded = scores_padded;
+    o.p_off = (long long)row_off * Wo; o.row_off = row_off;
+    const long long Pb = (long long)rows * Wo;
+    const int N = hWin * wWin;
+    const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);
+    const int grid = grid_for(Pb, 256);
+    if (threshold < 0.2)   // extract_output.cpp:83-85
+        hipLaunchKernelGGL(flow_finalize_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
+                           hWin, wWin, middle, threshold, o);
+    else
+        hipLaunchKernelGGL(flow_finalize_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
+                           hWin, wWin, middle, threshold, o);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
 
 extern "C" {
 

@@ -171,6 +171,36 @@ __device__ __forceinline__ void store_uniform_base(const void *base, unsigned la
     asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_bytes), "v"(v), "s"(base) : "memory");
 }
 
+// All-lanes maximum of EIGHT non-negative ints per lane (one per tile column) in ~30 VALU ops instead of 8 x 6:
+// a halving butterfly -- after exchanging with lane^1, lane^2, lane^4 each lane is left with the single column
+// (lane & 7), then lane^8, ^16, ^32 finish it.  lane^1 / lane^2 are DPP quad permutes and lane^8 a row rotate
+// (all fold into v_max_i32_dpp), lane^4 / ^16 are ds_swizzle and lane^32 a ds_bpermute (LDS crossbar, no LDS memory).
+// On return every lane holds the wave maximum of column (lane & 7).
+template <int TX> __device__ __forceinline__ int wave_max8_nonneg(const int (&k)[TX], int lane) {
+    static_assert(TX == 8, "butterfly is written for 8 columns");
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    int a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int mine = b0 ? k[2 * i + 1] : k[2 * i], other = b0 ? k[2 * i] : k[2 * i + 1];
+        a[i] = max(mine, __builtin_amdgcn_update_dpp(0, other, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mine = b1 ? a[2 * i + 1] : a[2 * i], other = b1 ? a[2 * i] : a[2 * i + 1];
+        b[i] = max(mine, __builtin_amdgcn_update_dpp(0, other, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+    }
+    int c;
+    {
+        const int mine = b2 ? b[1] : b[0], other = b2 ? b[0] : b[1];
+        c = max(mine, __builtin_amdgcn_ds_swizzle(other, 0x101f));                          // lane ^ 4
+    }
+    c = max(c, __builtin_amdgcn_update_dpp(0, c, 0x128, 0xf, 0xf, true));                   // row_ror:8  == lane ^ 8 pairing
+    c = max(c, __builtin_amdgcn_ds_swizzle(c, 0x401f));                                     // lane ^ 16
+    c = max(c, __shfl_xor(c, 32));                                                          // lane ^ 32
+    return c;
+}
+
 // Rows are swept in groups of U (the unroll that makes every ring index static):
 //   K == 7: U = 6, vertical sum as the fixed tree ((H0+H1)+(H2+H3))+((H4+H5)+H6) kept as a ring of six
 //           pair sums P_r = H_r + H_{r+1}  -> 4 adds per output;
@@ -181,9 +211,13 @@ template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K;
 // A block owns NT horizontally adjacent TX-pixel tiles (one staged frame-1 tile for all of them) and
 // TY = U*NQ-(K-1) output rows; its NT*nchunks (tile, 64-displacement chunk) tasks are dealt to NW waves,
 // which then run independently (no barrier after the staging one).
-template <int C, int K, int TX, int NT, int NW, int NQ>
+// FUSE: the kernel also leaves, per (chunk, pixel), the chunk's minimum cost + index, the centre cell's cost and (from
+// the wave that holds chunk 0) the extractOutput score, so the flow needs no second pass over the 1.16 GB volume: the
+// values are still in registers when they are stored.  The wave minimum is a 6-step DPP reduction, the first-index
+// rule a ballot; the arithmetic added (~50 %) hides under the store stream that bounds this kernel.
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE>
 __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
-                                                               float *__restrict__ out, CvTiledArgs p) {
+                                                               float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ;
@@ -224,8 +258,12 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
         const int chunk = p.chunk0 + task - tile * ncover;
         const int xt = x0 + tile * TX;                         // first output column of this task
         const int d = chunk * 64 + lane;
-        if (d < D) {   // one divergent region per task (only the last chunk is partial)
-            const int dy = d / p.wWin, dx = d - dy * p.wWin;
+        const bool valid = d < D;
+        // plain build: one divergent region per task (only the last chunk is partial).  FUSE: every lane runs
+        // (idle lanes shadow the last cell) because the wave reductions need the full wave; their stores are masked.
+        if (FUSE || valid) {
+            const int dc = valid ? d : D - 1;
+            const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
             const px_t *lp = lds + dy * p.pitch + dx + tile * TX;
             const unsigned dbytes = (unsigned)d * 4u;
 
@@ -301,16 +339,11 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
                     const int y = y0 + r - (K - 1);
                     const bool store_row = emit && y >= y0n && (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f);   // wave-uniform
                     const char *orow = (const char *)(out + ((long long)y * p.Wo + xt) * D);
+                    float vrow[TX];
                     if constexpr (K == 7) {
 #pragma unroll
                         for (int x = 0; x < TX; ++x) {
-                            if (store_row) {
-                                float v = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
-                                store_uniform_base(orow + (long long)x * D * 4, dbytes, v);
-                            }
-                        }
-#pragma unroll
-                        for (int x = 0; x < TX; ++x) {
+                            vrow[x] = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
                             ring[(m + 5) % 6][x] = hprev[x] + h[x];   // P_{r-1}; its slot held P_{r-7}, consumed last row
                             hprev[x] = h[x];
                         }
@@ -319,11 +352,42 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
                         for (int x = 0; x < TX; ++x) ring[m][x] = h[x];
 #pragma unroll
                         for (int x = 0; x < TX; ++x) {
-                            if (store_row) {
-                                float v = ring[(m + 1) % K][x];   // oldest row first
+                            float t = ring[(m + 1) % K][x];   // oldest row first
 #pragma unroll
-                                for (int i = 2; i <= K; ++i) v += ring[(m + i) % K][x];
-                                store_uniform_base(orow + (long long)x * D * 4, dbytes, v);
+                            for (int i = 2; i <= K; ++i) t += ring[(m + i) % K][x];
+                            vrow[x] = t;
+                        }
+                    }
+                    if (store_row) {
+#pragma unroll
+                        for (int x = 0; x < TX; ++x)
+                            if (!FUSE || valid) store_uniform_base(orow + (long long)x * D * 4, dbytes, vrow[x]);
+                        if constexpr (FUSE) {
+                            // Costs are >= 0, so their bit patterns order like integers; key = 0x7f800000 - bits is >= 0 and
+                            // larger for smaller costs, idle lanes (key 0) lose.  Butterfly 1 leaves lane L with the chunk
+                            // minimum of column L&7; each lane then fetches the 8 column maxima of its 8-lane group, marks
+                            // where it attains them, and butterfly 2 (max of 63-lane) yields the FIRST lane that does.
+                            int key[TX];
+#pragma unroll
+                            for (int x = 0; x < TX; ++x) key[x] = valid ? 0x7f800000 - __float_as_int(vrow[x]) : 0;
+                            const int wk = wave_max8_nonneg<TX>(key, lane);
+                            int cand[TX];
+#define DFE_CAND(x) cand[x] = (key[x] == __builtin_amdgcn_ds_swizzle(wk, 0x0018 | ((x) << 5))) ? 64 - lane : 0;
+                            // swizzle: lane (L & 0x18) | x of my half holds column x's maximum; 64-lane: earlier lane = larger
+                            DFE_CAND(0) DFE_CAND(1) DFE_CAND(2) DFE_CAND(3) DFE_CAND(4) DFE_CAND(5) DFE_CAND(6) DFE_CAND(7)
+#undef DFE_CAND
+                            const int wl = wave_max8_nonneg<TX>(cand, lane);
+                            const long long pg0 = (long long)(fa.row_off + y) * p.Wo + xt;          // pixel of column 0
+                            if (lane < TX)
+                                fa.part[(long long)chunk * fa.Ptot + pg0 + lane] =
+                                    make_float2(__int_as_float(0x7f800000 - wk), __int_as_float(chunk * 64 + 64 - wl));
+                            if (chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
+#pragma unroll
+                                for (int x = 0; x < TX; ++x) fa.centre[pg0 + x] = vrow[x];
+                            }
+                            if (chunk == 0 && lane < DFE_LEAD) {           // the pixel's first cells, for extractOutput
+#pragma unroll
+                                for (int x = 0; x < TX; ++x) fa.lead[(pg0 + x) * DFE_LEAD + lane] = valid ? vrow[x] : 0.f;
                             }
                         }
                     }
@@ -375,24 +439,26 @@ static CvTilePlan plan_cv_tiled(int NQ, int Ho, int Wo, int hWin, int wWin, int 
     return pl;
 }
 
-template <int C, int K, int TX, int NT, int NW, int NQ>
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE = false>
 static int launch_cv_tiled_one(dfe_ctx *ctx, const CvTilePlan &pl, const float *I0, const float *I1, int H, int W,
-                               long long plane, int hWin, int wWin, float *out) {
+                               long long plane, int hWin, int wWin, float *out, const CvFuseArgs *fa = nullptr) {
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
     a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.stage_off = 0; a.stage_len = 0;
     a.chunk0 = ctx->cv_chunk0;
-    auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ>;
+    auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ, FUSE>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     dim3 grid(dfe_cdiv(Wo, pl.GX), dfe_cdiv(Ho, pl.TY));
+    CvFuseArgs f{};
+    if (fa) f = *fa;
     {
         DfeProfScope prof(ctx);
-        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), pl.lds_bytes, ctx->stream, I0, I1, out, a);
+        hipLaunchKernelGGL(kern, grid, dim3(NW * 64), pl.lds_bytes, ctx->stream, I0, I1, out, a, f);
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = "ssd_cv_tiled_kernel";
+    ctx->last_kernel = FUSE ? "ssd_cv_tiled_kernel+fused_tail" : "ssd_cv_tiled_kernel";
     return DFE_OK;
 }
 
@@ -424,6 +490,39 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
         case 14: return launch_cv_tiled_one<C, K, TX, 1, 6, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         default: return launch_cv_tiled_one<C, K, TX, 1, 6, 5>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
     }
+}
+
+// fused build: the (4 tiles, 8 waves) block shape only; the caller falls back to build + tail pass otherwise
+template <int C, int K, int TX>
+static int launch_cv_tiled_fused(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin,
+                                 int wWin, float *out, const CvFuseArgs &fa, bool *handled) {
+    const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+    *handled = false;
+    int best = 0;
+    CvTilePlan bp{};
+    for (int nq = 2; nq <= 5; ++nq) {
+        if (ctx->cv_tyq && nq != ctx->cv_tyq) continue;
+        CvTilePlan p4 = plan_cv_tiled<C, K, TX, 4, 8>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
+        if (p4.score > bp.score) { bp = p4; best = nq; }
+    }
+    if (!best) return DFE_OK;
+    *handled = true;
+    switch (best) {
+        case 2: return launch_cv_tiled_one<C, K, TX, 4, 8, 2, true>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out, &fa);
+        case 3: return launch_cv_tiled_one<C, K, TX, 4, 8, 3, true>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out, &fa);
+        case 4: return launch_cv_tiled_one<C, K, TX, 4, 8, 4, true>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out, &fa);
+        default: return launch_cv_tiled_one<C, K, TX, 4, 8, 5, true>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out, &fa);
+    }
+}
+
+int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled) {
+    *handled = false;
+    if (ctx->cv_mode != 0 && ctx->cv_mode != 2) return DFE_OK;
+    if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
+    if (C == 3 && k == 7) return launch_cv_tiled_fused<3, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+    if (C == 1 && k == 7) return launch_cv_tiled_fused<1, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+    return DFE_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -704,6 +803,58 @@ static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D) {
     return (int)band;
 }
 
+// One pair through build + flow extraction.  Preferred: the fused build (per-chunk minimum + first index, the centre
+// cell and the pixel's first 16 cells leave the kernel with the volume, ~210 compact bytes per pixel) + a finalize that
+// reads only those; it goes back to the volume only for pixels whose first 16 cells hold fewer than M values above
+// the extractOutput threshold.
+// Fallback (shapes without a fused instantiation): build, then the full pass dfe_flow_tail.
+static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin,
+                         double thr, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int pitch,
+                         int pad_t, int pad_l, int scores_padded) {
+    const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
+    const int D = hWin * wWin, nch = (D + 63) / 64;
+    const long long P = (long long)Ho * Wo;
+    const int band = band_rows(ctx, Ho, Wo, D);
+    const size_t vol_bytes = ((size_t)band * Wo * D * sizeof(float) + 255) / 256 * 256;
+    const size_t part_bytes = ((size_t)nch * P * sizeof(float2) + 255) / 256 * 256;
+    const size_t cen_bytes = ((size_t)P * sizeof(float) + 255) / 256 * 256;
+    const size_t lead_bytes = ((size_t)P * DFE_LEAD * sizeof(float) + 255) / 256 * 256;
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, vol_bytes + part_bytes + cen_bytes + lead_bytes, &scr);
+    if (rc) return rc;
+    float *vol = (float *)scr;
+    CvFuseArgs fa{};
+    fa.part = (float2 *)((char *)scr + vol_bytes);
+    fa.centre = (float *)((char *)scr + vol_bytes + part_bytes);
+    fa.lead = (float *)((char *)scr + vol_bytes + part_bytes + cen_bytes);
+    fa.Ptot = P;
+    {
+        const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);   // radial/radial_opticalflow_groundtruth.lua:91
+        fa.cmid = (middle - 1) >> 6; fa.lmid = (middle - 1) & 63;
+    }
+    for (int r0 = 0; r0 < Ho; r0 += band) {
+        const int nr = (r0 + band <= Ho) ? band : Ho - r0;
+        const int Hb = nr + kh - 1 + hWin - 1;
+        const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
+        bool fused = false;
+        if (kh == kw) {
+            fa.row_off = r0;
+            rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused);
+            if (rc) return rc;
+        }
+        if (fused) {
+            rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nch, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
+                                   imaxs, pitch, pad_t, pad_l, scores_padded);
+        } else {
+            rc = cv_frames_dispatch(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, kw, hWin, wWin, vol);
+            if (rc) return rc;
+            rc = dfe_flow_tail(ctx, vol, nr, Wo, hWin, wWin, thr, r0, idx, best, fy, fx, scores, imaxs, pitch, pad_t, pad_l, scores_padded);
+        }
+        if (rc) return rc;
+    }
+    return DFE_OK;
+}
+
 int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin,
                      int wWin, double extract_threshold, int64_t *idx, float *best, float *flow_y, float *flow_x,
                      float *scores, int64_t *imaxs) {
@@ -715,23 +866,8 @@ int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int 
     DFE_REQUIRE(ctx, Ho > 0 && Wo > 0, DFE_E_SHAPE, "dfe_ssd_flow_f32: frame %dx%d too small for kernel %dx%d + window %dx%d",
                 H, W, kh, kw, hWin, wWin);
     DFE_REQUIRE(ctx, (scores == nullptr) == (imaxs == nullptr), DFE_E_ARG, "dfe_ssd_flow_f32: scores and imaxs go together");
-    const int D = hWin * wWin;
-    const int band = band_rows(ctx, Ho, Wo, D);
-    void *scr = nullptr;
-    int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
-    if (rc) return rc;
-    float *vol = (float *)scr;
-    for (int r0 = 0; r0 < Ho; r0 += band) {
-        int nr = (r0 + band <= Ho) ? band : Ho - r0;
-        int Hb = nr + kh - 1 + hWin - 1;
-        rc = cv_frames_dispatch(ctx, I0 + (long long)r0 * W, I1 + (long long)r0 * W, C, Hb, W, (long long)H * W, kh, kw, hWin,
-                                wWin, vol);
-        if (rc) return rc;
-        rc = dfe_flow_tail(ctx, vol, nr, Wo, hWin, wWin, extract_threshold, r0, idx, best, flow_y, flow_x, scores, imaxs, Wo, 0,
-                           0, 0);
-        if (rc) return rc;
-    }
-    return DFE_OK;
+    return flow_pipeline(ctx, I0, I1, C, H, W, kh, kw, hWin, wWin, extract_threshold, idx, best, flow_y, flow_x, scores, imaxs, Wo, 0,
+                         0, 0);
 }
 
 int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin,
@@ -746,27 +882,15 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     const int Ho = H - k + 1 - hWin + 1, Wo = W - k + 1 - wWin + 1;
     DFE_REQUIRE(ctx, Ho > 0 && Wo > 0, DFE_E_SHAPE, "dfe_flow_depth_pair_f32: frame %dx%d too small for kernel %d + window %dx%d",
                 H, W, k, hWin, wWin);
-    const int D = hWin * wWin;
     const long long HW = (long long)H * W;
     // centre-paste offsets: opticalflow_model.lua:228-230 floor((hImg-h)/2)
     //   == radial/radial_opticalflow_groundtruth.lua:27-32 floor((hWin-1)/2)+floor((k-1)/2)
     const int pad_t = (H - Ho) / 2, pad_l = (W - Wo) / 2;
     DFE_HIP(ctx, hipMemsetAsync(flow, 0, 2 * HW * sizeof(float), ctx->stream));
     if (scores) DFE_HIP(ctx, hipMemsetAsync(scores, 0, HW * sizeof(float), ctx->stream));
-    const int band = band_rows(ctx, Ho, Wo, D);
-    void *scr = nullptr;
-    int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
+    int rc = flow_pipeline(ctx, I0, I1, C, H, W, k, k, hWin, wWin, extract_threshold, nullptr, nullptr, flow, flow + HW, scores, nullptr,
+                           W, pad_t, pad_l, 1);
     if (rc) return rc;
-    float *vol = (float *)scr;
-    for (int r0 = 0; r0 < Ho; r0 += band) {
-        int nr = (r0 + band <= Ho) ? band : Ho - r0;
-        int Hb = nr + k - 1 + hWin - 1;
-        rc = cv_frames_dispatch(ctx, I0 + (long long)r0 * W, I1 + (long long)r0 * W, C, Hb, W, HW, k, k, hWin, wWin, vol);
-        if (rc) return rc;
-        rc = dfe_flow_tail(ctx, vol, nr, Wo, hWin, wWin, extract_threshold, r0, nullptr, nullptr, flow, flow + HW, scores,
-                           nullptr, W, pad_t, pad_l, 1);
-        if (rc) return rc;
-    }
     if (depth) {
         rc = dfe_flow_to_depth_cartesian(ctx, flow, H, W, foe_x, foe_y, 0, depth, depth_conf);
         if (rc) return rc;

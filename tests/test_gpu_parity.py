@@ -241,6 +241,49 @@ def test_fused_flow_entry_bit_exact_on_integer_frames(dfe, cuda):
     assert (np.abs(got_y - flow[0][inner]) <= 0).mean() > 0.9
 
 
+@pytest.mark.parametrize(
+    "hWin,wWin,C,thr",
+    [
+        (33, 33, 3, 0.21),      # 18 chunks, last one a single cell; M = 4
+        (17, 17, 3, 0.11),      # 5 chunks, last one 33 cells; M = 8
+        (16, 16, 1, 0.21),      # exactly 4 chunks, luminance
+        (8, 8, 3, 0.21),        # one chunk: nothing beyond chunk 0 to look at
+        (33, 33, 3, 20000.0),   # most pixels have fewer than 4 hits in their first 64 cells -> device-side fallback pass
+        (17, 17, 3, 1e12),      # nothing above the threshold anywhere -> scores / imaxs untouched
+    ],
+)
+def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr):
+    """dfe_ssd_flow_f32 through the fused build (minima, centre cost and extractOutput leave the cost-volume kernel)
+    == oracle, including the fallback for pixels whose first chunk has too few values above the threshold."""
+    H, W = 90, 110
+    f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=hWin + C, max_flow=min(hWin, wWin) // 2 - 1, noise_sigma=1.0)
+    ref = rp.dense_flow_oracle(f0, f1, hWin, wWin, 7, 7, thr=thr)
+    Ho, Wo = ref["idx"].shape
+    ctx = dfe.get_ctx(0)
+    for limit in (None, 2 << 20):   # whole volume in one band, then ~2 MiB bands
+        if limit:
+            ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, limit))
+        try:
+            idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+            best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
+            fy, fx = torch.empty_like(best), torch.empty_like(best)
+            scores = torch.full((Ho, Wo), -2.0, device=cuda)
+            imaxs = torch.full((Ho, Wo), -5, dtype=torch.int64, device=cuda)
+            t0, t1 = T(f0, cuda), T(f1, cuda)
+            ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, 7, 7, hWin, wWin, thr,
+                                                idx.data_ptr(), best.data_ptr(), fy.data_ptr(), fx.data_ptr(), scores.data_ptr(), imaxs.data_ptr()))
+            if not limit:   # (a short last band may legitimately fall back to the reference-order kernel + tail pass)
+                assert ctx.last_kernel() == "ssd_cv_tiled_kernel+fused_tail"
+        finally:
+            ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, 16 << 30))
+        assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+        assert np.array_equal(best.cpu().numpy(), ref["best"])
+        assert np.array_equal(fy.cpu().numpy(), ref["fy"]) and np.array_equal(fx.cpu().numpy(), ref["fx"])
+        sc, im = np.full((Ho, Wo), -2.0, np.float32), np.full((Ho, Wo), -5, np.int64)
+        orc.extract_output(ref["cost"].reshape(Ho, Wo, -1), thr, im, sc)
+        assert np.array_equal(imaxs.cpu().numpy(), im) and np.array_equal(scores.cpu().numpy(), sc)
+
+
 # ------------------------------------------------------------------ per-pixel consumers
 def test_argbest_center_device(dfe, cuda):
     rng = np.random.default_rng(5)
