@@ -52,7 +52,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = getenv("DFE_CV_ROWSPAN")) ctx->cv_rowspan = atoi(e);   // tuning: auto mode prefers the row-span kernel
+    if (const char *e = getenv("DFE_CV_MODE")) { int m = atoi(e); if (m >= 0 && m <= 3) ctx->cv_mode = m; }   // tuning: initial kernel mode
     if (!own_stream) {
         ctx->stream = (hipStream_t)stream;   // NULL = the default stream
     } else {
@@ -124,7 +124,7 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
 
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
-    DFE_REQUIRE(ctx, tyq == 0 || (tyq >= 2 && tyq <= 6), DFE_E_ARG, "tile height code %d not 0 or 2..6", tyq);
+    DFE_REQUIRE(ctx, tyq == 0 || (tyq >= 2 && tyq <= 7), DFE_E_ARG, "tile height code %d not 0 or 2..7", tyq);
     ctx->cv_tyq = tyq;
     return DFE_OK;
 }

@@ -265,20 +265,16 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
 #pragma unroll
             for (int j = 0; j < M; ++j) { hv[j] = 0.f; hi[j] = 0.f; }
             int n = 0;
-            const float4 *lp = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD);
+            float qq[DFE_LEAD];
 #pragma unroll
-            for (int g = 0; g < DFE_LEAD / 4; ++g) {
-                const float4 q = lp[g];
-                const float qq[4] = {q.x, q.y, q.z, q.w};
+            for (int kk = 0; kk < DFE_LEAD; ++kk) qq[kk] = kk < N ? lead[(long long)kk * Ptot + pg] : 0.f;   // all loads in flight
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int kk = 4 * g + u;
-                    if (kk < N && n < M && (double)qq[u] > threshold) {
+            for (int kk = 0; kk < DFE_LEAD; ++kk) {
+                if (kk < N && n < M && (double)qq[kk] > threshold) {
 #pragma unroll
-                        for (int j = 0; j < M; ++j)
-                            if (j == n) { hv[j] = qq[u]; hi[j] = (float)(kk + 1); }
-                        ++n;
-                    }
+                    for (int j = 0; j < M; ++j)
+                        if (j == n) { hv[j] = qq[kk]; hi[j] = (float)(kk + 1); }
+                    ++n;
                 }
             }
             if (n < M && N > DFE_LEAD) {   // rare: keep scanning the volume itself

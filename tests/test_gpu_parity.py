@@ -92,7 +92,7 @@ def test_cost_volume_every_tile_height_bit_exact(dfe, cuda, tyq):
 
 @pytest.mark.parametrize("nq", [0, 3, 4, 5, 6])
 @pytest.mark.parametrize("H,W", [(80, 100), (75, 47), (131, 90)])
-def test_cost_volume_rowspan_kernel_bit_exact(dfe, cuda, nq, H, W):
+def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
     # the row-span kernel (all 18 chunks of a tile row in one block, LDS row image, aligned copy-out), 33x33 window,
     # on frames whose last tile row / column are shifted and whose row spans start at every alignment mod 128 B
     f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + nq, max_flow=9)
@@ -108,7 +108,7 @@ def test_cost_volume_rowspan_kernel_bit_exact(dfe, cuda, nq, H, W):
                 ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, 33, 33, out.data_ptr()))
             return
         ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, 33, 33, out.data_ptr()))
-        assert ctx.last_kernel() == "ssd_cv_rowspan_kernel"
+        assert ctx.last_kernel() == "ssd_cv_rowimg_kernel"
     finally:
         ctx.set_cost_volume_kernel(0)
         ctx.set_cost_volume_tile(0)
@@ -252,17 +252,22 @@ def test_fused_flow_entry_bit_exact_on_integer_frames(dfe, cuda):
         (17, 17, 3, 1e12),      # nothing above the threshold anywhere -> scores / imaxs untouched
     ],
 )
-def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr):
+@pytest.mark.parametrize("mode", [0, 2])
+def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode):
     """dfe_ssd_flow_f32 through the fused build (minima, centre cost and extractOutput leave the cost-volume kernel)
-    == oracle, including the fallback for pixels whose first chunk has too few values above the threshold."""
+    == oracle, including the fallback for pixels whose first cells hold too few values above the threshold.  Auto mode
+    takes the row-image kernel at 33x33 / C=3 and the tiled kernel elsewhere; mode 2 forces the tiled kernel."""
     H, W = 90, 110
+    want = "ssd_cv_rowimg_kernel+fused_tail" if (mode == 0 and hWin == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"
     f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=hWin + C, max_flow=min(hWin, wWin) // 2 - 1, noise_sigma=1.0)
     ref = rp.dense_flow_oracle(f0, f1, hWin, wWin, 7, 7, thr=thr)
     Ho, Wo = ref["idx"].shape
     ctx = dfe.get_ctx(0)
-    for limit in (None, 2 << 20):   # whole volume in one band, then ~2 MiB bands
+    # whole volume in one band, then ~2 MiB bands (auto mode only: a short last band needs the reference-order fallback)
+    for limit in ((None, 2 << 20) if mode == 0 else (None,)):
         if limit:
             ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, limit))
+        ctx.set_cost_volume_kernel(mode)
         try:
             idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
             best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
@@ -273,8 +278,9 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr):
             ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, 7, 7, hWin, wWin, thr,
                                                 idx.data_ptr(), best.data_ptr(), fy.data_ptr(), fx.data_ptr(), scores.data_ptr(), imaxs.data_ptr()))
             if not limit:   # (a short last band may legitimately fall back to the reference-order kernel + tail pass)
-                assert ctx.last_kernel() == "ssd_cv_tiled_kernel+fused_tail"
+                assert ctx.last_kernel() == want
         finally:
+            ctx.set_cost_volume_kernel(0)
             ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, 16 << 30))
         assert np.array_equal(idx.cpu().numpy(), ref["idx"])
         assert np.array_equal(best.cpu().numpy(), ref["best"])
@@ -408,8 +414,8 @@ def test_golden_fixtures_on_gpu(dfe, cuda):
 
 # ------------------------------------------------------------------ full size (BASELINE configs[1]): properties
 def test_full_vga_cost_volume_properties(dfe, cuda):
-    """640x480, C=3, 7x7 patch, 33x33 window: (a) tiled == reference-order kernel bitwise on integer
-    frames (two independent formulations, 1.16 GB each); (b) oracle agreement on a band of rows;
+    """640x480, C=3, 7x7 patch, 33x33 window: (a) tiled == row-image == reference-order kernel bitwise on integer
+    frames (three independent formulations, 1.16 GB each); (b) oracle agreement on a band of rows;
     (c) cost(I,I) is zero exactly at the centre cell; (d) the planted flow is the arg-min."""
     H, W, k, win = 480, 640, 7, 33
     f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=0, max_flow=12, noise_sigma=0)
@@ -427,6 +433,10 @@ def test_full_vga_cost_volume_properties(dfe, cuda):
     assert tuple(tiled.shape) == (442, 602, 33, 33)
     assert torch.equal(tiled, ref)
     del ref
+    rowimg = op.forward([t0, t1])          # auto mode: the row-image kernel, a third formulation of the same sums
+    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel"
+    assert torch.equal(tiled, rowimg)
+    del rowimg
     rows = (0, 3, 200, 203, 439, 442)
     for r0, r1 in zip(rows[::2], rows[1::2]):
         cpu = np.zeros((442, 602, 33, 33), np.float32)[r0:r1] * 0

@@ -1,6 +1,8 @@
 #!/bin/bash
-# Tuning only: builds side libraries of the cost-volume kernel with parts removed (-DDFE_ABLATE=n) and times them.
+# Tuning only: times side libraries of the cost-volume kernels built with parts removed (-DDFE_ABLATE=n):
+#   tools/ablate.sh MODE n [n...]     (MODE = 2 tiled / 3 row-image)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mode=$1; shift
 for n in "$@"; do
-  DFE_LIB=tools/ubench/libdfe_abl$n.so timeout -k 10 120 python tools/tune_cv.py vga 2>&1 | grep "tyq=[045]" | sed "s/^/ABL=$n /"
+  CV_MODE=$mode DFE_LIB=tools/ubench/libdfe_abl$n.so timeout -k 10 120 python tools/tune_cv.py vga 2>&1 | grep "tyq=[34567]" | sed "s/^/ABL=$n /"
 done

@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         k = r.get("Kernel_Name", "")[:60]
         rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in rows.items():
-    if "tiled" not in k and "ref_kernel" not in k and "tail" not in k and "rowspan" not in k: continue
+    if "tiled" not in k and "ref_kernel" not in k and "tail" not in k and "rowimg" not in k: continue
     print("kernel:", k)
     for c in sorted(cs):
         v = cs[c]

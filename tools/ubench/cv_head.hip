@@ -28,7 +28,6 @@
 //                       Summation order is fixed relative to the output pixel (independent of the
 //                       tile), so results do not depend on the launch geometry.
 #include "dfe_internal.h"
-#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // reference-order kernel
@@ -151,19 +150,15 @@ struct CvTiledArgs {
     int pitch;         // LDS row pitch in pixels
     int lrows;         // LDS rows = ROWS + hWin - 1
     int lcols;         // staged columns = TX + K - 1 + wWin - 1
-    int chunk0;        // tiled kernel: first 64-displacement chunk it covers (0 = all)
-    int tile0_off;     // row-image kernel: byte offset of the frame-0 tile inside dynamic LDS
-    int stage_off;     // row-image kernel: byte offset of the run images inside dynamic LDS
-    int stage_len;     // row-image kernel: floats per image
+    int chunk0;        // tiled kernel: first 64-displacement chunk it covers (0 = all; the row-image kernel hands it the tail)
+    int stage_off;     // row-span kernel: byte offset of the store-exchange stage inside dynamic LDS
+    int stage_len;     // row-span kernel: floats per stage buffer
 };
 
 extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 
 // Tuning-only ablation bits (tools/ablate.sh builds side libraries with -DDFE_ABLATE=n; the product build
 // leaves it 0): 1 = no global stores, 2 = no LDS reads inside the row loop, 4 = no SMEM inside the row loop.
-#ifndef DFE_RI_SMEM
-#define DFE_RI_SMEM true   // row-image kernel: frame-0 values through warmed scalar loads (true) or LDS + DPP (false)
-#endif
 #ifndef DFE_ABLATE
 #define DFE_ABLATE 0
 #endif
@@ -181,92 +176,29 @@ __device__ __forceinline__ void store_uniform_base(const void *base, unsigned la
 // (lane & 7), then lane^8, ^16, ^32 finish it.  lane^1 / lane^2 are DPP quad permutes and lane^8 a row rotate
 // (all fold into v_max_i32_dpp), lane^4 / ^16 are ds_swizzle and lane^32 a ds_bpermute (LDS crossbar, no LDS memory).
 // On return every lane holds the wave maximum of column (lane & 7).
-template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], int lane) {
+template <int TX> __device__ __forceinline__ int wave_max8_nonneg(const int (&k)[TX], int lane) {
     static_assert(TX == 8, "butterfly is written for 8 columns");
     const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
     int a[4], b[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int mine = b0 ? k[2 * i + 1] : k[2 * i], other = b0 ? k[2 * i] : k[2 * i + 1];
-        a[i] = min(mine, __builtin_amdgcn_update_dpp(0, other, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
+        a[i] = max(mine, __builtin_amdgcn_update_dpp(0, other, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int mine = b1 ? a[2 * i + 1] : a[2 * i], other = b1 ? a[2 * i] : a[2 * i + 1];
-        b[i] = min(mine, __builtin_amdgcn_update_dpp(0, other, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
+        b[i] = max(mine, __builtin_amdgcn_update_dpp(0, other, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
     }
     int c;
     {
-        // row_ror:4 -- quad q takes from quad q+1 (mod 4): even quads (bit2 = 0) read an odd quad and vice versa, and
-        // the following ror:8 completes the row whichever neighbour was used.
         const int mine = b2 ? b[1] : b[0], other = b2 ? b[0] : b[1];
-        c = min(mine, __builtin_amdgcn_update_dpp(0, other, 0x124, 0xf, 0xf, false));
+        c = max(mine, __builtin_amdgcn_ds_swizzle(other, 0x101f));                          // lane ^ 4
     }
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x128, 0xf, 0xf, false));                  // row_ror:8
-    {   // gfx950 lane-swap instructions keep the cross-row steps on the VALU (no LDS-pipe swizzle/bpermute)
-        const auto r = __builtin_amdgcn_permlane16_swap(c, c, false, false);                // rows {0,1} and {2,3} pair up
-        c = min((int)r[0], (int)r[1]);
-        const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);                // halves pair up
-        c = min((int)q[0], (int)q[1]);
-    }
+    c = max(c, __builtin_amdgcn_update_dpp(0, c, 0x128, 0xf, 0xf, true));                   // row_ror:8  == lane ^ 8 pairing
+    c = max(c, __builtin_amdgcn_ds_swizzle(c, 0x401f));                                     // lane ^ 16
+    c = max(c, __shfl_xor(c, 32));                                                          // lane ^ 32
     return c;
-}
-
-// Fused flow epilogue of one task row (TX columns x 64 cells of chunk `chunk`, pixel pg0 = column 0): leaves, per column,
-// the chunk minimum and the 0-based index of the first cell attaining it in fa.part, plus the centre cell's cost and the
-// pixel's first DFE_LEAD cells.  Costs are >= 0, so their bit patterns order like integers.  The butterfly leaves lane L
-// with the chunk minimum of column L&7 (idle lanes carry +inf).  The first cell attaining it: compare every lane's value
-// with the column minimum (a v_cmp IS a ballot), take the lowest set bit on the scalar unit and drop it into lane x.
-template <int TX>
-__device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool valid, int lane, int chunk, long long pg0,
-                                              const CvFuseArgs &fa) {
-    // (plain stores first: after them the values are only needed as keys -- registers are scarce in the row-image kernel)
-    if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
-#pragma unroll
-        for (int x = 0; x < TX; ++x) fa.centre[pg0 + x] = vrow[x];
-    }
-    if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
-        // the pixel's first cells, for extractOutput: cell-major planes, so a lane's 8 columns are 32 contiguous
-        // bytes (2 stores per row instead of 8) and finalize reads them coalesced
-        f4u_t *lp4 = reinterpret_cast<f4u_t *>(fa.lead + (long long)lane * fa.Ptot + pg0);
-        lp4[0] = f4_t{vrow[0], vrow[1], vrow[2], vrow[3]};
-        lp4[1] = f4_t{vrow[4], vrow[5], vrow[6], vrow[7]};
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int key[TX];
-#pragma unroll
-    for (int x = 0; x < TX; ++x) key[x] = valid ? __float_as_int(vrow[x]) : 0x7f800000;
-    const int wk = wave_min8<TX>(key, lane);
-    int wl = 0;
-    if (!(DFE_ABLATE & 256)) {
-#define DFE_FIRST(x)                                                                                     \
-    {                                                                                                    \
-        const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key[x] == __builtin_amdgcn_readlane(wk, x))); \
-        asm("v_writelane_b32 %0, %1, " #x : "+v"(wl) : "s"(f));                                          \
-    }
-        DFE_FIRST(0) DFE_FIRST(1) DFE_FIRST(2) DFE_FIRST(3) DFE_FIRST(4) DFE_FIRST(5) DFE_FIRST(6) DFE_FIRST(7)
-#undef DFE_FIRST
-    }
-    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345))
-        fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
-}
-
-// the same for ONE column held by all 64 lanes (the row-image kernel's quarter tasks): a plain 6-step reduction
-__device__ __forceinline__ int wave_min1(int c) {
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x124, 0xf, 0xf, false));   // row_ror:4
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x128, 0xf, 0xf, false));   // row_ror:8
-    const auto r = __builtin_amdgcn_permlane16_swap(c, c, false, false);
-    c = min((int)r[0], (int)r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-    return min((int)q[0], (int)q[1]);
-}
-__device__ __forceinline__ void fuse_epilogue_col(float v, bool valid, int lane, int chunk, long long pg, const CvFuseArgs &fa) {
-    const int key = valid ? __float_as_int(v) : 0x7f800000;
-    const int wk = wave_min1(key);
-    const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == wk));
-    if (lane == 0) fa.part[(long long)chunk * fa.Ptot + pg] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + f));
 }
 
 // Rows are swept in groups of U (the unroll that makes every ring index static):
@@ -430,8 +362,34 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 #pragma unroll
                         for (int x = 0; x < TX; ++x)
                             if (!FUSE || valid) store_uniform_base(orow + (long long)x * D * 4, dbytes, vrow[x]);
-                        if constexpr (FUSE && !(DFE_ABLATE & 512))
-                            fuse_epilogue<TX>(vrow, valid, lane, chunk, (long long)(fa.row_off + y) * p.Wo + xt, fa);
+                        if constexpr (FUSE) {
+                            // Costs are >= 0, so their bit patterns order like integers; key = 0x7f800000 - bits is >= 0 and
+                            // larger for smaller costs, idle lanes (key 0) lose.  Butterfly 1 leaves lane L with the chunk
+                            // minimum of column L&7; each lane then fetches the 8 column maxima of its 8-lane group, marks
+                            // where it attains them, and butterfly 2 (max of 63-lane) yields the FIRST lane that does.
+                            int key[TX];
+#pragma unroll
+                            for (int x = 0; x < TX; ++x) key[x] = valid ? 0x7f800000 - __float_as_int(vrow[x]) : 0;
+                            const int wk = wave_max8_nonneg<TX>(key, lane);
+                            int cand[TX];
+#define DFE_CAND(x) cand[x] = (key[x] == __builtin_amdgcn_ds_swizzle(wk, 0x0018 | ((x) << 5))) ? 64 - lane : 0;
+                            // swizzle: lane (L & 0x18) | x of my half holds column x's maximum; 64-lane: earlier lane = larger
+                            DFE_CAND(0) DFE_CAND(1) DFE_CAND(2) DFE_CAND(3) DFE_CAND(4) DFE_CAND(5) DFE_CAND(6) DFE_CAND(7)
+#undef DFE_CAND
+                            const int wl = wave_max8_nonneg<TX>(cand, lane);
+                            const long long pg0 = (long long)(fa.row_off + y) * p.Wo + xt;          // pixel of column 0
+                            if (lane < TX)
+                                fa.part[(long long)chunk * fa.Ptot + pg0 + lane] =
+                                    make_float2(__int_as_float(0x7f800000 - wk), __int_as_float(chunk * 64 + 64 - wl));
+                            if (chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
+#pragma unroll
+                                for (int x = 0; x < TX; ++x) fa.centre[pg0 + x] = vrow[x];
+                            }
+                            if (chunk == 0 && lane < DFE_LEAD) {           // the pixel's first cells, for extractOutput
+#pragma unroll
+                                for (int x = 0; x < TX; ++x) fa.lead[(pg0 + x) * DFE_LEAD + lane] = valid ? vrow[x] : 0.f;
+                            }
+                        }
                     }
                 }
             }
@@ -488,7 +446,7 @@ static int launch_cv_tiled_one(dfe_ctx *ctx, const CvTilePlan &pl, const float *
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
-    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
+    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.stage_off = 0; a.stage_len = 0;
     a.chunk0 = ctx->cv_chunk0;
     auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ, FUSE>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
@@ -557,142 +515,48 @@ static int launch_cv_tiled_fused(dfe_ctx *ctx, const float *I0, const float *I1,
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// row-image kernel: every cell of a tile row leaves through an LDS image as whole cache lines
-// ------------------------------------------------------------------------------------------
-// The tiled kernel above hides its arithmetic completely (160 us of compute at VGA) but is bound by its store
-// pattern: each wave's 256-B piece has two partial cache lines that a sibling completes later, and partial-line
-// writes are what the memory side is slow at (2.9-3.3 TB/s against 5.4 TB/s for line-aligned
-// bursts; a partial line that misses L2 costs a read-modify-write at the ECC-protected HBM).
-// In the reference layout the TX pixels of a tile row are ONE contiguous run of TX*D floats.  Here one block of 16
-// waves owns that run completely and deposits it into a double-buffered LDS image whose float index is congruent to
-// the global float index mod 32; after one LDS-only barrier per row the block copies the image out as 128-B-aligned
-// dwordx4 bursts while the next row is already being computed.  Only the run's first and last line are partial.
-//   * wave w sweeps chunk w (cells 64w..64w+63) exactly like a tiled-kernel task;
-//   * cells 1024..1087 (a 17th chunk that has no wave) are swept as four 2-column quarter tasks by waves 0..3 -- one
-//     per SIMD, so the extra work (0.46 of a task each) stays balanced -- with 12 extra registers of box-filter state;
-//   * cells >= 1088 (one at 33x33, at most 8) are a lane-per-(cell, column) mini task of wave 4.
-// Frame-0 values: the tiled kernel's scalar loads go through L2, and behind this kernel's store stream their latency
-// (waited for before every barrier) serialised compute with the copy-out (345 us -> 240 us without them).  Here the
-// frame-0 tile sits in LDS as well; once per row each lane reads the pixel of column (lane & 15), and the subtract
-// takes its frame-0 operand through DPP row_newbcast:s -- position s of the 14-wide window, no extra instruction,
-// no SGPRs, no SMEM in the loop.
-// Blocks are renumbered so that x-adjacent tiles -- which share the run's boundary lines -- run on the same XCD.
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-template <int S> __device__ __forceinline__ float bcast16(float v) {   // lane S of my row of 16, folded into the consumer
-    if (DFE_ABLATE & 16384) return v;
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + S, 0xf, 0xf, true));
-}
-template <int C, int S> __device__ __forceinline__ float sqdiff_bc(const typename Px<C>::type &a, const typename Px<C>::type &b) {
-    if constexpr (C == 1) {
-        float d = bcast16<S>(a) - b;
-        return d * d;
-    } else {
-        float d0 = bcast16<S>(a.x) - b.x, d1 = bcast16<S>(a.y) - b.y, d2 = bcast16<S>(a.z) - b.z;
-        return fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
-    }
-}
-// One row of a box-filter task over TXL columns: e[s] for the TXL+K-1 positions (frame-1 pixels lr[s] against frame-0
-// positions s of `a`), horizontal K-sums, vertical K-sum through `ring` (phase M of the U-row cycle) -> v.
-template <int C, int K, int TXL, int M, bool SM>
-__device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, const typename Px<C>::type &a,
-                                                const float (&av)[C][TXL + K - 1], float (&ring)[VUnroll<K>::value][TXL],
-                                                float (&v)[TXL]) {
-    using px_t = typename Px<C>::type;
-    constexpr int NEL = TXL + K - 1;
-    constexpr int NB = (NEL > 10) ? 3 : (NEL > 5) ? 2 : 1;   // read batches: registers are the scarce resource here
-    constexpr int BS = (NEL + NB - 1) / NB;
-    float e[NEL];
-    static_for<0, NB>([&](auto bbc) {
-        constexpr int bb = decltype(bbc)::value;
-        px_t b[BS];
-#pragma unroll
-        for (int s = 0; s < BS; ++s)
-            if (bb * BS + s < NEL) b[s] = lr[bb * BS + s];
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (C == 3) {
-#pragma unroll
-            for (int s = 0; s < BS; ++s)
-                if (bb * BS + s < NEL) asm volatile("" ::"v"(b[s].w));   // keep ds_read_b128
-        }
-        static_for<0, BS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value;
-            if constexpr (bb * BS + s < NEL) {
-                if constexpr (SM) {
-                    float a3[C];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) a3[c] = av[c][bb * BS + s];
-                    e[bb * BS + s] = sqdiff<C>(a3, b[s]);
-                } else {
-                    e[bb * BS + s] = sqdiff_bc<C, bb * BS + s>(a, b[s]);
-                }
-            }
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    float h[TXL];
-    hsum<K, TXL>(e, h);
-    if constexpr (K == 7) {
-        // ring holds the pair sums P_{r-5}..P_{r-1} and, in the slot whose P has just been consumed, H_{r-1}
-        // (which becomes P_{r-1} = H_{r-1} + H_r in place)
-#pragma unroll
-        for (int x = 0; x < TXL; ++x) {
-            v[x] = (ring[M][x] + ring[(M + 2) % 6][x]) + (ring[(M + 4) % 6][x] + h[x]);
-            ring[(M + 5) % 6][x] += h[x];
-            ring[M][x] = h[x];
-        }
-    } else {
-#pragma unroll
-        for (int x = 0; x < TXL; ++x) ring[M][x] = h[x];
-#pragma unroll
-        for (int x = 0; x < TXL; ++x) {
-            float t = ring[(M + 1) % K][x];   // oldest row first
-#pragma unroll
-            for (int i = 2; i <= K; ++i) t += ring[(M + i) % K][x];
-            v[x] = t;
-        }
-    }
+int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled) {
+    *handled = false;
+    if (ctx->cv_mode != 0 && ctx->cv_mode != 2) return DFE_OK;
+    if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
+    if (C == 3 && k == 7) return launch_cv_tiled_fused<3, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+    if (C == 1 && k == 7) return launch_cv_tiled_fused<1, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+    return DFE_OK;
 }
 
-template <int C, int K, int TX, int NQ, bool SM, bool FUSE>
-__global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
-                                                             float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
+// ------------------------------------------------------------------------------------------
+// row-image kernel: 16 adjacent chunks of a tile row leave through an LDS image as whole cache lines
+// ------------------------------------------------------------------------------------------
+// The tiled kernel above hides its arithmetic completely (160 us of compute at VGA) but is bound by its
+// store pattern: 256-B pieces whose neighbours are written later reach 2.9 TB/s, line-aligned contiguous
+// bursts 5.7 TB/s.  Here one block = one TX-pixel tile and 16 waves = the first 16
+// chunks (1024 displacements) of every pixel, one chunk per thread exactly as above.  Per swept row each wave
+// deposits its 64 x TX values into a double-buffered LDS image whose float index is congruent to the
+// global float index mod 32; after one barrier the block copies the TX runs of 4 KB out as 128-B-aligned,
+// 1-KB-per-wave dwordx4 bursts (head/tail fragments of < 32 floats by dword stores), while the next row is
+// already being computed.  Displacement chunks >= 16 (65 of the 1089 cells at 33x33) are written by a
+// second launch of the tiled kernel restricted to those chunks.
+template <int C, int K, int TX, int NQ>
+__global__ __launch_bounds__(1024) void ssd_cv_rowspan_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
+                                                              float *__restrict__ out, CvTiledArgs p) {
     using px_t = typename Px<C>::type;
     constexpr int NW = 16;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ;
     constexpr int TY = ROWS - (K - 1);
     constexpr int NE = TX + K - 1;
-    constexpr int TQ = TX / 4;                   // columns of a quarter task
-    static_assert(NE <= 16, "row_newbcast reaches 16 positions");
-    static_assert(TX % 4 == 0, "four quarter tasks");
-    px_t *lds = reinterpret_cast<px_t *>(dfe_smem);                             // frame-1 tile [lrows][pitch]
-    const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + p.tile0_off);    // frame-0 tile [ROWS][32]
-    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);          // [2][stage_len], 128-B aligned
+    constexpr int RUN = NW * 64;                 // floats per pixel covered by the block
+    constexpr int SL = RUN + 32;                 // stage stride per pixel (multiple of 32 floats)
+    px_t *lds = reinterpret_cast<px_t *>(dfe_smem);
+    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);   // [2][TX][SL], 128-B aligned
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware block order: hardware deals linear block ids round-robin to the 8 XCDs; give every XCD a
-    // contiguous range of tiles (x fastest) instead, so neighbours in x share an L2.
-    int bx, by;
-    {
-        const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-        const int per = nb >> 3, rem = nb & 7, xcd = lin & 7, slot = lin >> 3;
-        const int t = xcd * per + min(xcd, rem) + slot;      // XCDs 0..rem-1 own per+1 tiles, the others per
-        by = t / (int)gridDim.x;
-        bx = t - by * (int)gridDim.x;
-    }
-    const int x0n = bx * TX, y0n = by * TY;
+    const int x0n = blockIdx.x * TX, y0n = blockIdx.y * TY;
     const int x0 = min(x0n, p.Wo - TX), y0 = min(y0n, p.Ho - TY);
     const long long HW = p.plane;
-    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
     for (int r = wave; r < p.lrows; r += NW) {
         const float *src = I1 + (long long)(y0 + r) * p.W + x0;
@@ -704,221 +568,142 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             }
         }
     }
-    {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to 32 columns (quarter tasks read at +2w)
-        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
-        for (int r = wave; r < ROWS; r += NW) {
-            if (lane < 32) {
-                const float *src = I0 + (long long)(y0 + oy + r) * p.W + (x0 + ox) + min(lane, NE - 1);
-                if constexpr (C == 1) {
-                    t0w[r * 32 + lane] = src[0];
-                } else {
-                    t0w[r * 32 + lane] = make_float4(src[0], src[HW], src[2 * HW], 0.f);
-                }
-            }
-        }
-    }
-    const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
-    if constexpr (SM && !(DFE_ABLATE & 32768)) {
-        // warm the scalar cache with every frame-0 line this block will read, so that the in-loop scalar loads hit
-        // there and never queue behind the store stream in L2 (a 64-B line per 16 floats; rows dealt to the waves)
-        for (int r = wave; r < ROWS; r += NW) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                cfptr ap = (cfptr)(I0 + a_base + (long long)r * p.W + c * HW);
-                const float w0 = ap[0], w1 = ap[NE - 1];
-                asm volatile("" ::"s"(w0), "s"(w1));
-            }
-        }
-    }
     __syncthreads();
 
     const int D = p.hWin * p.wWin;
-    const int RUN = TX * D;                       // floats in the block's run
-    const int l16 = lane & 15;
+    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
+    const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
+
+    const int d = wave * 64 + lane;              // < 1024 <= D by the launch condition
+    const int dy = d / p.wWin, dx = d - dy * p.wWin;
+    const px_t *lp = lds + dy * p.pitch + dx;
+
     float av[C][NE];
-    if constexpr (SM) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + c * HW), av[c]);
-    }
+    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + c * HW), av[c]);
 
-    // main task: chunk `wave`
-    const int d = wave * 64 + lane;
-    const bool valid = d < D;
-    const px_t *lp;
-    {
-        const int dc = valid ? d : D - 1;         // idle lanes shadow the last cell, their deposits are masked
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lp = lds + dy * p.pitch + dx;
-    }
-    // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
-    const bool has_q = wave < 4 && D > 1024 && !(DFE_ABLATE & 8192);      // wave-uniform
-    const int dq = 1024 + lane;
-    const bool validq = dq < D;
-    const px_t *lpq;
-    {
-        const int dc = validq ? dq : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lpq = lds + dy * p.pitch + dx + TQ * wave;
-    }
-    // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane
-    const bool has_m = wave == 4 && D > 1088 && !(DFE_ABLATE & 8192);     // wave-uniform
-    const int dm = 1088 + (lane >> 3), xm = lane & 7;
-    const bool validm = dm < D && xm < TX;
-    const px_t *lpm;
-    {
-        const int dc = validm ? dm : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lpm = lds + dy * p.pitch + dx + xm;
-    }
-
-    float ring[U][TX], ringq[U][TQ];
-    // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
-    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + ROWS * 32 * sizeof(px_t)) + lane;
+    float ring[U][TX], hprev[TX];
 #pragma unroll
-    for (int i = 0; i < U; ++i) {
+    for (int x = 0; x < TX; ++x) {
+        hprev[x] = 0.f;
 #pragma unroll
-        for (int x = 0; x < TX; ++x) ring[i][x] = 0.f;
-#pragma unroll
-        for (int x = 0; x < TQ; ++x) ringq[i][x] = 0.f;
-        if (wave == 4) rm[i * 64] = 0.f;
+        for (int i = 0; i < U; ++i) ring[i][x] = 0.f;
     }
 
     for (int q = 0; q < NQ; ++q) {
-        static_for<0, U>([&](auto mc) {
-            constexpr int m = decltype(mc)::value;
+#pragma unroll
+        for (int m = 0; m < U; ++m) {
             const int r = q * U + m;
+            const px_t *lr = lp + r * p.pitch;
+            float e[NE];
+            constexpr int NB = (NE > 8) ? 2 : 1;
+            constexpr int BS = (NE + NB - 1) / NB;
+#pragma unroll
+            for (int bb = 0; bb < NB; ++bb) {
+                px_t b[BS];
+#pragma unroll
+                for (int s = 0; s < BS; ++s)
+                    if (bb * BS + s < NE) b[s] = (DFE_ABLATE & 16) ? lp[s] : lr[bb * BS + s];
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (C == 3) {
+#pragma unroll
+                    for (int s = 0; s < BS; ++s)
+                        if (bb * BS + s < NE) asm volatile("" ::"v"(b[s].w));   // keep ds_read_b128
+                }
+#pragma unroll
+                for (int s = 0; s < BS; ++s) {
+                    if (bb * BS + s < NE) {
+                        float a3[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) a3[c] = av[c][bb * BS + s];
+                        e[bb * BS + s] = sqdiff<C>(a3, b[s]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!(DFE_ABLATE & 4096)) {
+                const int rn = min(y0 + oy + r + 1, p.H - 1) - (y0 + oy);
+                cfptr an = (cfptr)(I0 + a_base + (long long)rn * p.W);
+#pragma unroll
+                for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float h[TX], v[TX];
+            hsum<K, TX>(e, h);
+            if constexpr (K == 7) {
+#pragma unroll
+                for (int x = 0; x < TX; ++x) {
+                    v[x] = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
+                    ring[(m + 5) % 6][x] = hprev[x] + h[x];
+                    hprev[x] = h[x];
+                }
+            } else {
+#pragma unroll
+                for (int x = 0; x < TX; ++x) ring[m][x] = h[x];
+#pragma unroll
+                for (int x = 0; x < TX; ++x) {
+                    float t = ring[(m + 1) % K][x];
+#pragma unroll
+                    for (int i = 2; i <= K; ++i) t += ring[(m + i) % K][x];
+                    v[x] = t;
+                }
+            }
             const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
             const int y = y0 + r - (K - 1);
-            const bool store_row = emit && y >= y0n;                         // block-uniform
-            const long long G0 = ((long long)y * p.Wo + x0) * D;             // global float index of the run
-            const int a0 = (int)(G0 & 31);
-            float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
-            const int rn = min(r + 1, ROWS - 1);     // next row of the frame-0 tile (the row after the last is never used)
-            {
-                px_t a;
-                if constexpr (!SM) a = t0[r * 32 + l16];
-                float v[TX];
-                rowimg_task_row<C, K, TX, m, SM>(lp + r * p.pitch, a, av, ring, v);
-                if constexpr (SM) {   // next row's scalars
+            if (emit && y >= y0n) {                                          // block-uniform
+                const long long G0 = ((long long)y * p.Wo + x0) * D;         // global float index of pixel 0's run
+                const int a0 = (int)(G0 & 31);
+                float *st = stage + (r & 1) * (TX * SL);
+                // run x starts at global float G0 + x*D; its image starts at st + x*SL + ((a0 + x*D) & 31)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
-                }
-                // deposit at once (image (r&1) was last read for row r-2, before the barrier of row r-1)
-                if (store_row && valid) {
-#pragma unroll
-                    for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
-                }
-                if constexpr (FUSE) {
-                    if (store_row) fuse_epilogue<TX>(v, valid, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa);
-                }
-            }
-            if (has_q) {
-                // the quarter's frame-0 window always comes through LDS + DPP: its column offset is a run-time value and a
-                // second set of 24 scalars next to the main task's 42 does not fit the SGPR file
-                const px_t a = t0[r * 32 + TQ * wave + l16];
-                const float avq[C][TQ + K - 1] = {};
-                float v[TQ];
-                rowimg_task_row<C, K, TQ, m, false>(lpq + r * p.pitch, a, avq, ringq, v);
-                if (store_row && validq) {
-#pragma unroll
-                    for (int x = 0; x < TQ; ++x) st[(TQ * wave + x) * D + dq] = v[x];
-                }
-                if constexpr (FUSE) {
-                    if (store_row) {
-#pragma unroll
-                        for (int x = 0; x < TQ; ++x)
-                            fuse_epilogue_col(v[x], validq, lane, 16, (long long)(fa.row_off + y) * p.Wo + x0 + TQ * wave + x, fa);
-                    }
-                }
-            }
-            if (has_m) {
-                // per-lane frame-0 pixels: no broadcast here, every lane has its own column
-                const px_t *lr = lpm + r * p.pitch;
-                const px_t *ar = t0 + r * 32 + xm;
-                float e[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    if (j % 3 == 0) __builtin_amdgcn_sched_barrier(0);   // at most 6 pixel reads in flight (registers)
-                    const px_t av = ar[j], bv = lr[j];
-                    if constexpr (C == 1) {
-                        const float a1[1] = {av};
-                        e[j] = sqdiff<1>(a1, bv);
-                    } else {
-                        const float a3[3] = {av.x, av.y, av.z};
-                        e[j] = sqdiff<3>(a3, bv);
-                    }
-                }
-                float h[1], v;
-                hsum<K, 1>(e, h);
-                if constexpr (K == 7) {
-                    const float r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
-                    v = (r0 + r2) + (r4 + h[0]);
-                    rm[((m + 5) % 6) * 64] = r5 + h[0];
-                    rm[m * 64] = h[0];
-                } else {
-                    rm[m * 64] = h[0];
-                    v = rm[((m + 1) % K) * 64];
-#pragma unroll
-                    for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
-                }
-                if (store_row && validm) st[xm * D + dm] = v;
-                if constexpr (FUSE) {
-                    if (store_row) {
-                        // chunk 17 = the cells of this task: minimum over the lanes that share a column (lane ^ 8, 16, 32),
-                        // first attaining cell from the ballot restricted to the column's lanes
-                        const int key = validm ? __float_as_int(v) : 0x7f800000;
-                        int c = min(key, __builtin_amdgcn_update_dpp(0, key, 0x128, 0xf, 0xf, false));   // row_ror:8
-                        const auto r2 = __builtin_amdgcn_permlane16_swap(c, c, false, false);
-                        c = min((int)r2[0], (int)r2[1]);
-                        const auto q2 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-                        c = min((int)q2[0], (int)q2[1]);
-                        const unsigned long long hit = __builtin_amdgcn_ballot_w64(key == c) & (0x0101010101010101ull << xm);
-                        const int f = __builtin_ctzll(hit) >> 3;            // first cell of my column attaining the minimum
-                        if (lane < TX)
-                            fa.part[17ll * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xm] =
-                                make_float2(__int_as_float(c), __int_as_float(1088 + f));
-                    }
-                }
-            }
-            if (store_row) {
+                for (int x = 0; x < TX; ++x) st[x * SL + ((a0 + x * D) & 31) + d] = v[x];
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
                 // global stores to be acknowledged before every barrier and serialise stores with compute.
                 // One barrier per row is enough with two images: a wave re-deposits into image (r&1) only
                 // after the barrier of row r+1, which every wave reaches after its copy-out of row r.
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f) {
-                    const int head = (32 - a0) & 31;                         // floats before the first whole line
-                    const int nbody4 = ((RUN - head) >> 5) << 3;             // float4 pieces in whole 128-B lines
-                    const f4_t *sb = reinterpret_cast<const f4_t *>(st + head);
-                    const float *gb = out + G0 + head;
-                    int tj = tid;
-                    asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
-                    for (int j = tj; j < nbody4; j += NW * 64) {
-                        const f4_t val = sb[j];
-                        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)j * 16u), "v"(val), "s"(gb) : "memory");
+                if (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f) {
+                    // body: TX runs x 256 float4 slots, two per thread; a wave covers 1 KB of one run
+#pragma unroll
+                    for (int k2 = 0; k2 < (TX * 256) / 1024; ++k2) {
+                        const int slot = tid + 1024 * k2;
+                        const int x = slot >> 8, j = slot & 255;             // x is wave-uniform
+                        const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
+                        const int nbody4 = ((RUN - head) >> 5) << 3;         // float4 pieces in whole 128-B lines
+                        if (j < nbody4) {
+                            const float4 *sb = reinterpret_cast<const float4 *>(st + x * SL + ax + head);
+                            float4 *gb = reinterpret_cast<float4 *>(out + G0 + (long long)x * D + head);
+                            gb[j] = sb[j];
+                        }
                     }
-                    if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
-                        const int tail0 = head + (nbody4 << 2), ntail = RUN - tail0;
-                        if (wave == 5 && lane < head) out[G0 + lane] = st[lane];
-                        if (wave == 6 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
+                    // fragments: lanes 0..31 of wave x write run x's head, lanes 32..63 its tail (each < 32 floats)
+                    if (wave < TX && !(DFE_ABLATE & 32)) {
+                        const int x = wave;
+                        const int ax = (a0 + x * D) & 31, head = (32 - ax) & 31;
+                        const int nbody = ((RUN - head) >> 5) << 5;
+                        const int tail0 = head + nbody, ntail = RUN - tail0;
+                        const float *sr = st + x * SL + ax;
+                        float *gr = out + G0 + (long long)x * D;
+                        if (lane < 32) { if (lane < head) gr[lane] = sr[lane]; }
+                        else if (lane - 32 < ntail) gr[tail0 + lane - 32] = sr[tail0 + lane - 32];
                     }
                 }
             }
-        });
+        }
     }
 }
 
-template <int C, int K, int TX, int NQ, bool FUSE>
-static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
-                                float *out, const CvFuseArgs *fa, bool *handled) {
+template <int C, int K, int TX, int NQ>
+static int launch_cv_rowspan_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
+                                 float *out, bool *handled) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ, TY = ROWS - (K - 1);
+    static_assert(TX == 8, "the copy-out deals TX*256 float4 slots to 1024 threads");
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
     const int D = hWin * wWin;
     *handled = false;
-    // 16 chunk waves + the quarter/mini tasks cover up to 1096 cells; below 13 chunks too many waves would idle
-    if (D <= 768 || D > 1096 || Ho < TY || Wo < TX) return DFE_OK;
+    if (D < 1024 || Ho < TY || Wo < TX) return DFE_OK;   // needs 16 full chunks per pixel
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
@@ -928,54 +713,28 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     a.pitch = a.lcols;
     while ((a.pitch - wWin) % M != 0) ++a.pitch;
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
-    a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
-    a.stage_off = a.tile0_off + (int)(((size_t)ROWS * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
-    a.stage_len = (TX * D + 32 + 31) / 32 * 32;
+    a.stage_off = (int)((tile_bytes + 127) / 128 * 128);
+    a.stage_len = TX * (1024 + 32);
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
-    auto kern = ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE>;
+    auto kern = ssd_cv_rowspan_kernel<C, K, TX, NQ>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
     {
         DfeProfScope prof(ctx);
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a);
+        if (D > 1024 && !(DFE_ABLATE & 2048)) {   // the remaining displacement chunks, scattered-piece pattern (6 % of the bytes at 33x33)
+            const int save_mode = ctx->cv_mode, save_tyq = ctx->cv_tyq;
+            ctx->cv_chunk0 = 16; ctx->cv_mode = 2; ctx->cv_tyq = 0;
+            int rc = cv_frames_dispatch(ctx, I0, I1, C, H, W, plane, K, K, hWin, wWin, out);
+            ctx->cv_chunk0 = 0; ctx->cv_mode = save_mode; ctx->cv_tyq = save_tyq;
+            if (rc) return rc;
+        }
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = FUSE ? "ssd_cv_rowimg_kernel+fused_tail" : "ssd_cv_rowimg_kernel";
+    ctx->last_kernel = "ssd_cv_rowspan_kernel";
     *handled = true;
-    return DFE_OK;
-}
-
-// tile height: 24 rows (NQ = 5) unless forced or the frame is shorter
-template <int C, int K, int TX, bool FUSE>
-static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
-                            float *out, const CvFuseArgs *fa, bool *handled) {
-    constexpr int U = VUnroll<K>::value;
-    const int Ho = H - K + 1 - hWin + 1;
-    int nq = ctx->cv_tyq;
-    if (nq == 0) nq = Ho >= U * 5 - (K - 1) ? 5 : Ho >= U * 4 - (K - 1) ? 4 : 3;
-    switch (nq) {
-        case 3: return launch_cv_rowimg_one<C, K, TX, 3, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 4: return launch_cv_rowimg_one<C, K, TX, 4, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 6: return launch_cv_rowimg_one<C, K, TX, 6, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 7: return launch_cv_rowimg_one<C, K, TX, 7, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        default: return launch_cv_rowimg_one<C, K, TX, 5, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-    }
-}
-
-int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
-                             int wWin, float *out, const CvFuseArgs &fa, bool *handled) {
-    *handled = false;
-    if (ctx->cv_mode == 1) return DFE_OK;
-    if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
-    if ((ctx->cv_mode == 0 || ctx->cv_mode == 3) && C == 3 && k == 7) {
-        int rc = launch_cv_rowimg<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled);
-        if (rc != DFE_OK || *handled) return rc;
-    }
-    if (ctx->cv_mode == 3) return DFE_OK;   // forced row-image kernel that does not apply: unfused path reports it
-    if (C == 3 && k == 7) return launch_cv_tiled_fused<3, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-    if (C == 1 && k == 7) return launch_cv_tiled_fused<1, 7, 8>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
     return DFE_OK;
 }
 
@@ -986,12 +745,18 @@ int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int
 int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                               int kw, int hWin, int wWin, float *out) {
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
-    if ((ctx->cv_mode == 3 || ctx->cv_mode == 0) && kh == kw && C == 3 && kh == 7) {
+    if ((ctx->cv_mode == 3 || (ctx->cv_mode == 0 && ctx->cv_rowspan)) && kh == kw && C == 3 && kh == 7) {
         bool handled = false;
-        int rc = launch_cv_rowimg<3, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, nullptr, &handled);
+        int rc;
+        switch (ctx->cv_tyq) {
+            case 3: rc = launch_cv_rowspan_one<3, 7, 8, 3>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            case 4: rc = launch_cv_rowspan_one<3, 7, 8, 4>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            case 6: rc = launch_cv_rowspan_one<3, 7, 8, 6>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+            default: rc = launch_cv_rowspan_one<3, 7, 8, 5>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &handled); break;
+        }
         if (rc != DFE_OK || handled) return rc;
         if (ctx->cv_mode == 3)
-            return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no row-image cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);
+            return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no row-span cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);
     }
     if (ctx->cv_mode != 1 && ctx->cv_mode != 3 && kh == kw) {
         bool handled = false;
