@@ -298,6 +298,8 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
 #pragma unroll
                 for (int j = 0; j < M; ++j) acc += hv[j];
                 o.scores[o.padded ? fo : pg] = (float)acc;
+            } else if (o.padded) {
+                o.scores[fo] = 0.f;   // pair mode: the caller's buffer is not pre-zeroed (pixels without a hit read 0)
             }
         }
     }
@@ -377,6 +379,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void flow_tail_kernel(const fl
                     double acc = 0;
                     for (int k = 0; k < M; ++k) acc += hv[k];
                     o.scores[o.padded ? fo : pg] = (float)acc;
+                } else if (o.padded) {
+                    o.scores[fo] = 0.f;
                 }
             }
         }
@@ -407,6 +411,40 @@ __global__ void flow_to_depth_cart_kernel(const float *__restrict__ flow, int H,
         }
         depth[p] = r;
         conf[p] = c;
+    }
+}
+
+// Pair epilogue: zeroes flow / scores outside the centre-pasted interior (instead of two full-frame memsets before the
+// build) and turns the flow into depth in the same pass (same arithmetic as flow_to_depth_cart_kernel).
+__global__ void pair_border_depth_kernel(float *__restrict__ flow, float *__restrict__ scores, int H, int W, int pad_t, int pad_l,
+                                         int Ho, int Wo, float mw, float mh, float infty, float *__restrict__ depth,
+                                         float *__restrict__ conf) {
+    const long long P = (long long)H * W;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(p / W), j = (int)(p - (long long)i * W);
+        float dy = 0.f, dx = 0.f;
+        if (i >= pad_t && i < pad_t + Ho && j >= pad_l && j < pad_l + Wo) {
+            dy = flow[p]; dx = flow[P + p];
+        } else {
+            flow[p] = 0.f; flow[P + p] = 0.f;
+            if (scores) scores[p] = 0.f;
+        }
+        if (depth) {
+            const float py = (float)i - mh, px = (float)j - mw;
+            const float pn = (float)sqrt((double)(px * px + py * py));
+            const float dn = (float)sqrt((double)(dx * dx + dy * dy));
+            float r = 0.f, c = 0.f;
+            if (dn >= 0.2f) {
+                const float q = pn / dn;
+                r = q < infty ? q : infty;
+                if (px * dx + dy * dy > 0.125f) c = 1.0f;   // test_opticalflow.lua:181 (sic)
+            } else {
+                c = 1.0f;
+                r = infty;
+            }
+            depth[p] = r;
+            conf[p] = c;
+        }
     }
 }
 
@@ -453,6 +491,15 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
     else
         hipLaunchKernelGGL(flow_finalize_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
                            hWin, wWin, middle, threshold, o);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
+                          float cy, float *depth, float *conf) {
+    const float infty = (float)((double)W / 2);   // test_opticalflow.lua:148 geometry.wImg/2
+    hipLaunchKernelGGL(pair_border_depth_kernel, dim3(grid_for((long long)H * W, 256)), dim3(256), 0, ctx->stream, flow, scores, H, W,
+                       pad_t, pad_l, Ho, Wo, cx, cy, infty, depth, conf);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

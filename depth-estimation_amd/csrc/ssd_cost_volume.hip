@@ -1121,16 +1121,11 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     // centre-paste offsets: opticalflow_model.lua:228-230 floor((hImg-h)/2)
     //   == radial/radial_opticalflow_groundtruth.lua:27-32 floor((hWin-1)/2)+floor((k-1)/2)
     const int pad_t = (H - Ho) / 2, pad_l = (W - Wo) / 2;
-    DFE_HIP(ctx, hipMemsetAsync(flow, 0, 2 * HW * sizeof(float), ctx->stream));
-    if (scores) DFE_HIP(ctx, hipMemsetAsync(scores, 0, HW * sizeof(float), ctx->stream));
+    // the pipeline writes every interior pixel of flow / scores; one pass afterwards zeroes the border and makes depth
     int rc = flow_pipeline(ctx, I0, I1, C, H, W, k, k, hWin, wWin, extract_threshold, nullptr, nullptr, flow, flow + HW, scores, nullptr,
                            W, pad_t, pad_l, 1);
     if (rc) return rc;
-    if (depth) {
-        rc = dfe_flow_to_depth_cartesian(ctx, flow, H, W, foe_x, foe_y, 0, depth, depth_conf);
-        if (rc) return rc;
-    }
-    return DFE_OK;
+    return dfe_pair_border_depth(ctx, flow, scores, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
 }
 
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh,

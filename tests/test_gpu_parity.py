@@ -412,6 +412,45 @@ def test_golden_fixtures_on_gpu(dfe, cuda):
     assert np.array_equal(y.cpu().numpy(), g["codec_8_8_124_y"]) and np.array_equal(x.cpu().numpy(), g["codec_8_8_124_x"])
 
 
+@pytest.mark.parametrize(
+    "H,W,win,C,thr",
+    [
+        (96, 128, 33, 3, 0.21),    # row-image kernel, tiles divide the frame
+        (75, 80, 33, 3, 0.21),     # last tile row / column shifted inwards; 37 output rows -> 18-row tiles
+        (131, 90, 33, 3, 0.11),    # M = 8
+        (64, 50, 33, 3, 0.21),     # Wo = 12, Ho = 26
+        (90, 110, 17, 3, 0.21),    # 17x17 window: tiled kernel
+        (60, 70, 9, 1, 0.21),      # luminance frames
+    ],
+)
+def test_flow_depth_pair_matches_oracle(dfe, cuda, H, W, win, C, thr):
+    """dfe_flow_depth_pair_f32 (the bench step): flow / scores centre-pasted into buffers that are NOT pre-zeroed, borders
+    zero, depth and confidence from the quirk-preserving cartesian formula -- against the oracle composition."""
+    k = 7
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=C, seed=H + win, max_flow=min(win // 2 - 1, 12), noise_sigma=1.0)
+    ref = rp.dense_flow_oracle(f0, f1, win, win, k, k, thr=thr)
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    flow = torch.full((2, H, W), 7.0, device=cuda)
+    scores = torch.full((H, W), -3.0, device=cuda)
+    depth = torch.full((H, W), -1.0, device=cuda)
+    conf = torch.full((H, W), -1.0, device=cuda)
+    ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, thr,
+                                               flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), conf.data_ptr()))
+    name = ctx.last_kernel()
+    assert name == ("ssd_cv_rowimg_kernel+fused_tail" if (win == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"), name
+    eflow = ref["flowp"][:2]
+    assert np.array_equal(flow.cpu().numpy(), eflow)
+    assert np.array_equal(scores.cpu().numpy(), ref["flowp"][3])
+    ed, ec = orc.flow_to_depth_cartesian(eflow, cx, cy)
+    assert np.allclose(depth.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(conf.cpu().numpy(), ec)
+    # flow only: depth buffers may be NULL
+    flow2 = torch.full((2, H, W), 7.0, device=cuda)
+    ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, thr,
+                                               flow2.data_ptr(), None, None, None))
+    assert torch.equal(flow2, flow)
+
+
 # ------------------------------------------------------------------ full size (BASELINE configs[1]): properties
 def test_full_vga_cost_volume_properties(dfe, cuda):
     """640x480, C=3, 7x7 patch, 33x33 window: (a) tiled == row-image == reference-order kernel bitwise on integer
