@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload vga|720p|1080p]
 
 One *step* = one pass of the hot path over one frame pair per GPU, frames already resident in HBM:
-dfe_flow_depth_pair_f32 = SSD cost-volume build (materialised once, reference layout) -> fused
-arg-min / centre tie-break / extractOutput / decode tail -> flow->depth.  N > 1 is launched by
+dfe_flow_depth_pair_f32 = SSD cost-volume build (materialised once, reference layout) with the per-chunk
+arg-min fused into its epilogue -> finalize (centre tie-break / extractOutput / decode) -> border + flow->depth.  N > 1 is launched by
 torch.distributed.run, one rank per GPU; every rank processes its own pair (pairs are independent:
 weak scaling, no data-path collective; RCCL is used for the barrier and the max-over-ranks only).
 

@@ -771,6 +771,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         lpm = lds + dy * p.pitch + dx + xm;
     }
 
+    // waves with an extra task get issue priority: they run ahead while their three SIMD-mates fill the gaps, instead of
+    // finishing their surplus alone (one wave per SIMD hides no latency) while 15 waves sit at the barrier.
+    // (Tried and dropped: letting the odd waves run a row's flow epilogue after the barrier, from the row image, to
+    //  de-phase LDS reads and reductions across the lock-stepped waves -- 13 % slower.)
+    if (has_q) __builtin_amdgcn_s_setprio(3);
+    else if (has_m) __builtin_amdgcn_s_setprio(2);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
     float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + ROWS * 32 * sizeof(px_t)) + lane;

@@ -54,12 +54,14 @@ int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr);
 int dfe_free(dfe_ctx *ctx, void *dptr);
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
-/* cost-volume kernel selection: 0 = auto (default), 1 = force the reference-order kernel
- * (bit-identical float summation order to the CPU path), 2 = force the tiled fast kernel
- * (DFE_E_UNSUPPORTED from the op when the shape has no fast kernel) */
+/* cost-volume kernel selection (tuning / tests; also the DFE_CV_MODE environment variable at context creation):
+ * 0 = auto (default: the row-image kernel where it applies -- C=3, 7x7 patch, 769..1096 window cells, e.g. 33x33 --
+ * else the tiled kernel, else the reference-order kernel), 1 = force the reference-order kernel (bit-identical float
+ * summation order to the CPU path), 2 = force the tiled kernel, 3 = force the row-image kernel
+ * (2/3: DFE_E_UNSUPPORTED from the op when the shape has no such kernel) */
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
-/* tile height of the tiled kernel: 0 = chosen per shape (default); 2..5 = force TYQ (a tile sweeps
- * TYQ*k image rows), for tuning and for testing every instantiation */
+/* tile height of the tiled / row-image kernels: 0 = chosen per shape (default); 2..7 = force NQ (a tile sweeps
+ * NQ groups of 6 image rows at k = 7), for tuning and for testing every instantiation */
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* name of the kernel the last cost-volume call launched (static string) */
 const char *dfe_last_kernel(const dfe_ctx *ctx);

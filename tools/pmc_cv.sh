@@ -1,14 +1,14 @@
 #!/bin/bash
 # PMC passes over the cost-volume kernel (counters in their own runs, kernel-trace only).
-# usage: tools/pmc_cv.sh <tag> [workload]
+# usage: tools/pmc_cv.sh <tag> [workload] [pair|0..3]   (see tools/prof_cv.py)
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-tag=${1:-pmc}; wl=${2:-vga}
+tag=${1:-pmc}; wl=${2:-vga}; what=${3:-pair}
 out=gpurun_out/$tag; mkdir -p $out
 pass() { # pass <name> <counters...>
   local name=$1; shift
-  timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 tools/prof_cv.py $wl 4 > $out/$name.log 2>&1
+  timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 tools/prof_cv.py $wl 4 $what > $out/$name.log 2>&1
   local rc=$?
   echo "pass $name rc=$rc"
   if [ $rc -ge 124 ]; then exit $rc; fi

@@ -4,10 +4,10 @@ root = sys.argv[1]
 rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r.get("Kernel_Name", "")[:60]
+        k = r.get("Kernel_Name", "")[:70]
         rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in rows.items():
-    if "tiled" not in k and "ref_kernel" not in k and "tail" not in k and "rowimg" not in k: continue
+    if not any(t in k for t in ("tiled", "ref_kernel", "tail", "rowimg", "finalize", "border")): continue
     print("kernel:", k)
     for c in sorted(cs):
         v = cs[c]

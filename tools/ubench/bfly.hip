@@ -52,6 +52,29 @@ template <int V> __global__ __launch_bounds__(1024) void k(int *out, int seed) {
 #undef F
                 c += wl;
             }
+            if (V == 7) {             // index part, phased: 8 readlanes, 8 compares, 8 ff1, 8 writelanes
+                int wk8[8]; unsigned long long m8[8]; int f8[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x) wk8[x] = __builtin_amdgcn_readlane(c, x);
+#pragma unroll
+                for (int x = 0; x < 8; ++x) m8[x] = __builtin_amdgcn_ballot_w64(key[x] == wk8[x]) | 1ull << 63;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) f8[x] = __builtin_ctzll(m8[x]);
+                int wl = 0;
+#define W(x) asm("v_writelane_b32 %0, %1, " #x : "+v"(wl) : "s"(f8[x]));
+                W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7)
+#undef W
+                c += wl;
+            }
+            if (V == 8) {             // index part, packed: ff1 results packed on the scalar unit, one extract per lane
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(key[x] == __builtin_amdgcn_readlane(c, x)) | 1ull << 63;
+                    pk |= (unsigned long long)__builtin_ctzll(m) << (8 * x);
+                }
+                c += (int)((pk >> (8 * (lane & 7))) & 0xff);
+            }
             acc += c;
 #pragma unroll
             for (int x = 0; x < 8; ++x) key[x] += acc;   // 8 plain ops: keeps rounds dependent
@@ -74,10 +97,10 @@ int main() {
     int *d; (void)hipMalloc(&d, 4096);
     const float cal = run<0>(d) / 33.f;   // ms per plain op (x ITER x waves)
     const char *names[] = {"", "steps1-2 quad_perm (6 dpp-min + 12 cndmask)", "steps3-4 row_ror (2 dpp-min + 2 cndmask)", "steps5-6 permlane swaps",
-                           "index: 8 x readlane/cmp/ff1/writelane", "whole butterfly (swaps)", "whole butterfly (swizzle+bpermute)"};
-    float t[7];
-    t[1] = run<1>(d); t[2] = run<2>(d); t[3] = run<3>(d); t[4] = run<4>(d); t[5] = run<5>(d); t[6] = run<6>(d);
+                           "index: 8 x readlane/cmp/ff1/writelane", "whole butterfly (swaps)", "whole butterfly (swizzle+bpermute)", "index phased", "index packed on SALU"};
+    float t[9];
+    t[1] = run<1>(d); t[2] = run<2>(d); t[3] = run<3>(d); t[4] = run<4>(d); t[5] = run<5>(d); t[6] = run<6>(d); t[7] = run<7>(d); t[8] = run<8>(d);
     printf("plain op = %.4f ms\n", cal);
-    for (int v = 1; v <= 6; ++v) printf("V%d %-48s %.1f plain-op equivalents per round (incl. ~10 ops of glue)\n", v, names[v], t[v] / cal);
+    for (int v = 1; v <= 8; ++v) printf("V%d %-48s %.1f plain-op equivalents per round (incl. ~10 ops of glue)\n", v, names[v], t[v] / cal);
     return 0;
 }
