@@ -64,25 +64,37 @@ def cpu_baseline(f0, f1, k, hWin, wWin, cx, cy, budget_s=12.0):
         orc.flow_to_depth_cartesian(flow, cx, cy)
         return time.perf_counter() - t
 
+    ncores = orc.max_threads()
     run(1)  # start the OpenMP team
     t8 = run(8)
     rows = int(max(8, min(Ho, round(8 * budget_s / max(t8, 1e-6)))))
     t = run(rows)
     mpix = (H * W * rows / Ho) / t / 1e6
-    return {
+    out = {
         "value": round(mpix, 4),
         "unit": "Mpixels/s",
-        "cores": orc.max_threads(),
+        "cores": ncores,
         "kind": "port",
         "sample": "%d of %d output rows of one %dx%d pair (cost volume + arg-min/extract/decode/depth), %.1f s" % (rows, Ho, W, H, t),
     }
+    # the reference's own default is 2 OpenMP threads (depth_estimation_opticalflow.lua:16,40): same port, 2 threads
+    orc.set_num_threads(2)
+    try:
+        t2 = run(2)
+        rows2 = int(max(2, min(Ho, round(2 * 5.0 / max(t2, 1e-6)))))
+        t2 = run(rows2)
+        out["value_2_threads"] = round((H * W * rows2 / Ho) / t2 / 1e6, 5)
+        out["sample_2_threads"] = "%d rows, %.1f s" % (rows2, t2)
+    finally:
+        orc.set_num_threads(ncores)
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)   # clocks ramp up over the first few ms of work
     ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -188,6 +200,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": balg,
+                # sliding-window flops of the build, (3C+4) per cell: shows the kernel is not compute-priced
+                "gflops_sliding_window": round((3 * Cc + 4) * (H - k - hWin + 2) * (W - k - wWin + 2) * hWin * wWin / kern_s / 1e9, 1)
+                if kern_s > 0 else None,
                 "kernel_ms": round(kern_s * 1e3, 5),
                 "launches_timed": cv_n.value,
             },

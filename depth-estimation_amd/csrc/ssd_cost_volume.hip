@@ -152,6 +152,7 @@ struct CvTiledArgs {
     int lrows;         // LDS rows = ROWS + hWin - 1
     int lcols;         // staged columns = TX + K - 1 + wWin - 1
     int chunk0;        // tiled kernel: first 64-displacement chunk it covers (0 = all)
+    int seg_rows;      // row-image kernel, column sweep: output rows per block
     int tile0_off;     // row-image kernel: byte offset of the frame-0 tile inside dynamic LDS
     int stage_off;     // row-image kernel: byte offset of the run images inside dynamic LDS
     int stage_len;     // row-image kernel: floats per image
@@ -219,7 +220,7 @@ template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], i
 // with the column minimum (a v_cmp IS a ballot), take the lowest set bit on the scalar unit and drop it into lane x.
 template <int TX>
 __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool valid, int lane, int chunk, long long pg0,
-                                              const CvFuseArgs &fa) {
+                                              const CvFuseArgs &fa, float2 *handoff = nullptr) {
     // (plain stores first: after them the values are only needed as keys -- registers are scarce in the row-image kernel)
     if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
 #pragma unroll
@@ -247,8 +248,11 @@ __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool vali
         DFE_FIRST(0) DFE_FIRST(1) DFE_FIRST(2) DFE_FIRST(3) DFE_FIRST(4) DFE_FIRST(5) DFE_FIRST(6) DFE_FIRST(7)
 #undef DFE_FIRST
     }
-    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345))
-        fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
+    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345)) {
+        const float2 e = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
+        if (handoff) handoff[lane] = e;   // (wave-uniform) a wave that must not issue stores leaves its entries in LDS
+        else fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = e;
+    }
 }
 
 // the same for ONE column held by all 64 lanes (the row-image kernel's quarter tasks): a plain 6-step reduction
@@ -488,7 +492,7 @@ static int launch_cv_tiled_one(dfe_ctx *ctx, const CvTilePlan &pl, const float *
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
-    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
+    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.seg_rows = 0; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
     a.chunk0 = ctx->cv_chunk0;
     auto kern = ssd_cv_tiled_kernel<C, K, TX, NT, NW, NQ, FUSE>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
@@ -660,14 +664,16 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
     }
 }
 
-template <int C, int K, int TX, int NQ, bool SM, bool FUSE>
+template <int C, int K, int TX, int NQ, bool SM, bool FUSE, bool SWEEP>
 __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
                                                              float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
     using px_t = typename Px<C>::type;
     constexpr int NW = 16;
     constexpr int U = VUnroll<K>::value;
-    constexpr int ROWS = U * NQ;
+    constexpr int ROWS = U * NQ;                 // static tiles: rows swept per tile
     constexpr int TY = ROWS - (K - 1);
+    constexpr int R0 = 8;                        // column sweep: rows of the frame-0 ring
+    constexpr int LW = NW - 1;                   // column sweep: the wave that streams the tiles and never stores
     constexpr int NE = TX + K - 1;
     constexpr int TQ = TX / 4;                   // columns of a quarter task
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
@@ -689,13 +695,18 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         by = t / (int)gridDim.x;
         bx = t - by * (int)gridDim.x;
     }
-    const int x0n = bx * TX, y0n = by * TY;
-    const int x0 = min(x0n, p.Wo - TX), y0 = min(y0n, p.Ho - TY);
+    // static tiles: TY output rows per block, the last tile row shifted inwards.  Column sweep: the block walks down
+    // p.seg_rows output rows of its 8-pixel column, the frame-1 tile is a ring of p.lrows (= 64) rows that wave LW keeps
+    // filled a row step ahead, so the K-1 warm-up rows are paid once per segment instead of once per TY rows and no
+    // tile staging stalls the CU between tiles.
+    const int x0n = bx * TX, y0n = SWEEP ? by * p.seg_rows : by * TY;
+    const int x0 = min(x0n, p.Wo - TX), y0 = SWEEP ? y0n : min(y0n, p.Ho - TY);
+    const int nsweep = SWEEP ? min(p.seg_rows, p.Ho - y0) + (K - 1) : ROWS;   // rows this block sweeps
     const long long HW = p.plane;
     const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
     for (int r = wave; r < p.lrows; r += NW) {
-        const float *src = I1 + (long long)(y0 + r) * p.W + x0;
+        const float *src = I1 + (long long)min(y0 + r, p.H - 1) * p.W + x0;
         for (int s = lane; s < p.lcols; s += 64) {
             if constexpr (C == 1) {
                 lds[r * p.pitch + s] = src[s];
@@ -706,9 +717,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
     {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to 32 columns (quarter tasks read at +2w)
         px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
-        for (int r = wave; r < ROWS; r += NW) {
+        for (int r = wave; r < (SWEEP ? R0 : ROWS); r += NW) {
             if (lane < 32) {
-                const float *src = I0 + (long long)(y0 + oy + r) * p.W + (x0 + ox) + min(lane, NE - 1);
+                const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(lane, NE - 1);
                 if constexpr (C == 1) {
                     t0w[r * 32 + lane] = src[0];
                 } else {
@@ -718,18 +729,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         }
     }
     const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
-    if constexpr (SM && !(DFE_ABLATE & 32768)) {
-        // warm the scalar cache with every frame-0 line this block will read, so that the in-loop scalar loads hit
-        // there and never queue behind the store stream in L2 (a 64-B line per 16 floats; rows dealt to the waves)
-        for (int r = wave; r < ROWS; r += NW) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                cfptr ap = (cfptr)(I0 + a_base + (long long)r * p.W + c * HW);
-                const float w0 = ap[0], w1 = ap[NE - 1];
-                asm volatile("" ::"s"(w0), "s"(w1));
-            }
-        }
-    }
     __syncthreads();
 
     const int D = p.hWin * p.wWin;
@@ -744,31 +743,39 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // main task: chunk `wave`
     const int d = wave * 64 + lane;
     const bool valid = d < D;
-    const px_t *lp;
+    // lane address of a task: static tiles lds + (dy + r)*pitch + dx; column sweep lds + ((dy + r) & (lrows-1))*pitch + dx,
+    // kept as the pair (dy, dx + column offset) packed into one register
+    int lp;
     {
         const int dc = valid ? d : D - 1;         // idle lanes shadow the last cell, their deposits are masked
         const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lp = lds + dy * p.pitch + dx;
+        lp = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
     }
+    auto row_ptr = [&](int packed, int r) -> const px_t * {
+        if constexpr (SWEEP)   // (a 24-bit multiply here measured 15 % SLOWER at 720p than the plain one)
+            return lds + (((packed >> 16) + r) & (p.lrows - 1)) * p.pitch + (packed & 0xffff);
+        else
+            return lds + packed + r * p.pitch;
+    };
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
     const bool has_q = wave < 4 && D > 1024 && !(DFE_ABLATE & 8192);      // wave-uniform
     const int dq = 1024 + lane;
     const bool validq = dq < D;
-    const px_t *lpq;
+    int lpq;
     {
         const int dc = validq ? dq : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lpq = lds + dy * p.pitch + dx + TQ * wave;
+        const int dy = dc / p.wWin, dx = dc - dy * p.wWin + TQ * wave;
+        lpq = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane
     const bool has_m = wave == 4 && D > 1088 && !(DFE_ABLATE & 8192);     // wave-uniform
     const int dm = 1088 + (lane >> 3), xm = lane & 7;
     const bool validm = dm < D && xm < TX;
-    const px_t *lpm;
+    int lpm;
     {
         const int dc = validm ? dm : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lpm = lds + dy * p.pitch + dx + xm;
+        const int dy = dc / p.wWin, dx = dc - dy * p.wWin + xm;
+        lpm = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
     }
 
     // waves with an extra task get issue priority: they run ahead while their three SIMD-mates fill the gaps, instead of
@@ -779,7 +786,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     else if (has_m) __builtin_amdgcn_s_setprio(2);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
-    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + ROWS * 32 * sizeof(px_t)) + lane;
+    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + (SWEEP ? R0 : ROWS) * 32 * sizeof(px_t)) + lane;
+    // column sweep: wave LW's per-row part entries travel through LDS to wave LW-1, which stores them ([2][TX] float2 behind rm)
+    float2 *handoff = reinterpret_cast<float2 *>(dfe_smem + p.tile0_off + (SWEEP ? R0 : ROWS) * 32 * sizeof(px_t) + U * 64 * sizeof(float));
+    float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
+#pragma unroll
+    for (int c = 0; c < C; ++c) hold[c] = 0.f;
 #pragma unroll
     for (int i = 0; i < U; ++i) {
 #pragma unroll
@@ -789,22 +801,25 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         if (wave == 4) rm[i * 64] = 0.f;
     }
 
-    for (int q = 0; q < NQ; ++q) {
+    const int nq = SWEEP ? (nsweep + U - 1) / U : NQ;
+    for (int q = 0; q < nq; ++q) {
         static_for<0, U>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const int r = q * U + m;
+            if (SWEEP && r >= nsweep) return;                                // block-uniform
             const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
             const int y = y0 + r - (K - 1);
             const bool store_row = emit && y >= y0n;                         // block-uniform
             const long long G0 = ((long long)y * p.Wo + x0) * D;             // global float index of the run
             const int a0 = (int)(G0 & 31);
             float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
-            const int rn = min(r + 1, ROWS - 1);     // next row of the frame-0 tile (the row after the last is never used)
+            const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
+            const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * 32;
             {
                 px_t a;
-                if constexpr (!SM) a = t0[r * 32 + l16];
+                if constexpr (!SM) a = t0[t0r + l16];
                 float v[TX];
-                rowimg_task_row<C, K, TX, m, SM>(lp + r * p.pitch, a, av, ring, v);
+                rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
                 if constexpr (SM) {   // next row's scalars
 #pragma unroll
                     for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
@@ -815,16 +830,18 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
                 }
                 if constexpr (FUSE) {
-                    if (store_row) fuse_epilogue<TX>(v, valid, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa);
+                    if (store_row)
+                        fuse_epilogue<TX>(v, valid, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa,
+                                          (SWEEP && wave == LW) ? handoff + (r & 1) * TX : nullptr);
                 }
             }
             if (has_q) {
                 // the quarter's frame-0 window always comes through LDS + DPP: its column offset is a run-time value and a
                 // second set of 24 scalars next to the main task's 42 does not fit the SGPR file
-                const px_t a = t0[r * 32 + TQ * wave + l16];
+                const px_t a = t0[t0r + TQ * wave + l16];
                 const float avq[C][TQ + K - 1] = {};
                 float v[TQ];
-                rowimg_task_row<C, K, TQ, m, false>(lpq + r * p.pitch, a, avq, ringq, v);
+                rowimg_task_row<C, K, TQ, m, false>(row_ptr(lpq, r), a, avq, ringq, v);
                 if (store_row && validq) {
 #pragma unroll
                     for (int x = 0; x < TQ; ++x) st[(TQ * wave + x) * D + dq] = v[x];
@@ -839,8 +856,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             }
             if (has_m) {
                 // per-lane frame-0 pixels: no broadcast here, every lane has its own column
-                const px_t *lr = lpm + r * p.pitch;
-                const px_t *ar = t0 + r * 32 + xm;
+                const px_t *lr = row_ptr(lpm, r);
+                const px_t *ar = t0 + t0r + xm;
                 float e[K];
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -886,20 +903,47 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     }
                 }
             }
-            if (store_row) {
+            if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
                 // global stores to be acknowledged before every barrier and serialise stores with compute.
                 // One barrier per row is enough with two images: a wave re-deposits into image (r&1) only
                 // after the barrier of row r+1, which every wave reaches after its copy-out of row r.
+                // (The column sweep needs it in the warm-up rows too: it also frees the tile row the sweep has just left.)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f) {
+                if constexpr (SWEEP) {
+                    if (wave == LW && !(DFE_ABLATE & 131072)) {
+                        // Stream the rings: the pixels requested one row step ago go into the slots of the rows the sweep
+                        // left at r-1 (no wave reads them again; their first use is >= 2 barriers away), then the rows
+                        // that will take the slots of row r are requested.  This wave issues no stores at all, so waiting
+                        // for its loads never waits for the store stream (loads and stores share vmcnt on gfx9).
+                        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
+                        const bool t1lane = lane < p.lcols, t0lane = !t1lane && lane - p.lcols < NE;
+                        if (r >= 1 && !(DFE_ABLATE & 262144)) {
+                            px_t px;
+                            if constexpr (C == 1) px = hold[0]; else px = make_float4(hold[0], hold[1], hold[2], 0.f);
+                            if (t1lane) lds[((r - 1) & (p.lrows - 1)) * p.pitch + lane] = px;
+                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * 32 + lane - p.lcols] = px;
+                        }
+                        const float *src = t1lane ? I1 + (long long)min(y0 + r + p.lrows, p.H - 1) * p.W + x0 + lane
+                                                  : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lane - p.lcols);
+                        if (t1lane || t0lane) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) hold[c] = src[c * HW];
+                        }
+                    }
+                    if constexpr (FUSE) {
+                        if (wave == LW - 1 && store_row && lane < TX)
+                            fa.part[(long long)LW * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + lane] = handoff[(r & 1) * TX + lane];
+                    }
+                }
+                if (store_row && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int head = (32 - a0) & 31;                         // floats before the first whole line
                     const int nbody4 = ((RUN - head) >> 5) << 3;             // float4 pieces in whole 128-B lines
                     const f4_t *sb = reinterpret_cast<const f4_t *>(st + head);
                     const float *gb = out + G0 + head;
                     int tj = tid;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
-                    for (int j = tj; j < nbody4; j += NW * 64) {
+                    for (int j = tj; j < nbody4; j += (SWEEP ? LW : NW) * 64) {
                         const f4_t val = sb[j];
                         asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)j * 16u), "v"(val), "s"(gb) : "memory");
                     }
@@ -940,7 +984,7 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
-    auto kern = ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE>;
+    auto kern = ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
     {
@@ -953,14 +997,87 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     return DFE_OK;
 }
 
-// tile height: 24 rows (NQ = 5) unless forced or the frame is shorter
+// Column sweep: one block per (8-pixel column, row segment).  The segment count is chosen so that rounds x rows swept
+// per block is smallest (VGA: 76 columns x 3 segments = 228 blocks on 256 CUs, 154 row steps instead of 6 x 30).
+template <int C, int K, int TX, bool FUSE>
+static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
+                                  float *out, const CvFuseArgs *fa, bool *handled) {
+    using px_t = typename Px<C>::type;
+    constexpr int U = VUnroll<K>::value;
+    constexpr int R = 64, R0 = 8;                 // ring rows (frame-1: a power of two >= hWin + 2; frame-0)
+    const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+    const int D = hWin * wWin;
+    *handled = false;
+    if (D <= 768 || D > 1096 || Ho < 1 || Wo < TX || hWin + 2 > R) return DFE_OK;
+    CvTiledArgs a;
+    a.plane = plane;
+    a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
+    a.lrows = R;
+    a.lcols = TX + K - 1 + wWin - 1;
+    if (a.lcols + TX + K - 1 > 64) return DFE_OK;   // one wave streams a tile row and a frame-0 row per step
+    const int M = Px<C>::bank_mod;
+    a.pitch = a.lcols;
+    while ((a.pitch - wWin) % M != 0) ++a.pitch;
+    const int ncols = dfe_cdiv(Wo, TX);
+    int best_seg = 1;
+    long long best_cost = -1;
+    for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg) {
+        const long long rounds = dfe_cdiv(ncols * nseg, ctx->ncu);
+        const long long cost = rounds * (dfe_cdiv(Ho, nseg) + K - 1);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = nseg; }
+    }
+    a.seg_rows = dfe_cdiv(Ho, best_seg);
+    const int nseg = dfe_cdiv(Ho, a.seg_rows);
+    size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
+    a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
+    a.stage_off = a.tile0_off + (int)(((size_t)R0 * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 2 * TX * sizeof(float2) + 127) / 128 * 128);
+    a.stage_len = (TX * D + 32 + 31) / 32 * 32;
+    a.chunk0 = 0;
+    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
+    if (lds_bytes > 160 * 1024) return DFE_OK;
+    static_assert(!FUSE, "the fused column sweep does not fit the register file");
+    auto kern = ssd_cv_rowimg_kernel<C, K, TX, 0, DFE_RI_SMEM, FUSE, true>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    dim3 grid(ncols, nseg);
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = FUSE ? "ssd_cv_rowimg_kernel+fused_tail" : "ssd_cv_rowimg_kernel";
+    *handled = true;
+    return DFE_OK;
+}
+
+// row-image kernel, auto: static tiles or the column sweep, see below; dfe_set_cost_volume_tile 3..7 forces static
+// tiles of NQ*6 - 6 rows, 1 forces the column sweep
 template <int C, int K, int TX, bool FUSE>
 static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
                             float *out, const CvFuseArgs *fa, bool *handled) {
     constexpr int U = VUnroll<K>::value;
-    const int Ho = H - K + 1 - hWin + 1;
     int nq = ctx->cv_tyq;
-    if (nq == 0) nq = Ho >= U * 5 - (K - 1) ? 5 : Ho >= U * 4 - (K - 1) ? 4 : 3;
+    if (nq == 1) {   // forced column sweep (unfused build only: the fused instantiation does not fit 128 VGPRs)
+        if (FUSE) return DFE_OK;
+        return launch_cv_rowimg_sweep<C, K, TX, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+    }
+    if (nq == 0) {
+        // Static 24-row tiles or the column sweep?  Rows swept per CU: rounds x 30 against rounds x (segment + 6); a swept
+        // row of the sweep costs ~15 % more (measured: ring addressing, a barrier in every row, 15 copier waves), so it
+        // wins on frames with many rounds (720p +5 %, 1080p +3 %) and loses or ties at VGA (one under-full round).
+        const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+        nq = Ho >= U * 5 - (K - 1) ? 5 : Ho >= U * 4 - (K - 1) ? 4 : 3;
+        if (!FUSE && Ho >= 1 && Wo >= TX) {
+            const int TY = U * nq - (K - 1), ncols = dfe_cdiv(Wo, TX);
+            const double cost_static = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, TY), ctx->ncu) * (U * nq);
+            double cost_sweep = 1e30;
+            for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg)
+                cost_sweep = fmin(cost_sweep, (double)dfe_cdiv((long long)ncols * nseg, ctx->ncu) * (dfe_cdiv(Ho, nseg) + K - 1));
+            if (cost_sweep * 1.18 < cost_static) {
+                int rc = launch_cv_rowimg_sweep<C, K, TX, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+                if (rc != DFE_OK || *handled) return rc;
+            }
+        }
+    }
     switch (nq) {
         case 3: return launch_cv_rowimg_one<C, K, TX, 3, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
         case 4: return launch_cv_rowimg_one<C, K, TX, 4, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);

@@ -90,11 +90,12 @@ def test_cost_volume_every_tile_height_bit_exact(dfe, cuda, tyq):
     assert np.array_equal(out.cpu().numpy(), cpu)
 
 
-@pytest.mark.parametrize("nq", [0, 3, 4, 5, 6])
-@pytest.mark.parametrize("H,W", [(80, 100), (75, 47), (131, 90)])
+@pytest.mark.parametrize("nq", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("H,W", [(80, 100), (75, 47), (131, 90), (230, 64)])
 def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
-    # the row-span kernel (all 18 chunks of a tile row in one block, LDS row image, aligned copy-out), 33x33 window,
-    # on frames whose last tile row / column are shifted and whose row spans start at every alignment mod 128 B
+    # the row-image kernel (all 1089 cells of a tile row in one block, LDS row image, aligned copy-out), 33x33 window, as a
+    # column sweep (nq = 1; (230, 64): several segments of a column) and with static tiles of every height (0 = auto), on frames whose last tile row / column are shifted
+    # and whose runs start at every alignment mod 128 B
     f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + nq, max_flow=9)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
     ctx = dfe.get_ctx(0)
@@ -103,7 +104,7 @@ def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
     try:
         out = torch.full(cpu.shape, -1.0, device=cuda)
         t0, t1 = T(f0, cuda), T(f1, cuda)
-        if cpu.shape[0] < (6 * (nq or 5) - 6):
+        if nq != 1 and cpu.shape[0] < (6 * (nq or 3) - 6):   # static tiles need one full tile of rows; the column sweep (nq = 1) does not
             with pytest.raises(dfe.DfeError):
                 ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, 33, 33, out.data_ptr()))
             return
