@@ -156,6 +156,27 @@ def main():
     ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(cv_ms), C.byref(cv_n)))
     ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
 
+    # outside the timed region: the cost-volume build ALONE (dfe_ssd_cost_volume_f32, no flow epilogue), the kernel the
+    # north-star roofline target is stated for; reported as `roofline_build_only` next to the step's dominant kernel
+    build_ms = build_kernel = None
+    if rank == 0:
+        Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
+        try:
+            vol = torch.empty((Ho, Wo, hWin, wWin), device=dev)
+            for _ in range(5):
+                ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+            torch.cuda.synchronize()
+            ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
+            for _ in range(20):
+                ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+            b_ms, b_n = C.c_double(), C.c_int()
+            ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(b_ms), C.byref(b_n)))
+            ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+            build_ms, build_kernel = b_ms.value / max(b_n.value, 1), ctx.last_kernel()
+            del vol
+        except torch.OutOfMemoryError:
+            pass
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -207,6 +228,12 @@ def main():
                 "launches_timed": cv_n.value,
             },
         }
+        if build_ms:
+            out["roofline_build_only"] = {
+                "bound": "hbm", "kernel": build_kernel, "achieved": round(balg / (build_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(balg / (build_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(build_ms, 5),
+                "launches_timed": 20, "note": "dfe_ssd_cost_volume_f32 alone, measured after the timed region",
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f0, f1, k, hWin, wWin, cx, cy)
         print(json.dumps(out), flush=True)
