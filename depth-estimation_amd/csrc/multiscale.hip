@@ -129,6 +129,45 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_kernel(CascadeGeom g, flo
     }
 }
 
+// A4b: gradient of the cascade w.r.t. its inputs, fine -> coarse: g_0 = go_0, g_{s+1} = go_{s+1} + pad(blocksum_q(g_s)).
+// CascadingAddTable.lua:137-154.  One wave per pixel; g_s sits in LDS while the next scale gathers its q x q blocks
+// (row-major float accumulation, as in the CPU restatement).
+__global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGeom g) {
+    extern __shared__ float sh[];
+    const int N = g.maxh * g.maxw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float *cur = sh + (size_t)w * 2 * N, *prev = cur + N;
+    const long long P = (long long)g.H * g.W;
+    for (long long p = (long long)blockIdx.x * kWaves + w; p < P; p += (long long)gridDim.x * kWaves) {
+        for (int s = 0; s < g.nratios; ++s) {
+            const float *go = g.in[s] + p * N;
+            if (s == 0) {
+                for (int n = lane; n < N; n += 64) cur[n] = go[n];
+            } else {
+                const int r = g.ratios[s - 1], r2 = g.ratios[s], q = r2 / r;
+                const int dh = g.maxh * (r2 - r) / (2 * r2), dw = g.maxw * (r2 - r) / (2 * r2);
+                for (int n = lane; n < N; n += 64) {
+                    const int a = n / g.maxw - dh, b = n - (n / g.maxw) * g.maxw - dw;
+                    float v = go[n];
+                    if (a >= 0 && a < g.maxh / q && b >= 0 && b < g.maxw / q) {
+                        float acc = 0.f;
+                        for (int u = 0; u < q; ++u)
+                            for (int t = 0; t < q; ++t) acc += prev[(a * q + u) * g.maxw + b * q + t];
+                        v += acc;
+                    }
+                    cur[n] = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            float *o = g.out_scale[s] + p * N;
+            for (int n = lane; n < N; n += 64) o[n] = cur[n];
+            float *t = cur; cur = prev; prev = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int ring_width(int maxw, int r, int rprev) { return (int)floor((double)maxw * (r - rprev) / (2.0 * r) + 0.5); }
 
 int fill_cascade(dfe_ctx *ctx, CascadeGeom &g, const int *ratios, int nratios, int maxh, int maxw) {
@@ -250,6 +289,28 @@ int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratio
     size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascading_add_f32: window %dx%d too large", maxh, maxw);
     hipLaunchKernelGGL(cascade_kernel<false>, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, (float *)nullptr);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh,
+                                   int maxw, float *const *gradIn) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    CascadeGeom g;
+    int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
+    if (rc) return rc;
+    DFE_REQUIRE(ctx, gradOut && gradIn && P >= 0, DFE_E_ARG, "dfe_cascading_add_backward_f32: bad argument");
+    if (P == 0) return DFE_OK;
+    for (int s = 0; s < nratios; ++s) {
+        DFE_REQUIRE(ctx, gradOut[s] && gradIn[s], DFE_E_ARG, "dfe_cascading_add_backward_f32: tensor %d is NULL", s);
+        g.in[s] = gradOut[s];
+        g.out_scale[s] = gradIn[s];
+    }
+    DFE_REQUIRE(ctx, P <= 0x7fffffff, DFE_E_SHAPE, "dfe_cascading_add_backward_f32: P too large");
+    g.H = 1; g.W = (int)P;
+    size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
+    DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascading_add_backward_f32: window %dx%d too large", maxh, maxw);
+    hipLaunchKernelGGL(cascade_backward_kernel, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

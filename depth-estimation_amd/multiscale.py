@@ -42,6 +42,29 @@ class CascadingAddTable(Module):
         self.output = outs
         return outs
 
+    def updateGradInput(self, input, gradOutput):
+        """CascadingAddTable.lua:137-154.  HEAD's graph holds no trainable parameter (Mul2 / Power are commented
+        out), so accGradParameters has nothing to accumulate and `backward` is this."""
+        if len(gradOutput) != len(self.ratios):
+            raise ValueError("nn.CascadingAddTable: input and ratios must have the same size")
+        gos = [t.contiguous() for t in gradOutput]
+        P, maxh, maxw = gos[0].shape
+        for t in gos:
+            if t.dtype != torch.float32 or tuple(t.shape) != (P, maxh, maxw):
+                raise ValueError("nn.CascadingAddTable: gradOutputs must be FloatTensors of one size")
+        gis = [torch.empty_like(t) for t in gos]
+        ctx = get_ctx(gos[0])
+        r, n = ratios_array(self.ratios)
+        ctx.check(lib().dfe_cascading_add_backward_f32(ctx.handle, _ptr_array(gos), r, n, P, maxh, maxw, _ptr_array(gis)))
+        self.gradInput = gis
+        return gis
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):   # :156-164, nothing trainable at HEAD
+        return None
+
+    def backward(self, input, gradOutput, scale=1.0):
+        return self.updateGradInput(input, gradOutput)
+
 
 class MultiscaleModel(Module):
     """What getModelMultiscale(geometry, full_image=true, prefiltered=false):forward({I0, I1}) computes in

@@ -199,6 +199,13 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
 int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios,
                           int64_t P, int maxh, int maxw, float *const *out);
 
+/* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
+/* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
+ *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];
+ *   g_0 = gradOut_0, g_{i+1} = gradOut_{i+1} + zero-pad(q x q block sums of g_i), gradIn_i = g_i. */
+int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios,
+                                   int64_t P, int maxh, int maxw, float *const *gradIn);
+
 /* ---- A2(upsample)+A4+A5: cascade and ring extraction for a whole frame --------------------- */
 /* replaces: nearest upsampling of SpatialPyramid + CascadingAddTable + the "middle remover" +
  *   JoinTable(2) + SmartReshape(hImg,wImg,-2), opticalflow_model_multiscale.lua:227-229,285-333.

@@ -456,6 +456,33 @@ int orc_cascading_add(const float *const *in, int nratios, const int *ratios, in
     }
     return 0;
 }
+/* A4b: gradient of the cascade w.r.t. its inputs.  ref: CascadingAddTable.lua:137-154 (updateGradInput) with HEAD's
+ * transformer graph (:26-60: reshape | crop -> replicate -> reshape, CAddTable; Mul2/Power commented out, so there are
+ * no parameter gradients).  g_0 = go_0; g_{i+1} = go_{i+1} + pad(blocksum_q(g_i)); gradInput_i = g_i.
+ * Pinned the way the reference pins it (tests/test_cascad.lua:22: nn.Jacobian.testJacobian): adjoint of the forward. */
+int orc_cascading_add_backward(const float *const *gradOut, int nratios, const int *ratios, int64_t P, int maxh,
+                               int maxw, float *const *gradIn) {
+    if (cascade_check(nratios, ratios, maxh, maxw)) return -1;
+    int N = maxh * maxw;
+    for (int64_t p = 0; p < P; ++p) {
+        memcpy(gradIn[0] + p * N, gradOut[0] + p * N, sizeof(float) * N);
+        for (int i = 0; i + 1 < nratios; ++i) {
+            int r = ratios[i], r2 = ratios[i + 1], q = r2 / r;
+            int dh = maxh * (r2 - r) / (2 * r2), dw = maxw * (r2 - r) / (2 * r2);
+            const float *g = gradIn[i] + p * N;
+            float *gn = gradIn[i + 1] + p * N;
+            memcpy(gn, gradOut[i + 1] + p * N, sizeof(float) * N);
+            for (int a = 0; a < maxh / q; ++a)
+                for (int b = 0; b < maxw / q; ++b) {
+                    float acc = 0.f; /* row-major over the q x q block, float accumulation */
+                    for (int u = 0; u < q; ++u)
+                        for (int v = 0; v < q; ++v) acc += g[(a * q + u) * maxw + b * q + v];
+                    gn[(dh + a) * maxw + dw + b] += acc;
+                }
+        }
+    }
+    return 0;
+}
 int orc_cascade_ring(const float *const *prob, int nratios, const int *ratios, int H, int W,
                      int maxh, int maxw, float *out) {
     if (cascade_check(nratios, ratios, maxh, maxw) || nratios > ORC_MAX_RATIOS) return -1;

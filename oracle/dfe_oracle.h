@@ -113,6 +113,11 @@ int orc_cascade_ring(const float *const *prob, int nratios, const int *ratios, i
 int orc_cascading_add(const float *const *in, int nratios, const int *ratios, int64_t P,
                       int maxh, int maxw, float *const *out);
 
+/* A4b gradient of A4 w.r.t. its inputs: gradOut[s], gradIn[s] [P][maxh][maxw]. ref: CascadingAddTable.lua:137-154;
+ * pinned as the adjoint of orc_cascading_add (the reference's own test is a Jacobian check, tests/test_cascad.lua:22) */
+int orc_cascading_add_backward(const float *const *gradOut, int nratios, const int *ratios, int64_t P,
+                               int maxh, int maxw, float *const *gradIn);
+
 /* A11 centre-paste. ref: opticalflow_model.lua:227-250 */
 void orc_paste_center(const float *src, int h, int w, float *dst, int H, int W);
 

@@ -49,6 +49,7 @@ def lib():
             "orc_softmin": (None, [f32p, C.c_int64, C.c_int, f32p]),
             "orc_cascade_ring": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_cascading_add": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+            "orc_cascading_add_backward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
             "orc_paste_center": (None, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]),
             "orc_flow_to_depth_cartesian": (None, [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]),
             "orc_flow_to_depth_radial": (None, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]),
@@ -219,6 +220,17 @@ def cascading_add(ins, ratios, maxh, maxw):
     b = (C.c_void_p * len(ins))(*[p.ctypes.data for p in outs])
     rc = lib().orc_cascading_add(a, len(ins), r, P, maxh, maxw, b)
     return rc, outs
+
+
+def cascading_add_backward(grad_outs, ratios, maxh, maxw):
+    gos = [_f(p) for p in grad_outs]
+    P = gos[0].size // (maxh * maxw)
+    gis = [np.empty_like(p) for p in gos]
+    r = _r(ratios)
+    a = (C.c_void_p * len(gos))(*[p.ctypes.data for p in gos])
+    b = (C.c_void_p * len(gos))(*[p.ctypes.data for p in gis])
+    rc = lib().orc_cascading_add_backward(a, len(gos), r, P, maxh, maxw, b)
+    return rc, gis
 
 
 def flow_to_depth_cartesian(flow, cx, cy, fix_dot=False):

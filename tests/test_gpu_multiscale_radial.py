@@ -81,6 +81,31 @@ def test_cascading_add_table_module_bit_exact(dfe, cuda, ratios, mh, mw):
         assert np.array_equal(o.cpu().numpy(), e)
 
 
+@pytest.mark.parametrize("ratios,mh,mw", [([1, 2, 4], 8, 8), ([1, 2], 8, 16), ([1, 2, 4, 8], 16, 16), ([1], 8, 8), ([1, 4], 8, 8)])
+def test_cascading_add_table_backward_bit_exact(dfe, cuda, ratios, mh, mw):
+    """A4b (CascadingAddTable.lua:137-154): gradInput of the cascade == oracle, and the adjoint identity against the
+    GPU forward (the reference's own test is a Jacobian check, tests/test_cascad.lua:22)."""
+    rng = np.random.default_rng(len(ratios) + mw)
+    P = 41
+    xs = [rng.integers(-8, 9, (P, mh, mw)).astype(np.float32) for _ in ratios]   # integers: exact in any summation order
+    gs = [rng.integers(-8, 9, (P, mh, mw)).astype(np.float32) for _ in ratios]
+    rc, ref = orc.cascading_add_backward(gs, ratios, mh, mw)
+    assert rc == 0
+    m = dfe.nn.CascadingAddTable(ratios)
+    ys = m.forward([T(a, cuda) for a in xs])
+    gis = m.backward([T(a, cuda) for a in xs], [T(a, cuda) for a in gs])
+    assert m.gradInput is gis and len(gis) == len(ratios)
+    for o, e in zip(gis, ref):
+        assert np.array_equal(o.cpu().numpy(), e)
+    lhs = sum(float((y.double() * T(g, cuda).double()).sum()) for y, g in zip(ys, gs))
+    rhs = sum(float((T(x, cuda).double() * gi.double()).sum()) for x, gi in zip(xs, gis))
+    assert lhs == rhs
+    fl = [rng.standard_normal((P, mh, mw)).astype(np.float32) for _ in ratios]   # floats: same accumulation order as the oracle
+    rc, ref = orc.cascading_add_backward(fl, ratios, mh, mw)
+    for o, e in zip(m.updateGradInput(None, [T(a, cuda) for a in fl]), ref):
+        assert np.array_equal(o.cpu().numpy(), e)
+
+
 def test_cascading_add_table_errors(dfe, cuda):
     m = dfe.nn.CascadingAddTable([1, 2])
     with pytest.raises(ValueError, match="3D-tensors"):

@@ -282,3 +282,30 @@ def test_output_extractor_hand_checked():
     p[:] = 1 / 6
     x, y = orc.output_extractor(p, 2, 3)
     assert abs(x[0] - 2.0) < 1e-6 and abs(y[0] - 1.5) < 1e-6
+
+
+@pytest.mark.parametrize("ratios,mh,mw", [([1, 2, 4], 8, 8), ([1, 2], 8, 16), ([1, 2, 4, 8], 16, 16), ([1], 8, 8), ([1, 4], 8, 8)])
+def test_cascading_add_backward_is_the_adjoint_of_forward(ratios, mh, mw):
+    """A4b, pinned the way the reference pins it (tests/test_cascad.lua:22 nn.Jacobian.testJacobian): the cascade is
+    linear, so <J x, g> == <x, J^T g> for random x, g, and J^T g equals the finite-difference Jacobian column sums."""
+    rng = np.random.default_rng(len(ratios) * 100 + mh)
+    P = 3
+    xs = [rng.standard_normal((P, mh, mw)).astype(np.float32) for _ in ratios]
+    gs = [rng.standard_normal((P, mh, mw)).astype(np.float32) for _ in ratios]
+    rc, ys = orc.cascading_add(xs, ratios, mh, mw)
+    rc2, gis = orc.cascading_add_backward(gs, ratios, mh, mw)
+    assert rc == 0 and rc2 == 0
+    lhs = sum(float((y.astype(np.float64) * g).sum()) for y, g in zip(ys, gs))
+    rhs = sum(float((x.astype(np.float64) * gi).sum()) for x, gi in zip(xs, gis))
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    # explicit Jacobian on one pixel: d(sum_s <y_s, g_s>)/d x_s[n] by central differences (exact for a linear map)
+    for s_i in range(len(ratios)):
+        for n in (0, mw + 1, mh * mw - 1):
+            e = [np.zeros((1, mh, mw), np.float32) for _ in ratios]
+            e[s_i].reshape(-1)[n] = 1.0
+            _, ye = orc.cascading_add(e, ratios, mh, mw)
+            col = sum(float((y[0].astype(np.float64) * g[0]).sum()) for y, g in zip(ye, gs))
+            assert abs(col - float(gis[s_i][0].reshape(-1)[n])) <= 1e-4 * max(1.0, abs(col))
+    # incompatible geometry is refused like the forward
+    rc3, _ = orc.cascading_add_backward([np.zeros((1, 2, 2), np.float32)] * 2, [1, 2], 2, 2)
+    assert rc3 != 0
