@@ -247,9 +247,14 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < Pband; p += (long long)gridDim.x * blockDim.x) {
         const long long pg = o.p_off + p;
         float2 b = part[pg];
-        for (int c = 1; c < nchunks; ++c) {
-            const float2 t = part[(long long)c * Ptot + pg];
-            if (t.x < b.x) b = t;
+        for (int c0 = 1; c0 < nchunks; c0 += 6) {   // six loads in flight, compared in chunk order (first chunk wins ties)
+            float2 t[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                t[j] = c0 + j < nchunks ? part[(long long)(c0 + j) * Ptot + pg] : make_float2(__int_as_float(0x7f800000), 0.f);
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (t[j].x < b.x) b = t[j];
         }
         long long id = (long long)__float_as_int(b.y) + 1;
         if (middle > 0 && b.x == centre[pg]) id = middle;
