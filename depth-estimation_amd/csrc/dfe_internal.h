@@ -106,4 +106,4 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
 int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
                           float cy, float *depth, float *conf);
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
-                             int wWin, float *out, const CvFuseArgs &fa, bool *handled);
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts);

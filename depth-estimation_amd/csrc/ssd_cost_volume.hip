@@ -218,10 +218,9 @@ template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], i
 // pixel's first DFE_LEAD cells.  Costs are >= 0, so their bit patterns order like integers.  The butterfly leaves lane L
 // with the chunk minimum of column L&7 (idle lanes carry +inf).  The first cell attaining it: compare every lane's value
 // with the column minimum (a v_cmp IS a ballot), take the lowest set bit on the scalar unit and drop it into lane x.
+// the part of the fused epilogue that is plain stores: the centre cell's cost and the pixel's first DFE_LEAD cells
 template <int TX>
-__device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool valid, int lane, int chunk, long long pg0,
-                                              const CvFuseArgs &fa, float2 *handoff = nullptr) {
-    // (plain stores first: after them the values are only needed as keys -- registers are scarce in the row-image kernel)
+__device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa) {
     if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
 #pragma unroll
         for (int x = 0; x < TX; ++x) fa.centre[pg0 + x] = vrow[x];
@@ -233,6 +232,13 @@ __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool vali
         lp4[0] = f4_t{vrow[0], vrow[1], vrow[2], vrow[3]};
         lp4[1] = f4_t{vrow[4], vrow[5], vrow[6], vrow[7]};
     }
+}
+
+template <int TX>
+__device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool valid, int lane, int chunk, long long pg0,
+                                              const CvFuseArgs &fa) {
+    // (plain stores first: after them the values are only needed as keys)
+    fuse_plain_stores<TX>(vrow, lane, chunk, pg0, fa);
     __builtin_amdgcn_sched_barrier(0);
     int key[TX];
 #pragma unroll
@@ -248,14 +254,11 @@ __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool vali
         DFE_FIRST(0) DFE_FIRST(1) DFE_FIRST(2) DFE_FIRST(3) DFE_FIRST(4) DFE_FIRST(5) DFE_FIRST(6) DFE_FIRST(7)
 #undef DFE_FIRST
     }
-    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345)) {
-        const float2 e = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
-        if (handoff) handoff[lane] = e;   // (wave-uniform) a wave that must not issue stores leaves its entries in LDS
-        else fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = e;
-    }
+    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345))
+        fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
 }
 
-// the same for ONE column held by all 64 lanes (the row-image kernel's quarter tasks): a plain 6-step reduction
+// wave minimum of ONE value per lane: a plain 6-step reduction, all lanes get the result
 __device__ __forceinline__ int wave_min1(int c) {
     c = min(c, __builtin_amdgcn_update_dpp(0, c, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
     c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
@@ -265,12 +268,6 @@ __device__ __forceinline__ int wave_min1(int c) {
     c = min((int)r[0], (int)r[1]);
     const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
     return min((int)q[0], (int)q[1]);
-}
-__device__ __forceinline__ void fuse_epilogue_col(float v, bool valid, int lane, int chunk, long long pg, const CvFuseArgs &fa) {
-    const int key = valid ? __float_as_int(v) : 0x7f800000;
-    const int wk = wave_min1(key);
-    const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == wk));
-    if (lane == 0) fa.part[(long long)chunk * fa.Ptot + pg] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + f));
 }
 
 // Rows are swept in groups of U (the unroll that makes every ring index static):
@@ -787,8 +784,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
     float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + (SWEEP ? R0 : ROWS) * 32 * sizeof(px_t)) + lane;
-    // column sweep: wave LW's per-row part entries travel through LDS to wave LW-1, which stores them ([2][TX] float2 behind rm)
-    float2 *handoff = reinterpret_cast<float2 *>(dfe_smem + p.tile0_off + (SWEEP ? R0 : ROWS) * 32 * sizeof(px_t) + U * 64 * sizeof(float));
     float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
 #pragma unroll
     for (int c = 0; c < C; ++c) hold[c] = 0.f;
@@ -829,10 +824,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
                     for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
                 }
-                if constexpr (FUSE) {
-                    if (store_row)
-                        fuse_epilogue<TX>(v, valid, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa,
-                                          (SWEEP && wave == LW) ? handoff + (r & 1) * TX : nullptr);
+                if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
+                    if (store_row) fuse_plain_stores<TX>(v, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa);
                 }
             }
             if (has_q) {
@@ -845,13 +838,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 if (store_row && validq) {
 #pragma unroll
                     for (int x = 0; x < TQ; ++x) st[(TQ * wave + x) * D + dq] = v[x];
-                }
-                if constexpr (FUSE) {
-                    if (store_row) {
-#pragma unroll
-                        for (int x = 0; x < TQ; ++x)
-                            fuse_epilogue_col(v[x], validq, lane, 16, (long long)(fa.row_off + y) * p.Wo + x0 + TQ * wave + x, fa);
-                    }
                 }
             }
             if (has_m) {
@@ -885,23 +871,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
                 }
                 if (store_row && validm) st[xm * D + dm] = v;
-                if constexpr (FUSE) {
-                    if (store_row) {
-                        // chunk 17 = the cells of this task: minimum over the lanes that share a column (lane ^ 8, 16, 32),
-                        // first attaining cell from the ballot restricted to the column's lanes
-                        const int key = validm ? __float_as_int(v) : 0x7f800000;
-                        int c = min(key, __builtin_amdgcn_update_dpp(0, key, 0x128, 0xf, 0xf, false));   // row_ror:8
-                        const auto r2 = __builtin_amdgcn_permlane16_swap(c, c, false, false);
-                        c = min((int)r2[0], (int)r2[1]);
-                        const auto q2 = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-                        c = min((int)q2[0], (int)q2[1]);
-                        const unsigned long long hit = __builtin_amdgcn_ballot_w64(key == c) & (0x0101010101010101ull << xm);
-                        const int f = __builtin_ctzll(hit) >> 3;            // first cell of my column attaining the minimum
-                        if (lane < TX)
-                            fa.part[17ll * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xm] =
-                                make_float2(__int_as_float(c), __int_as_float(1088 + f));
-                    }
-                }
             }
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
@@ -931,9 +900,36 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                             for (int c = 0; c < C; ++c) hold[c] = src[c * HW];
                         }
                     }
-                    if constexpr (FUSE) {
-                        if (wave == LW - 1 && store_row && lane < TX)
-                            fa.part[(long long)LW * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + lane] = handoff[(r & 1) * TX + lane];
+                }
+                if constexpr (FUSE) {
+                    if (store_row && !(DFE_ABLATE & 512)) {
+                        // Flow epilogue from the row image: the run of pixel x is complete in LDS, so two waves per pixel
+                        // scan it -- every lane 9 consecutive cells (strict '<' keeps the lane's first minimum), one wave
+                        // minimum, the lowest lane attaining it owns the first index.  ~55 VALU per wave and row instead of
+                        // a butterfly + 8 ballots per TASK and row on values in registers (~95); in time the two are equal
+                        // (the scan sits between the barrier and the copy-out, its LDS latency exposed; after the
+                        // copy-out it measured 5 % slower, split around it it spills), but finalize reads 2 planes of fa.part instead of 18.  Half 0 /
+                        // half 1 go to the two planes; finalize keeps the smaller, the first on ties.
+                        constexpr int CPL = 9;                                // cells per lane: 128 lanes x 9 >= 1096
+                        const int xx = wave >> 1, hh = wave & 1;
+                        const int c0 = (hh * 64 + lane) * CPL;
+                        const float *px = st + xx * D;
+                        int cv[CPL];
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);   // all reads in flight
+                        int best = 0x7f800000, bi = 0;
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) {
+                            const bool lt = c0 + i < D && cv[i] < best;
+                            best = lt ? cv[i] : best;
+                            bi = lt ? i : bi;
+                        }
+                        const int vmin = wave_min1(best);
+                        const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
+                        const int bif = __builtin_amdgcn_readlane(bi, f);
+                        if (lane == 0)
+                            fa.part[(long long)hh * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xx] =
+                                make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
                     }
                 }
                 if (store_row && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
@@ -1087,13 +1083,17 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
     }
 }
 
+// *nparts: planes of fa.part the launched kernel filled -- 2 (the row-image kernel scans a pixel's run in two halves)
+// or ceil(D/64) (the tiled kernel leaves one entry per chunk)
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
-                             int wWin, float *out, const CvFuseArgs &fa, bool *handled) {
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts) {
     *handled = false;
+    *nparts = (hWin * wWin + 63) / 64;
     if (ctx->cv_mode == 1) return DFE_OK;
     if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
     if ((ctx->cv_mode == 0 || ctx->cv_mode == 3) && C == 3 && k == 7) {
         int rc = launch_cv_rowimg<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled);
+        if (*handled) *nparts = 2;
         if (rc != DFE_OK || *handled) return rc;
     }
     if (ctx->cv_mode == 3) return DFE_OK;   // forced row-image kernel that does not apply: unfused path reports it
@@ -1195,13 +1195,14 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         const int Hb = nr + kh - 1 + hWin - 1;
         const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
         bool fused = false;
+        int nparts = nch;
         if (kh == kw) {
             fa.row_off = r0;
-            rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused);
+            rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused, &nparts);
             if (rc) return rc;
         }
         if (fused) {
-            rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nch, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
+            rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nparts, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
                                    imaxs, pitch, pad_t, pad_l, scores_padded);
         } else {
             rc = cv_frames_dispatch(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, kw, hWin, wWin, vol);
