@@ -89,6 +89,42 @@ __global__ void flow_to_depth_radial_kernel(const float *__restrict__ rflow, int
     }
 }
 
+// A12(iii) ardrone/ardrone_api.cpp:99-140.  One thread per pixel; the 20-bin histogram of the 6x6 window lives in two
+// 64-bit registers (ten 6-bit counters each: a bin counts at most 36).
+__global__ void flow_to_depth_ardrone_kernel(const float *__restrict__ xflow, const float *__restrict__ mask, int H, int W, float m,
+                                             float *__restrict__ depth, float *__restrict__ conf) {
+    const long long P = (long long)H * W;
+    const int k = 3, middlex = W / 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(e / W), i = (int)(e - (long long)j * W);
+        const float mk = mask[e];
+        float mode = 0.f;
+        if (mk != 0.f) {
+            unsigned long long lo = 0, hi = 0;              // bins 0..9 / 10..19
+            for (int j2 = max(0, j - k); j2 < min(H, j + k); ++j2)
+                for (int i2 = max(0, i - k); i2 < min(W, i + k); ++i2)
+                    if (mask[(long long)j2 * W + i2] != 0.f) {
+                        const int f = (int)roundf(xflow[(long long)j2 * W + i2]) + 8;
+                        if (f >= 0 && f < 10) lo += 1ull << (6 * f);
+                        else if (f >= 10 && f < 20) hi += 1ull << (6 * (f - 10));
+                    }
+            int best = 0, im = 0;
+            for (int iv = 0; iv < 20; ++iv) {               // first maximum wins (:117-121)
+                const int c = (int)(((iv < 10 ? lo >> (6 * iv) : hi >> (6 * (iv - 10)))) & 63);
+                if (c > best) { best = c; im = iv - 8; }
+            }
+            mode = (float)im;
+        }
+        float d = 0.f, c = 0.f;
+        if (mk > 0.5f && i - middlex != 0) {
+            d = fabsf(mode) < 1.1f ? 100.0f : m * (float)abs(i - middlex) / fabsf(mode);
+            c = 1.0f;
+        }
+        depth[e] = d;
+        conf[e] = c;
+    }
+}
+
 int grid1d(long long n) {
     long long b = (n + 255) / 256;
     if (b > 256 * 32) b = 256 * 32;
@@ -150,6 +186,18 @@ int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, flo
     DFE_REQUIRE(ctx, rflow && depth && conf, DFE_E_ARG, "dfe_flow_to_depth_radial: NULL tensor");
     hipLaunchKernelGGL(flow_to_depth_radial_kernel, dim3(grid1d((long long)H * W)), dim3(256), 0, ctx->stream, rflow, H, W, xcenter,
                        ycenter, infty, depth, conf);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_flow_to_depth_ardrone(dfe_ctx *ctx, const float *xflow, const float *mask, int H, int W, float imu_tx, float *depth,
+                              float *conf) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, H >= 0 && W >= 0, DFE_E_SHAPE, "dfe_flow_to_depth_ardrone: H=%d W=%d", H, W);
+    if ((long long)H * W == 0) return DFE_OK;
+    DFE_REQUIRE(ctx, xflow && mask && depth && conf, DFE_E_ARG, "dfe_flow_to_depth_ardrone: NULL tensor");
+    hipLaunchKernelGGL(flow_to_depth_ardrone_kernel, dim3(grid1d((long long)H * W)), dim3(256), 0, ctx->stream, xflow, mask, H, W,
+                       imu_tx, depth, conf);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

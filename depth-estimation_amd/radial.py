@@ -68,3 +68,32 @@ def flow2depth(networkp, flow, center=None, kinfty=0.65):
     ctx = get_ctx(flow)
     ctx.check(lib().dfe_flow_to_depth_radial(ctx.handle, ptr(flow), H, W, float(center[0]), float(center[1]), infty, ptr(depth), ptr(conf)))
     return depth, conf
+
+
+def getKOutput(networkp):
+    """radial/radial_opticalflow_polar.lua:12-16"""
+    hPolar = networkp["hInput"] - math.floor((networkp["hKernel"] - 1) / 2) - networkp["hWin"] + 1
+    return hPolar / networkp["hInput"]
+
+
+def getP2CMaskOF(networkp, e2, alpha_polar=None, device="cuda"):
+    """radial/radial_opticalflow_polar.lua:18-30: the polar->cartesian grid for the (smaller) optical-flow output.
+    wOutput / hOutput are not integers in general; Torch truncates tensor sizes, so does this."""
+    wPolar = networkp["wInput"]
+    hPolar = networkp["hInput"] - networkp["hKernel"] - networkp["hWin"] + 2
+    kOutput = hPolar / networkp["hInput"]
+    wOutput = networkp["wImg"] * kOutput
+    hOutput = networkp["hImg"] * kOutput
+    newRMax = getRMax(networkp["hImg"], networkp["wImg"], e2) * kOutput
+    return getP2CMask(wPolar, hPolar, int(wOutput), int(hOutput), float(e2[0]) * kOutput, float(e2[1]) * kOutput, newRMax,
+                      alpha_polar, device=device)
+
+
+def computeDepthMapFromFlow(xflow, mask, imu_tx):
+    """ARdroneAPI::computeDepthMapFromFlow (ardrone/ardrone_api.cpp:99-140) -> (depthMap, confidenceMap)"""
+    xflow, mask = xflow.contiguous(), mask.contiguous()
+    H, W = xflow.shape
+    depth, conf = torch.empty_like(xflow), torch.empty_like(xflow)
+    ctx = get_ctx(xflow)
+    ctx.check(lib().dfe_flow_to_depth_ardrone(ctx.handle, ptr(xflow), ptr(mask), H, W, float(imu_tx), ptr(depth), ptr(conf)))
+    return depth, conf

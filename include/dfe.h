@@ -233,6 +233,15 @@ int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, c
 int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, float xcenter,
                              float ycenter, float infty, float *depth, float *conf);
 
+/* ---- A12(iii): x-flow -> depth of the drone API ----------------------------------------------- */
+/* replaces: ARdroneAPI::computeDepthMapFromFlow ardrone/ardrone_api.cpp:99-140.  xflow, mask [H][W];
+ *   mode filter of round(xflow) over the (sic) half-open 6x6 window [i-3,i+3) x [j-3,j+3) of pixels with non-zero
+ *   mask (20 bins, values -8..11; samples outside are skipped -- the reference indexes its histogram unchecked),
+ *   depth = imu_tx*|j-W/2|/|mode| (100 where |mode| < 1.1), conf = 1 where mask > 0.5 and j != W/2; elsewhere
+ *   conf = 0 and depth = 0 (uninitialised in the reference). */
+int dfe_flow_to_depth_ardrone(dfe_ctx *ctx, const float *xflow, const float *mask, int H, int W, float imu_tx,
+                              float *depth, float *conf);
+
 /* ---- A16: postProcessImage(input, mask, winsize, method) ------------------------------------ */
 /* replaces: the inline-C `fmax` (mode) and `fmed` (median) filters and their Lua wrapper
  *   opticalflow_model.lua:323-472.  flow, out [2][H][W] (plane 0 = y, 1 = x), mask [H][W].

@@ -565,6 +565,41 @@ void orc_flow_to_depth_radial(const float *rflow, const float *unused, int H, in
         }
 }
 
+/* A12(iii): ARdroneAPI::computeDepthMapFromFlow. ref: ardrone/ardrone_api.cpp:99-140.
+ * Mode filter of the rounded x-flow over the window [i-3, i+3) x [j-3, j+3) (sic: half-open, 6x6) of pixels with a
+ * non-zero mask, 20 bins for values -8..11 (the reference indexes values[f+8] unchecked: samples outside that range
+ * are undefined behaviour there and are skipped here), first maximum wins; depth = m*|j-W/2|/|mode| (100 where
+ * |mode| < 1.1) and conf = 1 where mask > 0.5 and j != W/2, else conf = 0 and depth 0 (left uninitialised there). */
+void orc_flow_to_depth_ardrone(const float *xflow, const float *mask, int H, int W, float m, float *depth, float *conf) {
+    const int k = 3, middlex = W / 2;
+    for (int j = 0; j < H; ++j)
+        for (int i = 0; i < W; ++i) {
+            float mode = 0.f;
+            if (mask[(size_t)j * W + i] != 0.f) {
+                int values[20] = {0};
+                int i2a = i - k > 0 ? i - k : 0, i2b = i + k < W ? i + k : W;
+                int j2a = j - k > 0 ? j - k : 0, j2b = j + k < H ? j + k : H;
+                for (int i2 = i2a; i2 < i2b; ++i2)
+                    for (int j2 = j2a; j2 < j2b; ++j2)
+                        if (mask[(size_t)j2 * W + i2] != 0.f) {
+                            int f = (int)roundf(xflow[(size_t)j2 * W + i2]);
+                            if (f >= -8 && f < 12) ++values[f + 8];
+                        }
+                int best = 0, im = 0;
+                for (int iv = 0; iv < 20; ++iv)
+                    if (values[iv] > best) { best = values[iv]; im = iv - 8; }
+                mode = (float)im;
+            }
+            float d = 0.f, c = 0.f;
+            if (mask[(size_t)j * W + i] > 0.5f && i - middlex != 0) {
+                d = fabsf(mode) < 1.1f ? 100.0f : m * (float)abs(i - middlex) / fabsf(mode);
+                c = 1.0f;
+            }
+            depth[(size_t)j * W + i] = d;
+            conf[(size_t)j * W + i] = c;
+        }
+}
+
 /* ---- A13 / A14 --------------------------------------------------------- */
 void orc_polar_grid_c2p(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc, int lpad,
                         int rpad, float rmax, float alpha, float *mask) {

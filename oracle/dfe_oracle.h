@@ -130,6 +130,9 @@ void orc_flow_to_depth_cartesian(const float *flow, int H, int W, float cx, floa
 void orc_flow_to_depth_radial(const float *rflow, const float *cartidx_conf, int H, int W,
                               float cx, float cy, float infty, float *depth, float *conf);
 
+/* (iii) ref: ardrone/ardrone_api.cpp:99-140 `computeDepthMapFromFlow`: xflow, mask [H][W]; m = IMU x-translation */
+void orc_flow_to_depth_ardrone(const float *xflow, const float *mask, int H, int W, float m, float *depth, float *conf);
+
 /* A13 polar grids. ref: radial/cartesian2polar.lua:4-49 (C2P), :51-89 (P2C) */
 void orc_polar_grid_c2p(int wsrc, int hsrc, int wdst, int hdst, float xc, float yc,
                         int lpad, int rpad, float rmax, float alpha, float *mask /*[2][hdst][wdst+lpad+rpad]*/);

@@ -53,6 +53,7 @@ def lib():
             "orc_paste_center": (None, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]),
             "orc_flow_to_depth_cartesian": (None, [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]),
             "orc_flow_to_depth_radial": (None, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]),
+            "orc_flow_to_depth_ardrone": (None, [f32p, f32p, C.c_int, C.c_int, C.c_float, f32p, f32p]),
             "orc_polar_grid_c2p": (None, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
             "orc_polar_grid_p2c": (None, [C.c_int] * 4 + [C.c_float] * 4 + [f32p]),
             "orc_warp_bilinear": (None, [f32p] + [C.c_int] * 3 + [f32p, C.c_int, C.c_int, f32p]),
@@ -246,6 +247,14 @@ def flow_to_depth_radial(rflow, cx, cy, infty):
     H, W = rflow.shape
     d, c = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
     lib().orc_flow_to_depth_radial(rflow, None, H, W, cx, cy, infty, d, c)
+    return d, c
+
+
+def flow_to_depth_ardrone(xflow, mask, m):
+    xflow, mask = _f(xflow), _f(mask)
+    H, W = xflow.shape
+    d, c = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
+    lib().orc_flow_to_depth_ardrone(xflow, mask, H, W, m, d, c)
     return d, c
 
 

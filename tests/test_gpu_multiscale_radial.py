@@ -283,3 +283,23 @@ def test_glue_modules(dfe, cuda):
     ex, ey = orc.output_extractor(p, maxh, maxw)
     gx, gy = dfe.nn.OutputExtractor(maxh, maxw).forward(T(p, cuda))
     assert np.allclose(gx.cpu().numpy(), ex, rtol=0, atol=2e-6) and np.allclose(gy.cpu().numpy(), ey, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (5, 8), (120, 160)])
+def test_flow_to_depth_ardrone_bit_exact(dfe, cuda, H, W):
+    """A12(iii) ardrone/ardrone_api.cpp:99-140 + the polar helpers of radial_opticalflow_polar.lua:12-30."""
+    rng = np.random.default_rng(H)
+    xflow = (rng.standard_normal((H, W)) * 3).astype(np.float32)
+    xflow[rng.random((H, W)) < 0.05] = 25.0                       # out-of-range samples are skipped on both sides
+    mask = rng.choice(np.array([0.0, 0.3, 1.0], np.float32), size=(H, W), p=[0.2, 0.1, 0.7])
+    ed, ec = orc.flow_to_depth_ardrone(xflow, mask, 0.37)
+    d, c = dfe.computeDepthMapFromFlow(T(xflow, cuda), T(mask, cuda), 0.37)
+    assert np.array_equal(d.cpu().numpy(), ed) and np.array_equal(c.cpu().numpy(), ec)
+    networkp = dict(hInput=96, wInput=128, hKernel=7, hWin=17, hImg=240, wImg=320)
+    assert dfe.getKOutput(networkp) == (96 - 3 - 17 + 1) / 96
+    e2 = (170.0, 110.0)
+    m = dfe.getP2CMaskOF(networkp, e2, 1.0)
+    hPolar = 96 - 7 - 17 + 2
+    kO = hPolar / 96
+    ref = orc.polar_grid_p2c(128, hPolar, int(320 * kO), int(240 * kO), e2[0] * kO, e2[1] * kO, dfe.getRMax(240, 320, e2) * kO, 1.0)
+    assert tuple(m.shape) == ref.shape and np.allclose(m.cpu().numpy(), ref, rtol=1e-6, atol=1e-4)

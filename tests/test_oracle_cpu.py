@@ -309,3 +309,34 @@ def test_cascading_add_backward_is_the_adjoint_of_forward(ratios, mh, mw):
     # incompatible geometry is refused like the forward
     rc3, _ = orc.cascading_add_backward([np.zeros((1, 2, 2), np.float32)] * 2, [1, 2], 2, 2)
     assert rc3 != 0
+
+
+def test_flow_to_depth_ardrone_hand_vector():
+    """A12(iii) ardrone/ardrone_api.cpp:99-140 on a vector worked by hand: the window is [i-3, i+3) (half-open), masked
+    samples only, first maximum of the histogram wins, |mode| < 1.1 -> 100, the centre column and unmasked pixels get
+    conf 0."""
+    H, W = 5, 8
+    xflow = np.zeros((H, W), np.float32)
+    xflow[:, :4] = 2.4      # rounds to 2
+    xflow[:, 4:] = -3.6     # rounds to -4
+    mask = np.ones((H, W), np.float32)
+    mask[0, 0] = 0.0        # not a sample, no output
+    mask[1, 1] = 0.3        # a sample (non-zero) but conf 0 (<= 0.5)
+    d, c = orc.flow_to_depth_ardrone(xflow, mask, 0.5)
+    middlex = W // 2
+    assert c[0, 0] == 0 and d[0, 0] == 0 and c[1, 1] == 0
+    assert np.all(c[:, middlex] == 0)
+    # pixel (2, 1): window columns [-2..3] -> 0..3 all "2": mode 2 -> 0.5*|1-4|/2
+    assert c[2, 1] == 1 and d[2, 1] == np.float32(0.5 * 3 / 2)
+    # pixel (2, 6): window columns 3..7: one column of 2 (col 3), four of -4 -> mode -4 -> 0.5*2/4
+    assert d[2, 6] == np.float32(0.5 * 2 / 4)
+    # pixel (2, 5): columns 2..7 -> two columns of 2, four of -4 -> -4
+    assert d[2, 5] == np.float32(0.5 * 1 / 4)
+    # tie: columns 1..6 around i=4 is the centre column (conf 0); i=3: columns 0..5 -> four columns of 2, two of -4 -> 2
+    assert d[2, 3] == np.float32(0.5 * 1 / 2)
+    # small flow -> 100
+    d2, c2 = orc.flow_to_depth_ardrone(np.full((H, W), 0.4, np.float32), np.ones((H, W), np.float32), 1.0)
+    assert np.all(d2[:, [0, 1, 2, 3, 5, 6, 7]] == 100.0) and np.all(c2[:, middlex] == 0)
+    # out-of-range samples (the reference's unchecked histogram index) are skipped
+    d3, _ = orc.flow_to_depth_ardrone(np.full((H, W), 40.0, np.float32), np.ones((H, W), np.float32), 1.0)
+    assert np.all(d3[:, 0] == 100.0)
