@@ -30,6 +30,7 @@ from .opticalflow_model import (  # noqa: F401
     x2yxMultiNumber,
     getMiddleIndex,
     getOutputConfidences,
+    getOutputConfidences2,
     processOutput,
 )
 from .multiscale import CascadingAddTable, MultiscaleModel, getModelMultiscale  # noqa: F401

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "dfe_polar_grid_p2c_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_float] * 4 + [C.c_void_p]),
     "dfe_warp_bilinear_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 3 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dfe_flow_to_depth_radial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "dfe_marginal_sum_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "dfe_flow_to_depth_ardrone": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "dfe_postprocess_image_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "dfe_enlarge_mask_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4),

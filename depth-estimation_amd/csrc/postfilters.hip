@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void output_extractor_kernel(const float *__re
 
 }  // namespace
 
+// A11 'mean' extraction: out[p] = sum_b in[p][b], double accumulator (opticalflow_model.lua:192; TH sums floats in double)
+__global__ void marginal_sum_kernel(const float *__restrict__ in, long long n, int B, float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        double acc = 0;
+        for (int b = 0; b < B; ++b) acc += in[e * B + b];
+        out[e] = (float)acc;
+    }
+}
+
 extern "C" {
 
 int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask, int H, int W, int winsize, int method,
@@ -189,6 +198,19 @@ int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int ma
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, input && x && y, DFE_E_ARG, "dfe_output_extractor_f32: NULL tensor");
     hipLaunchKernelGGL(output_extractor_kernel, dim3(grid1d(P, 4)), dim3(256), 0, ctx->stream, input, (long long)P, maxh, maxw, x, y);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, P >= 0 && A > 0 && B > 0, DFE_E_SHAPE, "dfe_marginal_sum_f32: P=%lld A=%d B=%d", (long long)P, A, B);
+    if (P == 0) return DFE_OK;
+    DFE_REQUIRE(ctx, in && out, DFE_E_ARG, "dfe_marginal_sum_f32: NULL tensor");
+    const long long n = (long long)P * A;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(marginal_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, in, n, B, out);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

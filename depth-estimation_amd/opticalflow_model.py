@@ -129,17 +129,45 @@ def getOutputConfidences(geometry, input, threshold=None):
     return imaxs, scores.gt(threshold)
 
 
+def getOutputConfidences2(geometry, input):
+    """opticalflow_model.lua:171-199 ('mean' extraction): soft arg-max y, x (1-based cell coordinates, float) and the
+    confidence mask: extractOutput on the window's row marginal (threshold 0.11), confident where a score was written."""
+    if input.dim() != 3:
+        raise ValueError("getOutputConfidences2: input must be H x W x N")
+    input = input.contiguous()
+    H, W, N = input.shape
+    maxh, maxw = _g(geometry, "maxh"), _g(geometry, "maxw")
+    if N != maxh * maxw:
+        raise ValueError("getOutputConfidences2: N != maxh*maxw")
+    ctx = get_ctx(input)
+    x = torch.empty((H, W), dtype=torch.float32, device=input.device)
+    y = torch.empty_like(x)
+    ctx.check(lib().dfe_output_extractor_f32(ctx.handle, ptr(input), H * W, maxh, maxw, ptr(x), ptr(y)))
+    marg = torch.empty((H, W, maxh), dtype=torch.float32, device=input.device)
+    ctx.check(lib().dfe_marginal_sum_f32(ctx.handle, ptr(input), H * W, maxh, maxw, ptr(marg)))
+    imaxs = torch.zeros((H, W), dtype=torch.int64, device=input.device)
+    scores = torch.zeros((H, W), dtype=torch.float32, device=input.device)   # uninitialised in the reference (:193)
+    extractoutput.extractOutput(marg, scores, 0.11, imaxs)
+    return y, x, scores.gt(0)
+
+
 def processOutput(geometry, output, process_full=None, threshold=None):
-    """opticalflow_model.lua:201-252 ('max' extraction): index, confidences, y, x and the
-    centre-pasted full-frame flow (plane 0 = y, plane 1 = x)."""
-    if _g(geometry, "output_extraction_method", "max") != "max":
-        raise NotImplementedError("processOutput: only output_extraction_method='max' is on the hot path")
+    """opticalflow_model.lua:201-252: index, confidences, y, x and the centre-pasted full-frame flow (plane 0 = y,
+    plane 1 = x), for output_extraction_method 'max' (arg-max with the centre tie-break / extractOutput) and 'mean'
+    (soft arg-max, single scale only)."""
     ret = {}
-    ret["index"], ret["confidences"] = getOutputConfidences(geometry, output, threshold)
-    if _g(geometry, "multiscale"):
-        ret["y"], ret["x"] = x2yxMulti(geometry, ret["index"])
+    if _g(geometry, "output_extraction_method", "max") == "max":
+        ret["index"], ret["confidences"] = getOutputConfidences(geometry, output, threshold)
+        if _g(geometry, "multiscale"):
+            ret["y"], ret["x"] = x2yxMulti(geometry, ret["index"])
+        else:
+            y, x = x2yx(geometry, ret["index"])
+            yoff, xoff = centered2onebased(geometry, 0, 0)
+            ret["y"], ret["x"] = y - yoff, x - xoff
     else:
-        y, x = x2yx(geometry, ret["index"])
+        assert not _g(geometry, "multiscale")   # :219
+        y, x, ret["confidences"] = getOutputConfidences2(geometry, output)
+        ret["index"] = yx2x(geometry, torch.floor(y + 0.5), torch.floor(x + 0.5)).to(torch.int64)   # :221
         yoff, xoff = centered2onebased(geometry, 0, 0)
         ret["y"], ret["x"] = y - yoff, x - xoff
     if process_full is None:

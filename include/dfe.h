@@ -263,6 +263,11 @@ int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy
 int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw,
                              float *x, float *y);
 
+/* ---- A11 ('mean' extraction): marginal of the window over its columns --------------------------- */
+/* replaces: input:reshape(H,W,maxh,maxw):sum(4) in getOutputConfidences2, opticalflow_model.lua:192.
+ *   in [P][A][B] -> out [P][A], double accumulator as in TH. */
+int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out);
+
 #ifdef __cplusplus
 }
 #endif

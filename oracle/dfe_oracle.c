@@ -565,6 +565,16 @@ void orc_flow_to_depth_radial(const float *rflow, const float *unused, int H, in
         }
 }
 
+/* A11 'mean' extraction helper: input:reshape(H,W,maxh,maxw):sum(4). ref: opticalflow_model.lua:192.
+ * [3P-recall: TH sums float tensors in a double accumulator] in [P][A][B] -> out [P][A] */
+void orc_marginal_sum(const float *in, int64_t P, int A, int B, float *out) {
+    for (int64_t p = 0; p < P * A; ++p) {
+        double acc = 0;
+        for (int b = 0; b < B; ++b) acc += in[p * B + b];
+        out[p] = (float)acc;
+    }
+}
+
 /* A12(iii): ARdroneAPI::computeDepthMapFromFlow. ref: ardrone/ardrone_api.cpp:99-140.
  * Mode filter of the rounded x-flow over the window [i-3, i+3) x [j-3, j+3) (sic: half-open, 6x6) of pixels with a
  * non-zero mask, 20 bins for values -8..11 (the reference indexes values[f+8] unchecked: samples outside that range

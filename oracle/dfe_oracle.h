@@ -130,6 +130,9 @@ void orc_flow_to_depth_cartesian(const float *flow, int H, int W, float cx, floa
 void orc_flow_to_depth_radial(const float *rflow, const float *cartidx_conf, int H, int W,
                               float cx, float cy, float infty, float *depth, float *conf);
 
+/* A11 'mean' extraction: marginal of the window over its columns. ref: opticalflow_model.lua:192. in [P][A][B] -> [P][A] */
+void orc_marginal_sum(const float *in, int64_t P, int A, int B, float *out);
+
 /* (iii) ref: ardrone/ardrone_api.cpp:99-140 `computeDepthMapFromFlow`: xflow, mask [H][W]; m = IMU x-translation */
 void orc_flow_to_depth_ardrone(const float *xflow, const float *mask, int H, int W, float m, float *depth, float *conf);
 

@@ -54,6 +54,7 @@ def lib():
             "orc_flow_to_depth_cartesian": (None, [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]),
             "orc_flow_to_depth_radial": (None, [f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, f32p, f32p]),
             "orc_flow_to_depth_ardrone": (None, [f32p, f32p, C.c_int, C.c_int, C.c_float, f32p, f32p]),
+            "orc_marginal_sum": (None, [f32p, C.c_int64, C.c_int, C.c_int, f32p]),
             "orc_polar_grid_c2p": (None, [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, f32p]),
             "orc_polar_grid_p2c": (None, [C.c_int] * 4 + [C.c_float] * 4 + [f32p]),
             "orc_warp_bilinear": (None, [f32p] + [C.c_int] * 3 + [f32p, C.c_int, C.c_int, f32p]),
@@ -248,6 +249,14 @@ def flow_to_depth_radial(rflow, cx, cy, infty):
     d, c = np.empty((H, W), np.float32), np.empty((H, W), np.float32)
     lib().orc_flow_to_depth_radial(rflow, None, H, W, cx, cy, infty, d, c)
     return d, c
+
+
+def marginal_sum(inp, A, B):
+    inp = _f(inp)
+    P = inp.size // (A * B)
+    out = np.empty((P, A), np.float32)
+    lib().orc_marginal_sum(inp.reshape(-1), P, A, B, out)
+    return out
 
 
 def flow_to_depth_ardrone(xflow, mask, m):

@@ -303,3 +303,31 @@ def test_flow_to_depth_ardrone_bit_exact(dfe, cuda, H, W):
     kO = hPolar / 96
     ref = orc.polar_grid_p2c(128, hPolar, int(320 * kO), int(240 * kO), e2[0] * kO, e2[1] * kO, dfe.getRMax(240, 320, e2) * kO, 1.0)
     assert tuple(m.shape) == ref.shape and np.allclose(m.cpu().numpy(), ref, rtol=1e-6, atol=1e-4)
+
+
+def test_process_output_mean_extraction(dfe, cuda):
+    """processOutput with output_extraction_method = 'mean' (opticalflow_model.lua:171-199, 218-226): soft arg-max,
+    confidences from extractOutput on the row marginal, index = yx2x(floor(y+.5), floor(x+.5)), centred y / x."""
+    rng = np.random.default_rng(5)
+    H, W, mh, mw = 21, 17, 8, 8
+    logits = rng.standard_normal((H, W, mh * mw)).astype(np.float32) * 2
+    prob = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+    prob = prob.astype(np.float32)
+    prob[3, 4] = 1.0 / (mh * mw)                         # a flat pixel: every row marginal is 0.125 > 0.11
+    prob[5, 6] = 0.0
+    prob[5, 6, 10] = 1.0                                 # a one-hot pixel
+    geometry = dict(maxh=mh, maxw=mw, hImg=H + 8, wImg=W + 8, multiscale=False, output_extraction_method="mean")
+    ret = dfe.processOutput(geometry, T(prob, cuda))
+    ex, ey = orc.output_extractor(prob, mh, mw)
+    marg = orc.marginal_sum(prob, mh, mw).reshape(H, W, mh)
+    gy, gx = ret["y"].cpu().numpy() + np.float32(4), ret["x"].cpu().numpy() + np.float32(4)   # back to 1-based cell coordinates
+    assert np.allclose(gy, ey, rtol=0, atol=4e-6) and np.allclose(gx, ex, rtol=0, atol=4e-6)    # (summation order, as in A18's test)
+    sc, im = np.zeros((H, W), np.float32), np.zeros((H, W), np.int64)
+    orc.extract_output(marg, 0.11, im, sc)
+    assert np.array_equal(ret["confidences"].cpu().numpy(), sc > 0)
+    eidx = (np.floor(gy + 0.5) - 1) * mw + np.floor(gx + 0.5)
+    assert np.array_equal(ret["index"].cpu().numpy(), eidx.astype(np.int64))
+    assert ret["index"][5, 6].item() == 11 and abs(ret["y"][5, 6].item() - (2 - 4)) < 1e-6 and abs(ret["x"][5, 6].item() - (3 - 4)) < 1e-6
+    full = ret["full"].cpu().numpy()
+    assert full.shape == (2, H + 8, W + 8) and np.array_equal(full[0, 4 : 4 + H, 4 : 4 + W], ret["y"].cpu().numpy())
+    assert np.all(full[:, :4] == 0)
