@@ -2,6 +2,8 @@
 for the raw-patch (identity filter) case: pyramid volumes -> softmin -> cascade -> ring extraction."""
 import ctypes as C
 
+import math
+
 import torch
 
 from ._lib import lib, ratios_array
@@ -92,7 +94,14 @@ class MultiscaleModel(Module):
         maxh, maxw, kh, kw = _g(g, "maxh"), _g(g, "maxw"), _g(g, "hKernel"), _g(g, "wKernel")
         rmax = self.ratios[-1]
         if H % rmax or W % rmax:
-            raise ValueError("frame %dx%d must be a multiple of the coarsest ratio %d" % (H, W, rmax))  # :238-243 pads; not needed here
+            # opticalflow_model_multiscale.lua:234-248: nn.SpatialPadding(0,0,0,0) with pad_b / pad_r up to the next
+            # multiple of the coarsest ratio, zeros; the output keeps the padded size (nothing crops it back)
+            th, tw = rmax * math.ceil(H / rmax), rmax * math.ceil(W / rmax)
+            p0 = torch.zeros((Cc, th, tw), dtype=i0.dtype, device=i0.device)
+            p1 = torch.zeros_like(p0)
+            p0[:, :H, :W] = i0
+            p1[:, :H, :W] = i1
+            i0, i1, H, W = p0, p1, th, tw
         ctx = get_ctx(i0)
         l = lib()
         N = maxh * maxw

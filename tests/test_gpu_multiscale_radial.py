@@ -170,6 +170,22 @@ def test_multiscale_model_end_to_end(dfe, cuda):
     assert ok[inner].mean() > 0.9
 
 
+def test_multiscale_model_pads_to_a_multiple_of_the_coarsest_ratio(dfe, cuda):
+    """opticalflow_model_multiscale.lua:234-248: frames whose size is not a multiple of rmax are zero-padded at the
+    bottom / right and the output keeps the padded size -- identical to running the padded frames."""
+    H, W = 50, 70
+    geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4], multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=9, max_flow=6, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    p0, p1 = np.zeros((3, 52, 72), np.float32), np.zeros((3, 52, 72), np.float32)
+    p0[:, :H, :W], p1[:, :H, :W] = f0, f1
+    model = dfe.getModelMultiscale(geo)
+    a = model.forward([T(f0, cuda), T(f1, cuda)])
+    b = dfe.getModelMultiscale(geo).forward([T(p0, cuda), T(p1, cuda)])
+    assert tuple(a.shape) == (52, 72, 160) and torch.equal(a, b)
+    assert np.allclose(model.volumes[2].cpu().numpy(), orc.pyramid_scale_volume(p0, p1, 4, 7, 7, 8, 8), rtol=1e-5, atol=1e-5)   # fast-kernel summation order
+
+
 def test_polar_grids_and_warp(dfe, cuda):
     wsrc, hsrc, wdst, hdst = 128, 96, 100, 60
     e2 = (70.5, 40.25)
