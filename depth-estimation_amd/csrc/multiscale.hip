@@ -168,6 +168,78 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGe
     }
 }
 
+// A4 + A5 + A6 + A10 in one pass: cascade coarse -> fine exactly like cascade_kernel<true>, but instead of writing the
+// joined [H][W][ncls] tensor the wave keeps the running arg-max over the classes it would have written (first maximum
+// wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
+// and decodes the winning class (x2yxMultiNumber).  Values are the same float sums in the same order, so the result is
+// bit-identical to cascade_ring -> argbest_center -> x2yx_multi.
+__global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom g, MultiGeom mg, int middle, long long *__restrict__ idx,
+                                                                     float *__restrict__ best_out, float *__restrict__ fy,
+                                                                     float *__restrict__ fx, int pitch, int pad_t, int pad_l) {
+    extern __shared__ float sh[];
+    const int N = g.maxh * g.maxw;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float *cur = sh + (size_t)w * 2 * N, *prev = cur + N;
+    const long long P = (long long)g.H * g.W;
+    for (long long p = (long long)blockIdx.x * kWaves + w; p < P; p += (long long)gridDim.x * kWaves) {
+        const int y = (int)(p / g.W), x = (int)(p - (long long)y * g.W);
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;           // 0-based class id
+        float centre = 0.f;
+        for (int s = g.nratios - 1; s >= 0; --s) {
+            const int r = g.ratios[s];
+            const float *src = g.in[s] + ((long long)(y / r) * (g.W / r) + x / r) * N;
+            const int d = g.d[s], mh = g.maxh, mw = g.maxw;
+            int r2 = 1, q = 1, dh = 0, dw = 0;
+            if (s < g.nratios - 1) {
+                r2 = g.ratios[s + 1]; q = r2 / r;
+                dh = mh * (r2 - r) / (2 * r2); dw = mw * (r2 - r) / (2 * r2);
+            }
+            for (int n = lane; n < N; n += 64) {
+                const int a = n / mw, b = n - a * mw;
+                float v = src[n];
+                if (s < g.nratios - 1) v += prev[(dh + a / q) * mw + dw + b / q];
+                cur[n] = v;
+                int cls = -1;          // class of this cell in the joined vector, -1 = not emitted (inside the ring hole)
+                if (s == 0) cls = n;
+                else if (a < d) cls = a * mw + b;
+                else if (a >= mh - d) cls = d * mw + 2 * (mh - 2 * d) * d + (a - (mh - d)) * mw + b;
+                else if (b < d) cls = d * mw + (a - d) * d + b;
+                else if (b >= mw - d) cls = d * mw + (mh - 2 * d) * d + (a - d) * d + (b - (mw - d));
+                if (cls >= 0) {
+                    cls += g.base[s];
+                    if (v > bv || (v == bv && cls < bi)) { bv = v; bi = cls; }
+                    if (cls == middle - 1) centre = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            float *t = cur; cur = prev; prev = t;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            centre += __shfl_xor(centre, off);       // exactly one lane holds it, the others 0
+        }
+        if (lane == 0) {
+            long long id = (long long)bi + 1;
+            if (middle > 0 && bv == centre) id = middle;
+            if (idx) idx[p] = id;
+            if (best_out) best_out[p] = bv;
+            if (fy) {
+                long long oy = 0, ox = 0;
+                multi_decode(mg, id, &oy, &ox);
+                const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
+                fy[fo] = (float)oy;
+                fx[fo] = (float)ox;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int ring_width(int maxw, int r, int rprev) { return (int)floor((double)maxw * (r - rprev) / (2.0 * r) + 0.5); }
 
 int fill_cascade(dfe_ctx *ctx, CascadeGeom &g, const int *ratios, int nratios, int maxh, int maxw) {
@@ -267,6 +339,36 @@ int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_ring_f32: window %dx%d too large", maxh, maxw);
     hipLaunchKernelGGL(cascade_kernel<true>, dim3(grid1d((long long)H * W, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw,
+                         int64_t *idx, float *best, float *flow_y, float *flow_x) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    CascadeGeom g;
+    int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
+    if (rc) return rc;
+    DFE_REQUIRE(ctx, prob && H > 0 && W > 0, DFE_E_ARG, "dfe_cascade_flow_f32: bad argument");
+    DFE_REQUIRE(ctx, (flow_y == nullptr) == (flow_x == nullptr), DFE_E_ARG, "dfe_cascade_flow_f32: flow_y and flow_x go together");
+    DFE_REQUIRE(ctx, idx || flow_y || best, DFE_E_ARG, "dfe_cascade_flow_f32: no output requested");
+    MultiGeom mg;
+    mg.maxh = maxh; mg.maxw = maxw; mg.nratios = nratios;
+    for (int s = 0; s < nratios; ++s) {
+        DFE_REQUIRE(ctx, prob[s], DFE_E_ARG, "dfe_cascade_flow_f32: prob[%d] is NULL", s);
+        DFE_REQUIRE(ctx, H % ratios[s] == 0 && W % ratios[s] == 0, DFE_E_SHAPE, "dfe_cascade_flow_f32: %dx%d not a multiple of ratio %d", H, W, ratios[s]);
+        g.in[s] = prob[s];
+        g.out_scale[s] = nullptr;
+        mg.ratios[s] = ratios[s];
+        mg.d[s] = g.d[s];
+    }
+    g.H = H; g.W = W;
+    // middle class = yx2xMulti(0, 0): the centre cell of scale 1 (opticalflow_model.lua:36-43)
+    const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;
+    size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
+    DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_flow_f32: window %dx%d too large", maxh, maxw);
+    hipLaunchKernelGGL(cascade_argmax_kernel, dim3(grid1d((long long)H * W, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
+                       (long long *)idx, best, flow_y, flow_x, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

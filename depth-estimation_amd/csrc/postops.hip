@@ -108,55 +108,6 @@ __global__ void x2yx_kernel(const long long *__restrict__ idx, long long P, int 
     }
 }
 
-struct MultiGeom {
-    int maxh, maxw, nratios;
-    int ratios[DFE_MAX_RATIOS];
-    int d[DFE_MAX_RATIOS];   // ring width per scale (index >= 1)
-};
-
-__host__ __device__ inline int multi_decode(const MultiGeom &g, long long id, long long *oy, long long *ox) {
-    // replaces: x2yxMultiNumber opticalflow_model_multiscale.lua:83-132
-    const int maxh = g.maxh, maxw = g.maxw;
-    const int chh = (maxh + 1) / 2, chw = (maxw + 1) / 2;
-    long long x = id;
-    if (x < 1) return -1;
-    if (x <= (long long)maxh * maxw) {
-        *oy = (x - 1) / maxw + 1 - chh;
-        *ox = (x - 1) % maxw + 1 - chw;
-        return 0;
-    }
-    x -= (long long)maxh * maxw;
-    for (int i = 1; i < g.nratios; ++i) {
-        const int d = g.d[i];
-        const long long len = 2ll * d * maxw + 2ll * (maxh - 2 * d) * d;
-        long long ty, tx;
-        if (x <= len) {
-            if (x <= (long long)d * maxw) {
-                ty = (x - 1) / maxw + 1; tx = (x - 1) % maxw + 1;
-            } else {
-                x -= (long long)d * maxw;
-                if (x <= (long long)(maxh - 2 * d) * d) {
-                    ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1;
-                } else {
-                    x -= (long long)(maxh - 2 * d) * d;
-                    if (x <= (long long)(maxh - 2 * d) * d) {
-                        ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1 + maxw - d;
-                    } else {
-                        x -= (long long)(maxh - 2 * d) * d;
-                        if (x > (long long)d * maxw) return -1;
-                        ty = (x - 1) / maxw + 1 + maxh - d; tx = (x - 1) % maxw + 1;
-                    }
-                }
-            }
-            *oy = (ty - chh) * g.ratios[i];
-            *ox = (tx - chw) * g.ratios[i];
-            return 0;
-        }
-        x -= len;
-    }
-    return -1;
-}
-
 __global__ void x2yx_multi_kernel(MultiGeom g, const long long *__restrict__ idx, long long P, long long *__restrict__ y,
                                   long long *__restrict__ x, int *__restrict__ flag) {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {

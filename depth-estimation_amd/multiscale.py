@@ -121,6 +121,58 @@ class MultiscaleModel(Module):
         return out
 
 
+    def forwardFlow(self, input, process_full=True):
+        """model:forward(input) followed by processOutput(geometry, output, process_full) for the 'max' extraction
+        without a threshold (opticalflow_model.lua:201-252), fused: the H x W x nclasses tensor is never built
+        (dfe_cascade_flow_f32).  Returns the same table: index, confidences (all 1), y, x [, full, full_confidences]."""
+        g = self.geometry
+        i0, i1 = input
+        i0, i1 = i0.contiguous(), i1.contiguous()
+        Cc, H, W = i0.shape
+        maxh, maxw, kh, kw = _g(g, "maxh"), _g(g, "maxw"), _g(g, "hKernel"), _g(g, "wKernel")
+        rmax = self.ratios[-1]
+        if H % rmax or W % rmax:   # opticalflow_model_multiscale.lua:234-248
+            th, tw = rmax * math.ceil(H / rmax), rmax * math.ceil(W / rmax)
+            p0 = torch.zeros((Cc, th, tw), dtype=i0.dtype, device=i0.device)
+            p1 = torch.zeros_like(p0)
+            p0[:, :H, :W] = i0
+            p1[:, :H, :W] = i1
+            i0, i1, H, W = p0, p1, th, tw
+        ctx = get_ctx(i0)
+        l = lib()
+        N = maxh * maxw
+        self.volumes, self.probs = [], []
+        for r in self.ratios:
+            vol = torch.empty((H // r, W // r, maxh, maxw), dtype=torch.float32, device=i0.device)
+            ctx.check(l.dfe_pyramid_scale_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, r, kh, kw, maxh, maxw, ptr(vol)))
+            prob = torch.empty_like(vol)
+            ctx.check(l.dfe_softmin_f32(ctx.handle, ptr(vol), vol.numel() // N, N, ptr(prob)))
+            self.volumes.append(vol)
+            self.probs.append(prob)
+        rr, n = ratios_array(self.ratios)
+        idx = torch.empty((H, W), dtype=torch.int64, device=i0.device)
+        fy = torch.empty((H, W), dtype=torch.float32, device=i0.device)
+        fx = torch.empty_like(fy)
+        ctx.check(l.dfe_cascade_flow_f32(ctx.handle, _ptr_array(self.probs), rr, n, H, W, maxh, maxw, ptr(idx), None, ptr(fy), ptr(fx)))
+        ret = {"index": idx, "confidences": torch.ones((H, W), dtype=torch.float32, device=i0.device),
+               "y": fy.to(torch.int64), "x": fx.to(torch.int64)}
+        if process_full:
+            hImg, wImg = _g(g, "hImg"), _g(g, "wImg")
+            ho, wo = (hImg - H) // 2, (wImg - W) // 2
+            if ho == 0 and wo == 0:
+                ret["full"] = torch.stack([fy, fx])
+                ret["full_confidences"] = ret["confidences"]
+            else:
+                full = torch.zeros((2, hImg, wImg), dtype=torch.float32, device=i0.device)
+                full[0, ho : ho + H, wo : wo + W] = fy
+                full[1, ho : ho + H, wo : wo + W] = fx
+                ret["full"] = full
+                fc = torch.zeros((hImg, wImg), dtype=torch.float32, device=i0.device)
+                fc[ho : ho + H, wo : wo + W] = 1.0
+                ret["full_confidences"] = fc
+        return ret
+
+
 def getModelMultiscale(geometry, full_image=True, prefiltered=False):
     """opticalflow_model_multiscale.lua:175 (inference mode, identity patch filter)."""
     if prefiltered:

