@@ -168,6 +168,27 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGe
     }
 }
 
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
+#undef DFE_STEP
+    const int b = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = fmaxf(__int_as_float((int)r[0]), __int_as_float((int)r[1]));
+    const int c = __float_as_int(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#define DFE_STEP(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false))
+    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);
+#undef DFE_STEP
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min((int)r[0], (int)r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min((int)q[0], (int)q[1]);
+}
+
 // A4 + A5 + A6 + A10 in one pass: cascade coarse -> fine exactly like cascade_kernel<true>, but instead of writing the
 // joined [H][W][ncls] tensor the wave keeps the running arg-max over the classes it would have written (first maximum
 // wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
@@ -181,6 +202,92 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float *cur = sh + (size_t)w * 2 * N, *prev = cur + N;
     const long long P = (long long)g.H * g.W;
+    if (N <= 64) {
+        // One cell per lane: everything that depends on the cell only -- where it reads the coarser window (crop +
+        // replicate) and which class it is in the joined vector -- is worked out once per wave; per pixel and scale
+        // remain one coalesced load, one cross-lane read of the coarser result (no LDS buffer, no barrier), one add and
+        // the running arg-max.
+        int gsrc[DFE_MAX_RATIOS], cls[DFE_MAX_RATIOS];
+        const int a = lane / g.maxw, b = lane - a * g.maxw;
+        for (int s = 0; s < g.nratios; ++s) {
+            const int d = g.d[s], mh = g.maxh, mw = g.maxw;
+            gsrc[s] = 0;
+            if (s < g.nratios - 1) {
+                const int r = g.ratios[s], r2 = g.ratios[s + 1], q = r2 / r;
+                const int dh = mh * (r2 - r) / (2 * r2), dw = mw * (r2 - r) / (2 * r2);
+                gsrc[s] = lane < N ? (dh + a / q) * mw + dw + b / q : 0;
+            }
+            int c = -1;
+            if (lane < N) {
+                if (s == 0) c = lane;
+                else if (a < d) c = a * mw + b;
+                else if (a >= mh - d) c = d * mw + 2 * (mh - 2 * d) * d + (a - (mh - d)) * mw + b;
+                else if (b < d) c = d * mw + (a - d) * d + b;
+                else if (b >= mw - d) c = d * mw + (mh - 2 * d) * d + (a - d) * d + (b - (mw - d));
+                if (c >= 0) c += g.base[s];
+            }
+            cls[s] = c;
+        }
+        // 2-D launch on this path: blockIdx.y = row, waves stride along it; all index arithmetic in 32 bits (a 64-bit
+        // divide per pixel cost more than the whole cascade), x / r through a float reciprocal (exact: (x + 0.5) / r is
+        // never within 1/(2r) of an integer).
+        const int y = blockIdx.y;
+        const float *rowp[DFE_MAX_RATIOS];
+        float rinv[DFE_MAX_RATIOS];
+        for (int s = 0; s < g.nratios; ++s) {
+            const int r = g.ratios[s];
+            rowp[s] = g.in[s] + (long long)(y / r) * (g.W / r) * N;
+            rinv[s] = 1.0f / (float)r;
+        }
+        const int chh = (g.maxh + 1) / 2, chw = (g.maxw + 1) / 2;
+        for (int x = blockIdx.x * kWaves + w; x < g.W; x += gridDim.x * kWaves) {
+            float bv = -INFINITY, centre = 0.f, pv = 0.f;
+            int bi = 0x7fffffff;
+            for (int s = g.nratios - 1; s >= 0; --s) {
+                const int xs = (int)(((float)x + 0.5f) * rinv[s]);
+                float v = lane < N ? rowp[s][xs * N + lane] : 0.f;
+                if (s < g.nratios - 1) v += __shfl(pv, gsrc[s]);
+                pv = v;
+                const int c = cls[s];
+                if (c >= 0) {
+                    if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
+                    if (c == middle - 1) centre = v;
+                }
+            }
+            // wave arg-max on the VALU (DPP / lane swaps, no LDS crossbar): maximum value, then the smallest class among
+            // the lanes that hold it; the centre class sits in a known lane of scale 1
+            centre = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), (middle - 1) & 63));
+            const float wmax = wave_max_f32(bv);
+            bi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
+            bv = wmax;
+            if (lane == 0) {
+                int id = bi + 1;
+                if (middle > 0 && bv == centre) id = middle;
+                const long long p = (long long)y * g.W + x;
+                if (idx) idx[p] = id;
+                if (best_out) best_out[p] = bv;
+                if (fy) {
+                    // x2yxMultiNumber (opticalflow_model_multiscale.lua:83-132) in 32-bit arithmetic: scale and cell of the class
+                    int sc = 0, ty, tx, rem = id - 1;
+                    if (rem < N) { ty = rem / g.maxw + 1; tx = rem - (ty - 1) * g.maxw + 1; }
+                    else {
+                        sc = g.nratios - 1;
+                        while (sc > 1 && rem < g.base[sc]) --sc;
+                        rem -= g.base[sc];
+                        const int d = g.d[sc], mh = g.maxh, mw = g.maxw, side = (mh - 2 * d) * d;
+                        if (rem < d * mw) { ty = rem / mw + 1; tx = rem - (ty - 1) * mw + 1; }
+                        else if (rem < d * mw + side) { rem -= d * mw; ty = rem / d + 1 + d; tx = rem - (ty - 1 - d) * d + 1; }
+                        else if (rem < d * mw + 2 * side) { rem -= d * mw + side; ty = rem / d + 1 + d; tx = rem - (ty - 1 - d) * d + 1 + mw - d; }
+                        else { rem -= d * mw + 2 * side; ty = rem / mw + 1 + mh - d; tx = rem - (ty - 1 - (mh - d)) * mw + 1; }
+                    }
+                    const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
+                    fy[fo] = (float)((ty - chh) * g.ratios[sc]);
+                    fx[fo] = (float)((tx - chw) * g.ratios[sc]);
+                }
+            }
+        }
+        return;
+    }
     for (long long p = (long long)blockIdx.x * kWaves + w; p < P; p += (long long)gridDim.x * kWaves) {
         const int y = (int)(p / g.W), x = (int)(p - (long long)y * g.W);
         float bv = -INFINITY;
@@ -367,7 +474,9 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;
     size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_flow_f32: window %dx%d too large", maxh, maxw);
-    hipLaunchKernelGGL(cascade_argmax_kernel, dim3(grid1d((long long)H * W, kWaves)), dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
+    dim3 grid(grid1d((long long)H * W, kWaves));
+    if (maxh * maxw <= 64) grid = dim3((unsigned)((W + kWaves * 4 - 1) / (kWaves * 4)), (unsigned)H);   // fast path: one row per blockIdx.y
+    hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
                        (long long *)idx, best, flow_y, flow_x, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
