@@ -43,6 +43,32 @@ __global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int
     }
 }
 
+// ---- down-sample by r (same arithmetic as downsample_box_kernel) and zero-pad, both frames, one launch ----
+__global__ void prep_scale_kernel(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl, int pt,
+                                  int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
+#pragma clang fp contract(off)
+    const int Hs = H / r, Ws = W / r;
+    const long long total = (long long)C * Hp * Wp;
+    const float inv = 1.0f / (float)(r * r);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * total; e += (long long)gridDim.x * blockDim.x) {
+        const bool second = e >= total;
+        const long long ee = second ? e - total : e;
+        const float *img = second ? I1 : I0;
+        const int x = (int)(ee % Wp);
+        const long long t = ee / Wp;
+        const int y = (int)(t % Hp), c = (int)(t / Hp);
+        const int sy = y - pt, sx = x - pl;
+        float v = 0.f;
+        if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
+            float s = 0.f;
+            for (int i = 0; i < r; ++i)
+                for (int j = 0; j < r; ++j) s = s + img[((long long)c * H + sy * r + i) * W + sx * r + j];
+            v = r > 1 ? s * inv : s;
+        }
+        (second ? p1 : p0)[ee] = v;
+    }
+}
+
 // ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
 __global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__restrict__ cost, long long P, int N,
                                                              float *__restrict__ prob) {
@@ -417,6 +443,63 @@ int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     DFE_LAUNCH_CHECK(ctx);
     // frame-0 crop floor/ceil((maxw-1)/2) (:198-202) is the oy/ox offset of the cost-volume op
     return cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, kh, kw, maxh, maxw, out);
+}
+
+int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                 const int *ratios, int nratios, float *flow, int64_t *idx) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_REQUIRE(ctx, I0 && I1 && (flow || idx), DFE_E_ARG, "dfe_multiscale_flow_pair_f32: NULL tensor");
+    DFE_REQUIRE(ctx, C > 0 && k > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_f32: bad size");
+    CascadeGeom g;
+    int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
+    if (rc) return rc;
+    const int N = maxh * maxw;
+    const int hp = maxh - 1 + k - 1, wp = maxw - 1 + k - 1;   // hPatch2-1 (opticalflow_model_multiscale.lua:136-141)
+    const int pt = hp / 2, pl = wp / 2;
+    size_t off_p[DFE_MAX_RATIOS], off_v[DFE_MAX_RATIOS], off_q[DFE_MAX_RATIOS], total = 0;
+    for (int s = 0; s < nratios; ++s) {
+        const int r = ratios[s];
+        DFE_REQUIRE(ctx, H % r == 0 && W % r == 0, DFE_E_SHAPE,
+                    "dfe_multiscale_flow_pair_f32: frame %dx%d is not a multiple of ratio %d (opticalflow_model_multiscale.lua:238-243)", H, W, r);
+        const size_t np = (size_t)C * (H / r + hp) * (W / r + wp), nv = (size_t)(H / r) * (W / r) * N;
+        off_p[s] = total; total += (2 * np * sizeof(float) + 255) / 256 * 256;
+        off_v[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
+        off_q[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
+    }
+    // the per-scale cost volumes below use the same arena for their own temporaries only through cv_frames_dispatch, which
+    // needs none; one allocation up front keeps every stage's buffers alive until the cascade has read them
+    void *scr = nullptr;
+    rc = dfe_scratch(ctx, total, &scr);
+    if (rc) return rc;
+    MultiGeom mg;
+    mg.maxh = maxh; mg.maxw = maxw; mg.nratios = nratios;
+    for (int s = 0; s < nratios; ++s) {
+        const int r = ratios[s], Hs = H / r, Ws = W / r, Hp = Hs + hp, Wp = Ws + wp;
+        float *p0 = (float *)((char *)scr + off_p[s]), *p1 = p0 + (size_t)C * Hp * Wp;
+        float *vol = (float *)((char *)scr + off_v[s]), *prob = (float *)((char *)scr + off_q[s]);
+        hipLaunchKernelGGL(prep_scale_kernel, dim3(grid1d(2ll * C * Hp * Wp, 256)), dim3(256), 0, ctx->stream, I0, I1, C, H, W, r, pl, pt, Hp,
+                           Wp, p0, p1);
+        DFE_LAUNCH_CHECK(ctx);
+        rc = cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, k, k, maxh, maxw, vol);
+        if (rc) return rc;
+        const long long P = (long long)Hs * Ws;
+        hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), 0, ctx->stream, vol, P, N, prob);
+        DFE_LAUNCH_CHECK(ctx);
+        g.in[s] = prob;
+        g.out_scale[s] = nullptr;
+        mg.ratios[s] = r;
+        mg.d[s] = g.d[s];
+    }
+    g.H = H; g.W = W;
+    const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
+    size_t lds = (size_t)kWaves * 2 * N * sizeof(float);
+    DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
+    dim3 grid(grid1d((long long)H * W, kWaves));
+    if (N <= 64) grid = dim3((unsigned)((W + kWaves * 4 - 1) / (kWaves * 4)), (unsigned)H);
+    hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
+                       flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
 }
 
 int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {

@@ -121,7 +121,7 @@ class MultiscaleModel(Module):
         return out
 
 
-    def forwardFlow(self, input, process_full=True):
+    def forwardFlow(self, input, process_full=True, one_call=True):
         """model:forward(input) followed by processOutput(geometry, output, process_full) for the 'max' extraction
         without a threshold (opticalflow_model.lua:201-252), fused: the H x W x nclasses tensor is never built
         (dfe_cascade_flow_f32).  Returns the same table: index, confidences (all 1), y, x [, full, full_confidences]."""
@@ -141,19 +141,26 @@ class MultiscaleModel(Module):
         ctx = get_ctx(i0)
         l = lib()
         N = maxh * maxw
-        self.volumes, self.probs = [], []
-        for r in self.ratios:
-            vol = torch.empty((H // r, W // r, maxh, maxw), dtype=torch.float32, device=i0.device)
-            ctx.check(l.dfe_pyramid_scale_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, r, kh, kw, maxh, maxw, ptr(vol)))
-            prob = torch.empty_like(vol)
-            ctx.check(l.dfe_softmin_f32(ctx.handle, ptr(vol), vol.numel() // N, N, ptr(prob)))
-            self.volumes.append(vol)
-            self.probs.append(prob)
         rr, n = ratios_array(self.ratios)
         idx = torch.empty((H, W), dtype=torch.int64, device=i0.device)
-        fy = torch.empty((H, W), dtype=torch.float32, device=i0.device)
-        fx = torch.empty_like(fy)
-        ctx.check(l.dfe_cascade_flow_f32(ctx.handle, _ptr_array(self.probs), rr, n, H, W, maxh, maxw, ptr(idx), None, ptr(fy), ptr(fx)))
+        if one_call and kh == kw:
+            # everything in one C call (dfe_multiscale_flow_pair_f32): no per-scale tensors on the host side
+            flow = torch.empty((2, H, W), dtype=torch.float32, device=i0.device)
+            ctx.check(l.dfe_multiscale_flow_pair_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, kh, maxh, maxw, rr, n, ptr(flow), ptr(idx)))
+            fy, fx = flow[0], flow[1]
+            self.volumes, self.probs = None, None
+        else:
+            self.volumes, self.probs = [], []
+            for r in self.ratios:
+                vol = torch.empty((H // r, W // r, maxh, maxw), dtype=torch.float32, device=i0.device)
+                ctx.check(l.dfe_pyramid_scale_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, r, kh, kw, maxh, maxw, ptr(vol)))
+                prob = torch.empty_like(vol)
+                ctx.check(l.dfe_softmin_f32(ctx.handle, ptr(vol), vol.numel() // N, N, ptr(prob)))
+                self.volumes.append(vol)
+                self.probs.append(prob)
+            fy = torch.empty((H, W), dtype=torch.float32, device=i0.device)
+            fx = torch.empty_like(fy)
+            ctx.check(l.dfe_cascade_flow_f32(ctx.handle, _ptr_array(self.probs), rr, n, H, W, maxh, maxw, ptr(idx), None, ptr(fy), ptr(fx)))
         ret = {"index": idx, "confidences": torch.ones((H, W), dtype=torch.float32, device=i0.device),
                "y": fy.to(torch.int64), "x": fx.to(torch.int64)}
         if process_full:

@@ -209,6 +209,15 @@ int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratio
 int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W,
                          int maxh, int maxw, int64_t *idx, float *best, float *flow_y, float *flow_x);
 
+/* ---- A2..A6 + A10 in one call: the multiscale matcher of a frame pair ------------------------------ */
+/* replaces: getModelMultiscale(geometry, true, false):forward({I0, I1}) + processOutput ('max', no threshold) for
+ *   the identity patch filter -- opticalflow_model_multiscale.lua:175-333, opticalflow_model.lua:201-226.
+ *   I0, I1 [C][H][W] with H, W multiples of every ratio (the caller pads, :234-248).  Per scale: box down-sample,
+ *   zero-pad, k x k raw-patch SSD over a maxh x maxw window, softmin; then the fused cascade / ring / arg-max /
+ *   decode.  flow [2][H][W] (plane 0 = y, 1 = x, finest-scale pixels) and / or idx [H][W] (1-based class id). */
+int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k,
+                                 int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
+
 /* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
 /* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
  *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];

@@ -211,9 +211,18 @@ def test_multiscale_model_forward_flow_equals_forward_plus_process_output(dfe, c
     f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
     model = dfe.getModelMultiscale(geo)
     ret = dfe.processOutput(geo, model.forward([T(f0, cuda), T(f1, cuda)]), True)
-    fused = model.forwardFlow([T(f0, cuda), T(f1, cuda)], True)
-    for k in ("index", "y", "x", "full", "full_confidences"):
-        assert torch.equal(ret[k].to(fused[k].dtype), fused[k]), k
+    for one_call in (False, True):   # staged C calls with host-side tensors / everything inside dfe_multiscale_flow_pair_f32
+        fused = model.forwardFlow([T(f0, cuda), T(f1, cuda)], True, one_call=one_call)
+        for k in ("index", "y", "x", "full", "full_confidences"):
+            assert torch.equal(ret[k].to(fused[k].dtype), fused[k]), (k, one_call)
+    # a frame that needs the pad-to-multiple wrapper, and two scales only
+    geo2 = dict(maxh=8, maxw=8, ratios=[1, 2], multiscale=True, hKernel=7, wKernel=7, hImg=51, wImg=71, output_extraction_method="max")
+    g0, g1, _, _ = rp.synth_pair(51, 71, C=3, seed=6, max_flow=5, noise_sigma=0)
+    g0, g1 = g0 / np.float32(64), g1 / np.float32(64)
+    m2 = dfe.getModelMultiscale(geo2)
+    a = m2.forwardFlow([T(g0, cuda), T(g1, cuda)], False, one_call=False)
+    b = m2.forwardFlow([T(g0, cuda), T(g1, cuda)], False, one_call=True)
+    assert tuple(a["index"].shape) == (52, 72) and torch.equal(a["index"], b["index"]) and torch.equal(a["y"], b["y"]) and torch.equal(a["x"], b["x"])
 
 
 def test_multiscale_model_pads_to_a_multiple_of_the_coarsest_ratio(dfe, cuda):

@@ -32,6 +32,15 @@ for _ in range(n):
     ret2 = model.forwardFlow([t0, t1], True)
 torch.cuda.synchronize()
 f = time.perf_counter()
-print("fused forwardFlow %.3f ms -> %.1f Mpixels/s" % ((f - e) / n * 1e3, H * W / ((f - e) / n) / 1e6))
+print("forwardFlow (one C call) %.3f ms -> %.1f Mpixels/s" % ((f - e) / n * 1e3, H * W / ((f - e) / n) / 1e6))
+for _ in range(5):
+    ret3 = model.forwardFlow([t0, t1], True, one_call=False)
+torch.cuda.synchronize()
+e = time.perf_counter()
+for _ in range(n):
+    ret3 = model.forwardFlow([t0, t1], True, one_call=False)
+torch.cuda.synchronize()
+f = time.perf_counter()
+print("forwardFlow (staged) %.3f ms -> %.1f Mpixels/s" % ((f - e) / n * 1e3, H * W / ((f - e) / n) / 1e6))
 print("multiscale forward %.3f ms, processOutput %.3f ms -> %.1f Mpixels/s (host-driven, includes per-call allocation)" %
       ((b - a) / n * 1e3, (c - b) / n * 1e3, H * W / ((c - a) / n) / 1e6))
