@@ -69,10 +69,67 @@ __global__ void prep_scale_kernel(const float *__restrict__ I0, const float *__r
     }
 }
 
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
+#undef DFE_STEP
+    const int b = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = fmaxf(__int_as_float((int)r[0]), __int_as_float((int)r[1]));
+    const int c = __float_as_int(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#define DFE_STEP(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false))
+    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);
+#undef DFE_STEP
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min((int)r[0], (int)r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min((int)q[0], (int)q[1]);
+}
+
+// wave sum in the association order of `for (off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off)` -- partners at
+// distance 32, 16, 8, 4, 2, 1 -- on the VALU only (lane swaps + DPP), bit-identical to the shuffle version: after the
+// distance-8 step lanes L and L^8 hold equal values, so row_ror:4 (partner (L+4) mod 16) reads the same number as L^4
+__device__ __forceinline__ float wave_sum_f32_ordered(float v) {
+    int b = __float_as_int(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    v = __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
+    b = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+#define DFE_STEP(ctrl) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);   // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
+#undef DFE_STEP
+    return v;
+}
+
 // ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
 __global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__restrict__ cost, long long P, int N,
                                                              float *__restrict__ prob) {
     const int lane = threadIdx.x & 63;
+    if (N <= 64) {
+        // one cell per lane: NPX pixels per step, all loads issued before the first is used, reductions on the VALU (the
+        // shuffle version is LDS-crossbar- and latency-bound: 62 us for the 157 MB of the VGA scale-1 volume)
+        constexpr int NPX = 8;
+        const bool on = lane < N;
+        for (long long p0 = ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * NPX; p0 < P; p0 += (long long)gridDim.x * kWaves * NPX) {
+            float c[NPX];
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) c[i] = (on && p0 + i < P) ? cost[(p0 + i) * N + lane] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                if (p0 + i >= P) break;                                   // wave-uniform
+                const float m = wave_max_f32(on ? -c[i] : -INFINITY);
+                const float e = on ? expf(-c[i] - m) : 0.f;
+                const float sum = wave_sum_f32_ordered(e);
+                if (on) prob[(p0 + i) * N + lane] = e * (1.0f / sum);
+            }
+        }
+        return;
+    }
     for (long long p = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6); p < P; p += (long long)gridDim.x * kWaves) {
         const float *c = cost + p * N;
         float *o = prob + p * N;
@@ -194,27 +251,6 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGe
     }
 }
 
-__device__ __forceinline__ float wave_max_f32(float v) {
-#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
-    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
-#undef DFE_STEP
-    const int b = __float_as_int(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-    v = fmaxf(__int_as_float((int)r[0]), __int_as_float((int)r[1]));
-    const int c = __float_as_int(v);
-    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-    return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
-}
-__device__ __forceinline__ int wave_min_i32(int v) {
-#define DFE_STEP(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false))
-    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);
-#undef DFE_STEP
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = min((int)r[0], (int)r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return min((int)q[0], (int)q[1]);
-}
-
 // A4 + A5 + A6 + A10 in one pass: cascade coarse -> fine exactly like cascade_kernel<true>, but instead of writing the
 // joined [H][W][ncls] tensor the wave keeps the running arg-max over the classes it would have written (first maximum
 // wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float *cur = sh + (size_t)w * 2 * N, *prev = cur + N;
     const long long P = (long long)g.H * g.W;
-    if (N <= 64) {
+    if (N <= 64 && g.nratios <= 5) {
         // One cell per lane: everything that depends on the cell only -- where it reads the coarser window (crop +
         // replicate) and which class it is in the joined vector -- is worked out once per wave; per pixel and scale
         // remain one coalesced load, one cross-lane read of the coarser result (no LDS buffer, no barrier), one add and
@@ -254,61 +290,71 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
             }
             cls[s] = c;
         }
-        // 2-D launch on this path: blockIdx.y = row, waves stride along it; all index arithmetic in 32 bits (a 64-bit
-        // divide per pixel cost more than the whole cascade), x / r through a float reciprocal (exact: (x + 0.5) / r is
-        // never within 1/(2r) of an integer).
+        // 2-D launch on this path: blockIdx.y = row, a wave takes NPX adjacent pixels per step and issues all of their
+        // loads before it touches any (one pixel at a time the kernel was bound by load latency: 154 us at VGA); all
+        // index arithmetic in 32 bits (a 64-bit divide per pixel cost more than the whole cascade), x / r through a float
+        // reciprocal (exact: (x + 0.5) / r is never within 1/(2r) of an integer); class -> displacement from a table
+        // built once per block instead of divisions per pixel.
+        constexpr int NPX = 4, MAXS = 5;
+        int2 *tab = reinterpret_cast<int2 *>(sh);             // [ncls] (oy, ox); the cur/prev buffers are not used on this path
+        for (int c = threadIdx.x; c < g.ncls; c += blockDim.x) {
+            long long oy = 0, ox = 0;
+            multi_decode(mg, c + 1, &oy, &ox);
+            tab[c] = make_int2((int)oy, (int)ox);
+        }
+        __syncthreads();
         const int y = blockIdx.y;
-        const float *rowp[DFE_MAX_RATIOS];
-        float rinv[DFE_MAX_RATIOS];
-        for (int s = 0; s < g.nratios; ++s) {
-            const int r = g.ratios[s];
-            rowp[s] = g.in[s] + (long long)(y / r) * (g.W / r) * N;
+        const float *rowp[MAXS];
+        float rinv[MAXS];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            const int r = s < g.nratios ? g.ratios[s] : 1;
+            rowp[s] = g.in[s < g.nratios ? s : 0] + (long long)(y / r) * (g.W / r) * N;
             rinv[s] = 1.0f / (float)r;
         }
-        const int chh = (g.maxh + 1) / 2, chw = (g.maxw + 1) / 2;
-        for (int x = blockIdx.x * kWaves + w; x < g.W; x += gridDim.x * kWaves) {
-            float bv = -INFINITY, centre = 0.f, pv = 0.f;
-            int bi = 0x7fffffff;
-            for (int s = g.nratios - 1; s >= 0; --s) {
-                const int xs = (int)(((float)x + 0.5f) * rinv[s]);
-                float v = lane < N ? rowp[s][xs * N + lane] : 0.f;
-                if (s < g.nratios - 1) v += __shfl(pv, gsrc[s]);
-                pv = v;
-                const int c = cls[s];
-                if (c >= 0) {
-                    if (v > bv || (v == bv && c < bi)) { bv = v; bi = c; }
-                    if (c == middle - 1) centre = v;
+        for (int x0 = (blockIdx.x * kWaves + w) * NPX; x0 < g.W; x0 += gridDim.x * kWaves * NPX) {
+            float vin[NPX][MAXS];
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int x = min(x0 + i, g.W - 1);
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s) {
+                    const int xs = (int)(((float)x + 0.5f) * rinv[s]);
+                    vin[i][s] = (s < g.nratios && lane < N) ? rowp[s][xs * N + lane] : 0.f;
                 }
             }
-            // wave arg-max on the VALU (DPP / lane swaps, no LDS crossbar): maximum value, then the smallest class among
-            // the lanes that hold it; the centre class sits in a known lane of scale 1
-            centre = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), (middle - 1) & 63));
-            const float wmax = wave_max_f32(bv);
-            bi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
-            bv = wmax;
-            if (lane == 0) {
-                int id = bi + 1;
-                if (middle > 0 && bv == centre) id = middle;
-                const long long p = (long long)y * g.W + x;
-                if (idx) idx[p] = id;
-                if (best_out) best_out[p] = bv;
-                if (fy) {
-                    // x2yxMultiNumber (opticalflow_model_multiscale.lua:83-132) in 32-bit arithmetic: scale and cell of the class
-                    int sc = 0, ty, tx, rem = id - 1;
-                    if (rem < N) { ty = rem / g.maxw + 1; tx = rem - (ty - 1) * g.maxw + 1; }
-                    else {
-                        sc = g.nratios - 1;
-                        while (sc > 1 && rem < g.base[sc]) --sc;
-                        rem -= g.base[sc];
-                        const int d = g.d[sc], mh = g.maxh, mw = g.maxw, side = (mh - 2 * d) * d;
-                        if (rem < d * mw) { ty = rem / mw + 1; tx = rem - (ty - 1) * mw + 1; }
-                        else if (rem < d * mw + side) { rem -= d * mw; ty = rem / d + 1 + d; tx = rem - (ty - 1 - d) * d + 1; }
-                        else if (rem < d * mw + 2 * side) { rem -= d * mw + side; ty = rem / d + 1 + d; tx = rem - (ty - 1 - d) * d + 1 + mw - d; }
-                        else { rem -= d * mw + 2 * side; ty = rem / mw + 1 + mh - d; tx = rem - (ty - 1 - (mh - d)) * mw + 1; }
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) {
+                const int x = x0 + i;
+                if (x >= g.W) break;                              // wave-uniform
+                float bv = -INFINITY, pv = 0.f;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int s = MAXS - 1; s >= 0; --s) {
+                    if (s >= g.nratios) continue;
+                    float v = vin[i][s];
+                    if (s < g.nratios - 1) v += __shfl(pv, gsrc[s]);
+                    pv = v;
+                    const int c = cls[s];
+                    if (c >= 0 && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
+                }
+                // wave arg-max on the VALU (DPP / lane swaps, no LDS crossbar): maximum value, then the smallest class
+                // among the lanes that hold it; the centre class sits in a known lane of scale 1
+                const float centre = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), (middle - 1) & 63));
+                const float wmax = wave_max_f32(bv);
+                bi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
+                if (lane == 0) {
+                    int id = bi + 1;
+                    if (middle > 0 && wmax == centre) id = middle;
+                    const long long p = (long long)y * g.W + x;
+                    if (idx) idx[p] = id;
+                    if (best_out) best_out[p] = wmax;
+                    if (fy) {
+                        const int2 t = tab[id - 1];
+                        const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
+                        fy[fo] = (float)t.x;
+                        fx[fo] = (float)t.y;
                     }
-                    const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
-                    fy[fo] = (float)((ty - chh) * g.ratios[sc]);
-                    fx[fo] = (float)((tx - chw) * g.ratios[sc]);
                 }
             }
         }
@@ -483,7 +529,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         rc = cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, k, k, maxh, maxw, vol);
         if (rc) return rc;
         const long long P = (long long)Hs * Ws;
-        hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), 0, ctx->stream, vol, P, N, prob);
+        hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves * (N <= 64 ? 8 : 1))), dim3(kWaves * 64), 0, ctx->stream, vol, P, N, prob);
         DFE_LAUNCH_CHECK(ctx);
         g.in[s] = prob;
         g.out_scale[s] = nullptr;
@@ -494,8 +540,9 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
     size_t lds = (size_t)kWaves * 2 * N * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
+    if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);
     dim3 grid(grid1d((long long)H * W, kWaves));
-    if (N <= 64) grid = dim3((unsigned)((W + kWaves * 4 - 1) / (kWaves * 4)), (unsigned)H);
+    if (N <= 64 && nratios <= 5) grid = dim3((unsigned)((W + kWaves * 16 - 1) / (kWaves * 16)), (unsigned)H);
     hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
                        flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
@@ -507,7 +554,7 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
     DFE_REQUIRE(ctx, P >= 0 && N > 0, DFE_E_SHAPE, "dfe_softmin_f32: P=%lld N=%d", (long long)P, N);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, cost && prob, DFE_E_ARG, "dfe_softmin_f32: NULL tensor");
-    hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves)), dim3(kWaves * 64), 0, ctx->stream, cost, (long long)P, N, prob);
+    hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves * (N <= 64 ? 8 : 1))), dim3(kWaves * 64), 0, ctx->stream, cost, (long long)P, N, prob);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }
@@ -557,8 +604,9 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;
     size_t lds = (size_t)kWaves * 2 * maxh * maxw * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_flow_f32: window %dx%d too large", maxh, maxw);
+    if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);   // fast path: class -> displacement table
     dim3 grid(grid1d((long long)H * W, kWaves));
-    if (maxh * maxw <= 64) grid = dim3((unsigned)((W + kWaves * 4 - 1) / (kWaves * 4)), (unsigned)H);   // fast path: one row per blockIdx.y
+    if (maxh * maxw <= 64 && nratios <= 5) grid = dim3((unsigned)((W + kWaves * 16 - 1) / (kWaves * 16)), (unsigned)H);   // fast path: one row per blockIdx.y
     hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
                        (long long *)idx, best, flow_y, flow_x, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
