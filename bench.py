@@ -31,6 +31,13 @@ WORKLOADS = {
     "720p": (720, 1280, 3, 7, 33, 33),
     "1080p": (1080, 1920, 3, 7, 33, 33),
 }
+# BASELINE.json configs[1] literally: 640x480, 3-level pyramid {1,2,4}, 7x7 patch, 8x8 window per scale (= +-16 at the
+# coarsest scale), through dfe_multiscale_flow_pair_f32.  Not the default: the north-star roofline target is stated for
+# the single-scale cost-volume build, which is what `vga` measures.
+PYRAMIDS = {
+    "vga-pyramid": (480, 640, 3, 7, 8, 8, (1, 2, 4)),
+    "1080p-pyramid": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -90,12 +97,70 @@ def cpu_baseline(f0, f1, k, hWin, wWin, cx, cy, budget_s=12.0):
     return out
 
 
+def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
+    """Multiscale workload: step = dfe_multiscale_flow_pair_f32 on one pair per GPU (per scale: down-sample + pad, raw-patch
+    SSD volume, softmin; then the fused cascade / ring / arg-max / decode).  Several small kernels, so `roofline` prices
+    the WHOLE step against the algorithmic bytes of SURVEY 8(d) (frames read once + every scale's native volume once)."""
+    H, W, Cc, k, maxh, maxw, ratios = PYRAMIDS[args.workload]
+    rmax = ratios[-1]
+    Hp, Wp = -(-H // rmax) * rmax, -(-W // rmax) * rmax            # the reference pads to a multiple of the coarsest ratio
+    f0, f1, _, _ = rp.synth_pair(H, W, C=Cc, seed=rank, max_flow=12)
+    import numpy as np
+    p0, p1 = np.zeros((Cc, Hp, Wp), np.float32), np.zeros((Cc, Hp, Wp), np.float32)
+    p0[:, :H, :W], p1[:, :H, :W] = f0 / 64.0, f1 / 64.0
+    t0, t1 = torch.from_numpy(p0).to(dev), torch.from_numpy(p1).to(dev)
+    flow = torch.empty((2, Hp, Wp), device=dev)
+    ctx = d.get_ctx(local_rank)
+    lib = d.lib()
+    rr = (C.c_int32 * len(ratios))(*ratios)
+
+    def step():
+        ctx.check(lib.dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, k, maxh, maxw, rr, len(ratios),
+                                                  flow.data_ptr(), None))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        balg = 2 * Cc * Hp * Wp * 4 + sum((Hp // r) * (Wp // r) * maxh * maxw * 4 for r in ratios)
+        step_s = elapsed / args.steps
+        print(json.dumps({
+            "metric": "Mpixels/s dense flow, %dx%d pair, %d-level pyramid, 7x7 patch, %dx%d window per scale" % (W, H, len(ratios), maxh, maxw),
+            "value": round(world * args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, 7x7 raw-patch SSD over %dx%d, "
+                                   "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (W, H, Cc, list(ratios), maxh, maxw),
+                       "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "whole step (10 launches)", "achieved": round(balg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(balg / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": balg},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)   # clocks ramp up over the first few ms of work
-    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,6 +183,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload in PYRAMIDS:
+        return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
     H, W, Cc, k, hWin, wWin = WORKLOADS[args.workload]
     f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=rank, max_flow=12)  # one seeded pair per rank
     t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
