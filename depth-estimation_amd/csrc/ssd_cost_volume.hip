@@ -228,7 +228,9 @@ __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int l
     if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
         // the pixel's first cells, for extractOutput: cell-major planes, so a lane's 8 columns are 32 contiguous
         // bytes (2 stores per row instead of 8) and finalize reads them coalesced
-        f4u_t *lp4 = reinterpret_cast<f4u_t *>(fa.lead + (long long)lane * fa.Ptot + pg0);
+        int ll = lane;
+        asm volatile("" : "+v"(ll));   // the plane address is rebuilt per row: hoisted, it gets spilled, and a scratch reload waits for every store in flight
+        f4u_t *lp4 = reinterpret_cast<f4u_t *>(fa.lead + (long long)ll * fa.Ptot + pg0);
         lp4[0] = f4_t{vrow[0], vrow[1], vrow[2], vrow[3]};
         lp4[1] = f4_t{vrow[4], vrow[5], vrow[6], vrow[7]};
     }
@@ -870,7 +872,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
                     for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
                 }
-                if (store_row && validm) st[xm * D + dm] = v;
+                if (store_row && validm) {
+                    int lm = lane;
+                    asm volatile("" : "+v"(lm));   // (same reason: keep this address out of the spill slots)
+                    st[(lm & 7) * D + 1088 + (lm >> 3)] = v;
+                }
             }
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
@@ -917,13 +923,16 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         int cv[CPL];
 #pragma unroll
                         for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);   // all reads in flight
-                        int best = 0x7f800000, bi = 0;
 #pragma unroll
-                        for (int i = 0; i < CPL; ++i) {
-                            const bool lt = c0 + i < D && cv[i] < best;
-                            best = lt ? cv[i] : best;
-                            bi = lt ? i : bi;
-                        }
+                        for (int i = 0; i < CPL; ++i) cv[i] = c0 + i < D ? cv[i] : 0x7f800000;
+                        // shallow dependency chains (every wave of the block is in this phase at once, nothing else hides
+                        // latency): the lane minimum as a tree of 3-input minima, its first position independently of
+                        // the wave reduction that follows
+                        static_assert(CPL == 9, "min tree below is written for 9 cells");
+                        const int best = min(min(min(cv[0], cv[1]), min(cv[2], cv[3])), min(min(min(cv[4], cv[5]), min(cv[6], cv[7])), cv[8]));
+                        int bi = CPL - 1;
+#pragma unroll
+                        for (int i = CPL - 2; i >= 0; --i) bi = cv[i] == best ? i : bi;
                         const int vmin = wave_min1(best);
                         const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
                         const int bif = __builtin_amdgcn_readlane(bi, f);
