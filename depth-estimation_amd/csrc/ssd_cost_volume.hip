@@ -948,10 +948,19 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     const float *gb = out + G0 + head;
                     int tj = tid;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
-                    for (int j = tj; j < nbody4; j += (SWEEP ? LW : NW) * 64) {
-                        const f4_t val = sb[j];
-                        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)j * 16u), "v"(val), "s"(gb) : "memory");
-                    }
+                    // at most 3 pieces per thread (TX*D/4 <= 2192 float4 over >= 960 threads): all LDS reads first, then the
+                    // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
+                    // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
+                    // these (scan arithmetic after the stores: +3 %; before them: no change).
+                    constexpr int STR = (SWEEP ? LW : NW) * 64;
+                    static_assert(3 * 15 * 64 >= TX * 1096 / 4, "three pieces per thread cover the run");
+                    f4_t val[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (tj + i * STR < nbody4)
+                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = head + (nbody4 << 2), ntail = RUN - tail0;
                         if (wave == 5 && lane < head) out[G0 + lane] = st[lane];
