@@ -65,6 +65,8 @@ PROTOTYPES = {
     "dfe_pyramid_scale_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "dfe_softmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dfe_cascading_add_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dfe_spatial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_radial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_cascade_flow_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfe_multiscale_flow_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_cascading_add_backward_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -50,6 +50,24 @@ class SpatialMatching(Module):
         self.output = out
         return out
 
+    def updateGradInput(self, input, gradOutput):
+        """Gradient w.r.t. both feature maps (nnx's updateGradInput; reached from the training drivers through
+        model:backward).  Returns [gradIn1, gradIn2]."""
+        in1, in2 = input
+        in1, in2 = _f32c(in1, "input[1]"), _f32c(in2, "input[2]")
+        go = _f32c(gradOutput, "gradOutput")
+        K, H1, W1 = in1.shape
+        if tuple(go.shape) != (H1, W1, self.maxh, self.maxw):
+            raise ValueError("SpatialMatching: gradOutput must be %s, got %s" % ((H1, W1, self.maxh, self.maxw), tuple(go.shape)))
+        ctx = get_ctx(in1)
+        g1, g2 = torch.empty_like(in1), torch.empty_like(in2)
+        ctx.check(lib().dfe_spatial_matching_backward_f32(ctx.handle, ptr(in1), ptr(in2), ptr(go), K, H1, W1, self.maxh, self.maxw, ptr(g1), ptr(g2)))
+        self.gradInput = [g1, g2]
+        return self.gradInput
+
+    def backward(self, input, gradOutput, scale=1.0):
+        return self.updateGradInput(input, gradOutput)
+
 
 class SpatialRadialMatching(Module):
     """nn.SpatialRadialMatching(hWin) -- un-vendored nnx module.
@@ -71,6 +89,23 @@ class SpatialRadialMatching(Module):
         ctx.check(lib().dfe_radial_matching_f32(ctx.handle, ptr(in1), ptr(in2), K, H1, W, self.hWin, ptr(out)))
         self.output = out
         return out
+
+    def updateGradInput(self, input, gradOutput):
+        """Gradient w.r.t. both feature maps (radial/train_radial_opticalflow.lua:228-252 trains through it)."""
+        in1, in2 = input
+        in1, in2 = _f32c(in1, "input[1]"), _f32c(in2, "input[2]")
+        go = _f32c(gradOutput, "gradOutput")
+        K, H1, W = in1.shape
+        if tuple(go.shape) != (H1, W, self.hWin):
+            raise ValueError("SpatialRadialMatching: gradOutput must be %s, got %s" % ((H1, W, self.hWin), tuple(go.shape)))
+        ctx = get_ctx(in1)
+        g1, g2 = torch.empty_like(in1), torch.empty_like(in2)
+        ctx.check(lib().dfe_radial_matching_backward_f32(ctx.handle, ptr(in1), ptr(in2), ptr(go), K, H1, W, self.hWin, ptr(g1), ptr(g2)))
+        self.gradInput = [g1, g2]
+        return self.gradInput
+
+    def backward(self, input, gradOutput, scale=1.0):
+        return self.updateGradInput(input, gradOutput)
 
 
 class SSDCostVolume(Module):

@@ -99,6 +99,16 @@ int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, i
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
                             int W, int hWin, float *out);
 
+/* ---- N2: gradients of the two matchers (training drivers call model:backward through them) ------- */
+/* replaces: nn.SpatialMatching:updateGradInput / nn.SpatialRadialMatching:updateGradInput (un-vendored nnx), reached
+ *   from radial/train_radial_opticalflow.lua:228-252 and opticalflow.lua:296-338.  gradOut has the forward output's
+ *   layout; gradIn1 / gradIn2 the inputs'.  Gather form (no atomics): every input element sums its own terms in
+ *   (dy, dx) order. */
+int dfe_spatial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K,
+                                      int H1, int W1, int maxh, int maxw, float *gradIn1, float *gradIn2);
+int dfe_radial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K,
+                                     int H1, int W, int hWin, float *gradIn1, float *gradIn2);
+
 /* ---- A6: arg-min / arg-max with the centre tie-break ---------------------- */
 /* replaces: output:min(3) + centre override radial/radial_opticalflow_groundtruth.lua:88-94;
  *   input:max(3) + override in getOutputConfidences opticalflow_model.lua:153-161.

@@ -73,6 +73,61 @@ void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int
     (void)H2;
 }
 
+/* N2: gradients of A1 / A1r w.r.t. both feature maps (un-vendored nnx; nothing in the reference tests them -- pinned as
+ * the Jacobian of orc_spatial_matching / orc_radial_matching, the way tests/test_cascad.lua:22 pins the cascade).
+ * g1[k][y][x]  = sum_{dy,dx}  2 (in1[k][y][x] - in2[k][y+dy][x+dx]) go[y][x][dy][dx]
+ * g2[k][v][u]  = sum_{dy,dx} -2 (in1[k][v-dy][u-dx] - in2[k][v][u]) go[v-dy][u-dx][dy][dx]   over the (dy,dx) that keep
+ * (v-dy, u-dx) inside in1; float accumulation in (dy, dx) order. */
+void orc_spatial_matching_backward(const float *in1, const float *in2, const float *go, int K, int H1, int W1,
+                                   int maxh, int maxw, float *g1, float *g2) {
+    int H2 = H1 + maxh - 1, W2 = W1 + maxw - 1;
+    ORC_PAR_FOR
+    for (int k = 0; k < K; ++k) {
+        for (int y = 0; y < H1; ++y)
+            for (int x = 0; x < W1; ++x) {
+                float a = in1[((size_t)k * H1 + y) * W1 + x], s = 0.f;
+                for (int dy = 0; dy < maxh; ++dy)
+                    for (int dx = 0; dx < maxw; ++dx)
+                        s += 2.0f * (a - in2[((size_t)k * H2 + y + dy) * W2 + x + dx]) * go[(((size_t)y * W1 + x) * maxh + dy) * maxw + dx];
+                g1[((size_t)k * H1 + y) * W1 + x] = s;
+            }
+        for (int v = 0; v < H2; ++v)
+            for (int u = 0; u < W2; ++u) {
+                float b = in2[((size_t)k * H2 + v) * W2 + u], s = 0.f;
+                for (int dy = 0; dy < maxh; ++dy)
+                    for (int dx = 0; dx < maxw; ++dx) {
+                        int y = v - dy, x = u - dx;
+                        if (y < 0 || y >= H1 || x < 0 || x >= W1) continue;
+                        s += -2.0f * (in1[((size_t)k * H1 + y) * W1 + x] - b) * go[(((size_t)y * W1 + x) * maxh + dy) * maxw + dx];
+                    }
+                g2[((size_t)k * H2 + v) * W2 + u] = s;
+            }
+    }
+}
+void orc_radial_matching_backward(const float *in1, const float *in2, const float *go, int K, int H1, int W, int hWin,
+                                  float *g1, float *g2) {
+    int H2 = H1 + hWin - 1;
+    ORC_PAR_FOR
+    for (int k = 0; k < K; ++k) {
+        for (int y = 0; y < H1; ++y)
+            for (int x = 0; x < W; ++x) {
+                float a = in1[((size_t)k * H1 + y) * W + x], s = 0.f;
+                for (int d = 0; d < hWin; ++d) s += 2.0f * (a - in2[((size_t)k * H2 + y + d) * W + x]) * go[((size_t)y * W + x) * hWin + d];
+                g1[((size_t)k * H1 + y) * W + x] = s;
+            }
+        for (int v = 0; v < H2; ++v)
+            for (int x = 0; x < W; ++x) {
+                float b = in2[((size_t)k * H2 + v) * W + x], s = 0.f;
+                for (int d = 0; d < hWin; ++d) {
+                    int y = v - d;
+                    if (y < 0 || y >= H1) continue;
+                    s += -2.0f * (in1[((size_t)k * H1 + y) * W + x] - b) * go[((size_t)y * W + x) * hWin + d];
+                }
+                g2[((size_t)k * H2 + v) * W + x] = s;
+            }
+    }
+}
+
 void orc_ssd_cost_volume(const float *I0, const float *I1, int C, int H, int W,
                          int kh, int kw, int hWin, int wWin, float *out, int row0, int row1) {
     /* ref: radial/radial_opticalflow_groundtruth.lua:79-84.  Feature k=(c,i,j) of frame0 at

@@ -45,6 +45,13 @@ void orc_unfold(const float *img, int C, int H, int W, int kh, int kw, float *ou
 void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int W1,
                           int maxh, int maxw, float *out);
 
+/* N2: gradients of A1 and A1r w.r.t. in1 and in2 (go = gradOutput, layout of the forward output). Pinned as the Jacobian
+ * of the forward restatements (no reference test exists; method of tests/test_cascad.lua:22). */
+void orc_spatial_matching_backward(const float *in1, const float *in2, const float *go, int K, int H1, int W1,
+                                   int maxh, int maxw, float *g1, float *g2);
+void orc_radial_matching_backward(const float *in1, const float *in2, const float *go, int K, int H1, int W,
+                                  int hWin, float *g1, float *g2);
+
 /* A0+A1 fused on raw frames (never materialises the unfolded features):
  * unfold(kh,kw) -> crop frame0 features by floor/ceil((win-1)/2) -> SpatialMatching.
  * ref: radial/radial_opticalflow_groundtruth.lua:79-84.

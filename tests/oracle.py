@@ -49,6 +49,8 @@ def lib():
             "orc_softmin": (None, [f32p, C.c_int64, C.c_int, f32p]),
             "orc_cascade_ring": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_cascading_add": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+            "orc_spatial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
+            "orc_radial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
             "orc_cascading_add_backward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
             "orc_paste_center": (None, [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]),
             "orc_flow_to_depth_cartesian": (None, [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p, f32p]),
@@ -222,6 +224,22 @@ def cascading_add(ins, ratios, maxh, maxw):
     b = (C.c_void_p * len(ins))(*[p.ctypes.data for p in outs])
     rc = lib().orc_cascading_add(a, len(ins), r, P, maxh, maxw, b)
     return rc, outs
+
+
+def spatial_matching_backward(in1, in2, go, maxh, maxw):
+    in1, in2, go = _f(in1), _f(in2), _f(go)
+    K, H1, W1 = in1.shape
+    g1, g2 = np.empty_like(in1), np.empty_like(in2)
+    lib().orc_spatial_matching_backward(in1, in2, go, K, H1, W1, maxh, maxw, g1, g2)
+    return g1, g2
+
+
+def radial_matching_backward(in1, in2, go, hWin):
+    in1, in2, go = _f(in1), _f(in2), _f(go)
+    K, H1, W = in1.shape
+    g1, g2 = np.empty_like(in1), np.empty_like(in2)
+    lib().orc_radial_matching_backward(in1, in2, go, K, H1, W, hWin, g1, g2)
+    return g1, g2
 
 
 def cascading_add_backward(grad_outs, ratios, maxh, maxw):

@@ -452,6 +452,33 @@ def test_flow_depth_pair_matches_oracle(dfe, cuda, H, W, win, C, thr):
     assert torch.equal(flow2, flow)
 
 
+@pytest.mark.parametrize("K,H1,W1,mh,mw", [(3, 9, 11, 5, 4), (30, 20, 26, 7, 9), (1, 6, 70, 17, 17), (8, 33, 5, 1, 1)])
+def test_spatial_matching_backward_bit_exact(dfe, cuda, K, H1, W1, mh, mw):
+    """N2: nn.SpatialMatching:updateGradInput == oracle (integer-valued data: exact in any order; the kernels also use
+    the oracle's (dy, dx) accumulation order, checked on floats)."""
+    rng = np.random.default_rng(K + H1)
+    for integer in (True, False):
+        gen = (lambda s: rng.integers(-5, 6, s).astype(np.float32)) if integer else (lambda s: rng.standard_normal(s).astype(np.float32))
+        in1, in2 = gen((K, H1, W1)), gen((K, H1 + mh - 1, W1 + mw - 1))
+        go = gen((H1, W1, mh, mw))
+        e1, e2 = orc.spatial_matching_backward(in1, in2, go, mh, mw)
+        m = dfe.nn.SpatialMatching(mh, mw, False)
+        g1, g2 = m.backward([T(in1, cuda), T(in2, cuda)], T(go, cuda))
+        assert np.array_equal(g1.cpu().numpy(), e1) and np.array_equal(g2.cpu().numpy(), e2)
+
+
+def test_radial_matching_backward_bit_exact(dfe, cuda):
+    rng = np.random.default_rng(3)
+    K, H1, W, hW = 12, 25, 31, 12
+    in1, in2 = rng.standard_normal((K, H1, W)).astype(np.float32), rng.standard_normal((K, H1 + hW - 1, W)).astype(np.float32)
+    go = rng.standard_normal((H1, W, hW)).astype(np.float32)
+    e1, e2 = orc.radial_matching_backward(in1, in2, go, hW)
+    g1, g2 = dfe.nn.SpatialRadialMatching(hW).backward([T(in1, cuda), T(in2, cuda)], T(go, cuda))
+    assert np.array_equal(g1.cpu().numpy(), e1) and np.array_equal(g2.cpu().numpy(), e2)
+    with pytest.raises(ValueError, match="gradOutput"):
+        dfe.nn.SpatialRadialMatching(hW).backward([T(in1, cuda), T(in2, cuda)], T(go[:-1], cuda))
+
+
 # ------------------------------------------------------------------ full size (BASELINE configs[1]): properties
 def test_full_vga_cost_volume_properties(dfe, cuda):
     """640x480, C=3, 7x7 patch, 33x33 window: (a) tiled == row-image == reference-order kernel bitwise on integer

@@ -340,3 +340,38 @@ def test_flow_to_depth_ardrone_hand_vector():
     # out-of-range samples (the reference's unchecked histogram index) are skipped
     d3, _ = orc.flow_to_depth_ardrone(np.full((H, W), 40.0, np.float32), np.ones((H, W), np.float32), 1.0)
     assert np.all(d3[:, 0] == 100.0)
+
+
+def test_matcher_gradients_are_the_jacobian_of_the_forward():
+    """N2: orc_spatial_matching_backward / orc_radial_matching_backward against central differences of the forward
+    restatements (quadratic in the inputs, so the difference quotient is exact on small integers) -- the reference
+    holds no test for these un-vendored modules; method of tests/test_cascad.lua:22."""
+    rng = np.random.default_rng(11)
+    K, H1, W1, mh, mw = 3, 5, 6, 3, 4
+    in1 = rng.integers(-4, 5, (K, H1, W1)).astype(np.float32)
+    in2 = rng.integers(-4, 5, (K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    go = rng.integers(-3, 4, (H1, W1, mh, mw)).astype(np.float32)
+    g1, g2 = orc.spatial_matching_backward(in1, in2, go, mh, mw)
+    def loss(a, b):
+        return float((orc.spatial_matching(a, b, mh, mw).astype(np.float64) * go).sum())
+    for arr, g, which in ((in1, g1, 0), (in2, g2, 1)):
+        for idx in [(0, 0, 0), (1, 2, 3), (K - 1, arr.shape[1] - 1, arr.shape[2] - 1), (2, 1, 0)]:
+            p, m = arr.copy(), arr.copy()
+            p[idx] += 1.0
+            m[idx] -= 1.0
+            fd = (loss(p, in2) - loss(m, in2)) / 2.0 if which == 0 else (loss(in1, p) - loss(in1, m)) / 2.0
+            assert fd == float(g[idx]), (which, idx, fd, g[idx])
+    hW = 4
+    r1 = rng.integers(-4, 5, (K, H1, W1)).astype(np.float32)
+    r2 = rng.integers(-4, 5, (K, H1 + hW - 1, W1)).astype(np.float32)
+    rgo = rng.integers(-3, 4, (H1, W1, hW)).astype(np.float32)
+    h1, h2 = orc.radial_matching_backward(r1, r2, rgo, hW)
+    # the radial matcher is the 2-D one with a 1-column window
+    e1, e2 = orc.spatial_matching_backward(r1, r2, rgo.reshape(H1, W1, hW, 1), hW, 1)
+    assert np.array_equal(h1, e1) and np.array_equal(h2, e2)
+    def rloss(a, b):
+        return float((orc.radial_matching(a, b, hW).astype(np.float64) * rgo).sum())
+    p, m = r2.copy(), r2.copy()
+    p[1, 3, 2] += 1.0
+    m[1, 3, 2] -= 1.0
+    assert (rloss(r1, p) - rloss(r1, m)) / 2.0 == float(h2[1, 3, 2])
