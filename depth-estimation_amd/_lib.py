@@ -65,6 +65,9 @@ PROTOTYPES = {
     "dfe_pyramid_scale_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "dfe_softmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "dfe_cascading_add_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dfe_spatial_convolution_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dfe_spatial_convolution_map_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dfe_tanh_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "dfe_spatial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_radial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_cascade_flow_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,218 @@
+"""The learned patch-feature stack and the single-scale model of the reference (next-row N1):
+getFilter / getModel of opticalflow_model.lua:45-130 and getFilter of radial/radial_opticalflow_network.lua:6-30, with
+nn.SpatialConvolution / nn.SpatialConvolutionMap / nn.Tanh / nn.Sequential / nn.ParallelTable stand-ins that keep Torch7's
+module protocol (`modules` is a plain index-assignable list, as the callers patch it by index)."""
+import math
+
+import torch
+
+from ._lib import lib
+from .context import get_ctx, ptr
+from .nn import Module, SpatialMatching, _f32c
+from . import glue
+
+
+class SpatialConvolution(Module):
+    """nn.SpatialConvolution(nInputPlane, nOutputPlane, kW, kH): valid cross-correlation + bias."""
+
+    def __init__(self, nInputPlane, nOutputPlane, kW, kH, device="cuda", generator=None):
+        super().__init__()
+        self.nInputPlane, self.nOutputPlane, self.kW, self.kH = int(nInputPlane), int(nOutputPlane), int(kW), int(kH)
+        stdv = 1.0 / math.sqrt(self.kW * self.kH * self.nInputPlane)   # nn.SpatialConvolution:reset
+        self.weight = (torch.rand((self.nOutputPlane, self.nInputPlane, self.kH, self.kW), generator=generator) * 2 - 1).mul_(stdv).to(device)
+        self.bias = (torch.rand((self.nOutputPlane,), generator=generator) * 2 - 1).mul_(stdv).to(device)
+
+    def updateOutput(self, input):
+        x = _f32c(input, "input")
+        nIn, H, W = x.shape
+        if nIn != self.nInputPlane:
+            raise ValueError("SpatialConvolution: expected %d input planes, got %d" % (self.nInputPlane, nIn))
+        out = torch.empty((self.nOutputPlane, H - self.kH + 1, W - self.kW + 1), dtype=torch.float32, device=x.device)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_f32(ctx.handle, ptr(x), ptr(self.weight), ptr(self.bias), nIn, self.nOutputPlane, H, W,
+                                                    self.kH, self.kW, ptr(out)))
+        self.output = out
+        return out
+
+
+def tables_random(nin, nout, nto, generator=None):
+    """nn.tables.random(nin, nout, nto): every output plane is connected to `nto` distinct random input planes; rows are
+    (from, to), 1-based."""
+    rows = []
+    for o in range(1, nout + 1):
+        for i in torch.randperm(nin, generator=generator)[:nto].tolist():
+            rows.append((i + 1, o))
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+class SpatialConvolutionMap(Module):
+    """nn.SpatialConvolutionMap(connTable, kW, kH)."""
+
+    def __init__(self, connTable, kW, kH, device="cuda", generator=None):
+        super().__init__()
+        self.connTable = connTable.to(torch.int32).contiguous()
+        self.kW, self.kH = int(kW), int(kH)
+        self.nInputPlane = int(self.connTable[:, 0].max())
+        self.nOutputPlane = int(self.connTable[:, 1].max())
+        nconn = self.connTable.shape[0]
+        ninp = nconn / self.nOutputPlane
+        stdv = 1.0 / math.sqrt(self.kW * self.kH * ninp)
+        self.weight = (torch.rand((nconn, self.kH, self.kW), generator=generator) * 2 - 1).mul_(stdv).to(device)
+        self.bias = (torch.rand((self.nOutputPlane,), generator=generator) * 2 - 1).mul_(stdv).to(device)
+        self._conn_dev = self.connTable.to(device)
+
+    def updateOutput(self, input):
+        x = _f32c(input, "input")
+        nIn, H, W = x.shape
+        if nIn < self.nInputPlane:
+            raise ValueError("SpatialConvolutionMap: the table reads plane %d, input has %d" % (self.nInputPlane, nIn))
+        out = torch.empty((self.nOutputPlane, H - self.kH + 1, W - self.kW + 1), dtype=torch.float32, device=x.device)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_map_f32(ctx.handle, ptr(x), ptr(self.weight), ptr(self.bias), ptr(self._conn_dev),
+                                                        self.connTable.shape[0], nIn, self.nOutputPlane, H, W, self.kH, self.kW, ptr(out)))
+        self.output = out
+        return out
+
+
+class Tanh(Module):
+    def updateOutput(self, input):
+        x = _f32c(input, "input")
+        out = torch.empty_like(x)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_tanh_f32(ctx.handle, ptr(x), x.numel(), ptr(out)))
+        self.output = out
+        return out
+
+
+class Sequential(Module):
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def updateOutput(self, input):
+        for m in self.modules:
+            input = m.forward(input)
+        self.output = input
+        return input
+
+
+class ParallelTable(Module):
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def updateOutput(self, input):
+        self.output = [m.forward(x) for m, x in zip(self.modules, input)]
+        return self.output
+
+
+class Minus(Module):
+    def updateOutput(self, input):
+        self.output = -input
+        return self.output
+
+
+class SoftMaxWindow(Module):
+    """The FunctionWrapper of getModel (opticalflow_model.lua:96-109) applied after nn.Minus: SmartReshape({-1,-2},{-3,-4})
+    -> nn.SoftMax -> SmartReshape(H, W, -2).  Together with the Minus in front this is A3's softmin; here the pair
+    (Minus, SoftMaxWindow) is evaluated by dfe_softmin_f32 on the un-negated costs."""
+
+    def updateOutput(self, input):
+        x = _f32c(input, "input")
+        H, W = x.shape[0], x.shape[1]
+        N = x.numel() // (H * W)
+        cost = (-x).contiguous()          # undo the Minus that precedes this module
+        out = torch.empty((H, W, N), dtype=torch.float32, device=x.device)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_softmin_f32(ctx.handle, ptr(cost), H * W, N, ptr(out)))
+        self.output = out
+        return out
+
+
+def getFilter(geometry, device="cuda", generator=None):
+    """opticalflow_model.lua:45-79: geometry.layers[i] = {nIn, kW, kH, nOut}; Tanh between layers; a layer whose fan-in
+    differs from the previous fan-out becomes a SpatialConvolutionMap over a random connection table."""
+    layers = geometry["layers"] if isinstance(geometry, dict) else geometry.layers
+    filt = Sequential()
+    for i, l in enumerate(layers):
+        nin, kw, kh, nout = l
+        if i == 0 or layers[i - 1][3] == nin:
+            filt.add(SpatialConvolution(nin, nout, kw, kh, device=device, generator=generator))
+        else:
+            filt.add(SpatialConvolutionMap(tables_random(layers[i - 1][3], nout, nin, generator=generator), kw, kh, device=device, generator=generator))
+        if i != len(layers) - 1:
+            filt.add(Tanh())
+    return filt
+
+
+def getFilterRadial(networkp, device="cuda", generator=None):
+    """radial/radial_opticalflow_network.lua:6-30: layers are 'tanh' or {nIn, kH, kW, nOut} (note the kH, kW order)."""
+    filt = Sequential()
+    last = None
+    for layer in networkp["layers"]:
+        if layer == "tanh":
+            filt.add(Tanh())
+        elif isinstance(layer, (list, tuple)):
+            nin, kh, kw, nout = layer
+            if last is None or nin == last:
+                filt.add(SpatialConvolution(nin, nout, kw, kh, device=device, generator=generator))
+            else:
+                filt.add(SpatialConvolutionMap(tables_random(last, nout, nin, generator=generator), kw, kh, device=device, generator=generator))
+            last = nout
+        else:
+            raise ValueError("Unknown layer %r" % (layer,))
+    return filt
+
+
+class _SharedFilter(Module):
+    """filter:clone('weight','bias',...) -- the second branch shares the first one's parameters."""
+
+    def __init__(self, filt):
+        super().__init__()
+        self.filt = filt
+
+    def updateOutput(self, input):
+        out = input
+        for m in self.filt.modules:     # run with the shared weights, keep an own output
+            if isinstance(m, SpatialConvolution):
+                mm = SpatialConvolution.__new__(SpatialConvolution)
+                mm.__dict__.update(m.__dict__)
+            elif isinstance(m, SpatialConvolutionMap):
+                mm = SpatialConvolutionMap.__new__(SpatialConvolutionMap)
+                mm.__dict__.update(m.__dict__)
+            else:
+                mm = type(m)()
+            out = mm.forward(out)
+        self.output = out
+        return out
+
+
+def getModel(geometry, full_image=True, prefiltered=False, device="cuda", generator=None):
+    """opticalflow_model.lua:81-130 (single scale): [ParallelTable(filter, shared clone)] -> SpatialMatching -> Minus ->
+    softmax over the window -> OutputExtractor for 'mean'.  `model.modules` is a plain list in the reference's order, so
+    callers can patch it by index (depth_estimation_api.lua:27)."""
+    g = geometry
+    get = (lambda k, d=None: g.get(k, d)) if isinstance(g, dict) else (lambda k, d=None: getattr(g, k, d))
+    model = Sequential()
+    if not prefiltered:
+        filt = getFilter(g, device=device, generator=generator)
+        par = ParallelTable()
+        par.add(filt)
+        par.add(_SharedFilter(filt))
+        model.add(par)
+    model.add(SpatialMatching(get("maxh"), get("maxw"), False))
+    model.add(Minus())
+    model.add(SoftMaxWindow())
+    if get("output_extraction_method", "max") == "mean":
+        model.add(glue.OutputExtractor(get("maxh"), get("maxw")))
+    elif get("training_mode", False):
+        model.add(glue.Log2(1e-10))
+    return model

@@ -143,4 +143,8 @@ def __getattr__(name):  # nn.CascadingAddTable lives in multiscale.py (it needs 
         from . import glue
 
         return getattr(glue, name)
+    if name in ("SpatialConvolution", "SpatialConvolutionMap", "Tanh", "Sequential", "ParallelTable", "Minus"):
+        from . import network
+
+        return getattr(network, name)
     raise AttributeError(name)

@@ -292,6 +292,20 @@ int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy
 int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw,
                              float *x, float *y);
 
+/* ---- A15 (next-row N1): the learned patch-feature stack -------------------------------------------- */
+/* replaces: nn.SpatialConvolution / nn.SpatialConvolutionMap / nn.Tanh as used by getFilter
+ *   (opticalflow_model.lua:45-79, radial/radial_opticalflow_network.lua:6-30): valid cross-correlation + bias,
+ *   in [nIn][H][W] -> out [nOut][H-kH+1][W-kW+1]; weight [nOut][nIn][kH][kW] resp. one [kH][kW] kernel per
+ *   connection of conn [nConn][2] = (from, to), 1-based, device int32; bias [nOut] or NULL.  Direct form, one thread
+ *   per output, accumulation order (input plane | connection, ky, kx) -- correctness first, not tuned (this is where
+ *   an implicit-GEMM MFMA kernel belongs). */
+int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut,
+                                int H, int W, int kH, int kW, float *out);
+int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias,
+                                    const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW,
+                                    float *out);
+int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
+
 /* ---- A11 ('mean' extraction): marginal of the window over its columns --------------------------- */
 /* replaces: input:reshape(H,W,maxh,maxw):sum(4) in getOutputConfidences2, opticalflow_model.lua:192.
  *   in [P][A][B] -> out [P][A], double accumulator as in TH. */

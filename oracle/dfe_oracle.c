@@ -73,6 +73,50 @@ void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int
     (void)H2;
 }
 
+/* ---- A15 (next-row N1): the learned patch-feature stack ------------------------------------------ */
+/* nn.SpatialConvolution(nIn, nOut, kW, kH):updateOutput -- valid cross-correlation + bias.  ref call sites:
+ * opticalflow_model.lua:45-79 (getFilter), radial/radial_opticalflow_network.lua:6-30.  [3P nn: out = bias, then for
+ * every input plane out += xcorr2(in_i, w[o][i]) -- per output element that is the order i, then ky, then kx; float.] */
+void orc_spatial_convolution(const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W,
+                             int kH, int kW, float *out) {
+    int Ho = H - kH + 1, Wo = W - kW + 1;
+    ORC_PAR_FOR
+    for (int o = 0; o < nOut; ++o)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float s = bias ? bias[o] : 0.f;
+                for (int i = 0; i < nIn; ++i)
+                    for (int u = 0; u < kH; ++u)
+                        for (int v = 0; v < kW; ++v)
+                            s += weight[(((size_t)o * nIn + i) * kH + u) * kW + v] * in[((size_t)i * H + y + u) * W + x + v];
+                out[((size_t)o * Ho + y) * Wo + x] = s;
+            }
+}
+/* nn.SpatialConvolutionMap(connTable, kW, kH): connection c = (from, to) 1-based, one kH x kW kernel per connection,
+ * accumulated into out[to] in table order. ref: opticalflow_model.lua:56-59 (nn.tables.random fan-in tables) */
+void orc_spatial_convolution_map(const float *in, const float *weight, const float *bias, const int *conn, int nConn,
+                                 int nIn, int nOut, int H, int W, int kH, int kW, float *out) {
+    int Ho = H - kH + 1, Wo = W - kW + 1;
+    (void)nIn;
+    ORC_PAR_FOR
+    for (int o = 0; o < nOut; ++o)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float s = bias ? bias[o] : 0.f;
+                for (int c = 0; c < nConn; ++c) {
+                    if (conn[2 * c + 1] - 1 != o) continue;
+                    int i = conn[2 * c] - 1;
+                    for (int u = 0; u < kH; ++u)
+                        for (int v = 0; v < kW; ++v)
+                            s += weight[((size_t)c * kH + u) * kW + v] * in[((size_t)i * H + y + u) * W + x + v];
+                }
+                out[((size_t)o * Ho + y) * Wo + x] = s;
+            }
+}
+void orc_tanh(const float *in, int64_t n, float *out) { /* nn.Tanh: tanhf */
+    for (int64_t i = 0; i < n; ++i) out[i] = tanhf(in[i]);
+}
+
 /* N2: gradients of A1 / A1r w.r.t. both feature maps (un-vendored nnx; nothing in the reference tests them -- pinned as
  * the Jacobian of orc_spatial_matching / orc_radial_matching, the way tests/test_cascad.lua:22 pins the cascade).
  * g1[k][y][x]  = sum_{dy,dx}  2 (in1[k][y][x] - in2[k][y+dy][x+dx]) go[y][x][dy][dx]

@@ -45,6 +45,15 @@ void orc_unfold(const float *img, int C, int H, int W, int kh, int kw, float *ou
 void orc_spatial_matching(const float *in1, const float *in2, int K, int H1, int W1,
                           int maxh, int maxw, float *out);
 
+/* A15 / N1 learned filter stack: nn.SpatialConvolution, nn.SpatialConvolutionMap (connection table [nConn][2] =
+ * (from, to), 1-based), nn.Tanh. ref: opticalflow_model.lua:45-79, radial/radial_opticalflow_network.lua:6-30.
+ * Summation order of un-vendored nn recalled, not pinned by a reference test. */
+void orc_spatial_convolution(const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W,
+                             int kH, int kW, float *out);
+void orc_spatial_convolution_map(const float *in, const float *weight, const float *bias, const int *conn, int nConn,
+                                 int nIn, int nOut, int H, int W, int kH, int kW, float *out);
+void orc_tanh(const float *in, int64_t n, float *out);
+
 /* N2: gradients of A1 and A1r w.r.t. in1 and in2 (go = gradOutput, layout of the forward output). Pinned as the Jacobian
  * of the forward restatements (no reference test exists; method of tests/test_cascad.lua:22). */
 void orc_spatial_matching_backward(const float *in1, const float *in2, const float *go, int K, int H1, int W1,

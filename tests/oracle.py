@@ -49,6 +49,9 @@ def lib():
             "orc_softmin": (None, [f32p, C.c_int64, C.c_int, f32p]),
             "orc_cascade_ring": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_cascading_add": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+            "orc_spatial_convolution": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+            "orc_spatial_convolution_map": (None, [f32p, f32p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+            "orc_tanh": (None, [f32p, C.c_int64, f32p]),
             "orc_spatial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
             "orc_radial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
             "orc_cascading_add_backward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -224,6 +227,34 @@ def cascading_add(ins, ratios, maxh, maxw):
     b = (C.c_void_p * len(ins))(*[p.ctypes.data for p in outs])
     rc = lib().orc_cascading_add(a, len(ins), r, P, maxh, maxw, b)
     return rc, outs
+
+
+def spatial_convolution(inp, weight, bias):
+    inp, weight = _f(inp), _f(weight)
+    nOut, nIn, kH, kW = weight.shape
+    _, H, W = inp.shape
+    out = np.empty((nOut, H - kH + 1, W - kW + 1), np.float32)
+    b = _f(bias) if bias is not None else None
+    lib().orc_spatial_convolution(inp, weight, b.ctypes.data if b is not None else None, nIn, nOut, H, W, kH, kW, out)
+    return out
+
+
+def spatial_convolution_map(inp, weight, bias, conn, nOut):
+    inp, weight = _f(inp), _f(weight)
+    nConn, kH, kW = weight.shape
+    nIn, H, W = inp.shape
+    conn = np.ascontiguousarray(conn, np.int32)
+    out = np.empty((nOut, H - kH + 1, W - kW + 1), np.float32)
+    b = _f(bias) if bias is not None else None
+    lib().orc_spatial_convolution_map(inp, weight, b.ctypes.data if b is not None else None, conn.reshape(-1), nConn, nIn, nOut, H, W, kH, kW, out)
+    return out
+
+
+def tanh(inp):
+    inp = _f(inp)
+    out = np.empty_like(inp)
+    lib().orc_tanh(inp.reshape(-1), inp.size, out.reshape(-1))
+    return out
 
 
 def spatial_matching_backward(in1, in2, go, maxh, maxw):

@@ -402,3 +402,48 @@ def test_process_output_mean_extraction(dfe, cuda):
     full = ret["full"].cpu().numpy()
     assert full.shape == (2, H + 8, W + 8) and np.array_equal(full[0, 4 : 4 + H, 4 : 4 + W], ret["y"].cpu().numpy())
     assert np.all(full[:, :4] == 0)
+
+
+def test_filter_stack_and_single_scale_model(dfe, cuda):
+    """A15 / N1: nn.SpatialConvolution, nn.SpatialConvolutionMap, nn.Tanh against the oracle (bit-exact: same accumulation
+    order), getFilter's layer rule, and getModel end to end: shared-weight filters -> SpatialMatching -> softmax(-cost)
+    -> processOutput (opticalflow_model.lua:45-130)."""
+    gen = torch.Generator().manual_seed(7)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((3, 30, 37)).astype(np.float32)
+    conv = dfe.nn.SpatialConvolution(3, 8, 5, 3, generator=gen)            # kW = 5, kH = 3
+    out = conv.forward(T(x, cuda))
+    w, b = conv.weight.cpu().numpy(), conv.bias.cpu().numpy()
+    assert tuple(out.shape) == (8, 28, 33) and np.array_equal(out.cpu().numpy(), orc.spatial_convolution(x, w, b))
+    t = dfe.nn.Tanh().forward(out)
+    assert np.allclose(t.cpu().numpy(), orc.tanh(out.cpu().numpy()), rtol=0, atol=2e-7)
+    table = dfe.tables_random(8, 6, 4, generator=gen)
+    assert table.shape == (24, 2) and all(len(set(table[table[:, 1] == o][:, 0].tolist())) == 4 for o in range(1, 7))
+    cmap = dfe.nn.SpatialConvolutionMap(table, 3, 3, generator=gen)
+    y = cmap.forward(out)
+    assert np.array_equal(y.cpu().numpy(), orc.spatial_convolution_map(out.cpu().numpy(), cmap.weight.cpu().numpy(), cmap.bias.cpu().numpy(), table.numpy(), 6))
+    # getFilter: equal fan-in -> SpatialConvolution, different -> SpatialConvolutionMap; Tanh between layers only
+    geo = dict(layers=[(3, 5, 5, 8), (8, 3, 3, 8), (4, 3, 3, 6)], maxh=7, maxw=7, multiscale=False, output_extraction_method="max",
+               hImg=40, wImg=52)
+    filt = dfe.getFilter(geo, generator=gen)
+    kinds = [type(m).__name__ for m in filt.modules]
+    assert kinds == ["SpatialConvolution", "Tanh", "SpatialConvolution", "Tanh", "SpatialConvolutionMap"]
+    # getModel end to end on a pair whose second frame is a shifted crop of the same image: the arg-max recovers the shift
+    model = dfe.getModel(geo, True, False, generator=gen)
+    assert [type(m).__name__ for m in model.modules] == ["ParallelTable", "SpatialMatching", "Minus", "SoftMaxWindow"]
+    base = rng.standard_normal((3, 60, 70)).astype(np.float32)
+    i0 = base[:, 10:44, 10:56]                                            # patch windows of frame 0: maxh-1 smaller than frame 1's
+    i1 = base[:, 10 - 3 + 2 : 44 + 3 + 2, 10 - 3 - 1 : 56 + 3 - 1]
+    prob = model.forward([T(np.ascontiguousarray(i0), cuda), T(np.ascontiguousarray(i1), cuda)])
+    f0, f1 = model.modules[0].output
+    assert tuple(prob.shape) == (f0.shape[1], f0.shape[2], 49) and f1.shape[1] == f0.shape[1] + 6
+    ref_cost = orc.spatial_matching(f0.cpu().numpy(), f1.cpu().numpy(), 7, 7)
+    assert np.array_equal(model.modules[1].output.cpu().numpy(), ref_cost)
+    assert np.abs(prob.cpu().numpy().reshape(-1, 49) - orc.softmin(ref_cost.reshape(-1, 49))).max() <= SOFT_ATOL
+    ret = dfe.processOutput(geo, prob, False)
+    # frame 1's window starts 3-2 rows / 3+1 columns before frame 0's: the matching cell is (dy, dx) = (1, 4) -> centred (-2, +1)
+    assert (ret["y"] == -2).float().mean() > 0.95 and (ret["x"] == 1).float().mean() > 0.95
+    # radial variant of the layer list (kH, kW order and literal 'tanh' entries)
+    rf = dfe.getFilterRadial(dict(layers=[(3, 1, 9, 6), "tanh", (6, 9, 1, 6)]), generator=gen)
+    z = rf.forward(T(x, cuda))
+    assert tuple(z.shape) == (6, 30 - 8, 37 - 8)
