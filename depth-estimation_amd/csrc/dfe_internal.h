@@ -105,6 +105,8 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
                       float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded);
 int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
                           float cy, float *depth, float *conf);
+int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,
+                           bool *handled);
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
                              int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts);
 

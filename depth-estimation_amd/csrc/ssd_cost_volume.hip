@@ -1276,6 +1276,11 @@ int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, i
     DFE_REQUIRE(ctx, in1 && in2 && out, DFE_E_ARG, "dfe_spatial_matching_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE,
                 "dfe_spatial_matching_f32: K=%d H1=%d W1=%d maxh=%d maxw=%d must be positive", K, H1, W1, maxh, maxw);
+    {
+        bool handled = false;   // lane <-> cell kernel with the feature tile in LDS (feat_matching.hip), bit-identical results
+        int rc = dfe_feat_matching_fast(ctx, in1, in2, K, H1, W1, maxh, maxw, out, &handled);
+        if (rc != DFE_OK || handled) return rc;
+    }
     CvRefArgs a;
     a.a = in1; a.a_plane = (long long)H1 * W1; a.a_pitch = W1; a.a_oy = 0; a.a_ox = 0;
     a.b = in2; a.b_plane = (long long)(H1 + maxh - 1) * (W1 + maxw - 1); a.b_pitch = W1 + maxw - 1;
