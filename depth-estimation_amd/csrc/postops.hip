@@ -223,7 +223,12 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
             int n = 0;
             float qq[DFE_LEAD];
 #pragma unroll
-            for (int kk = 0; kk < DFE_LEAD; ++kk) qq[kk] = kk < N ? lead[(long long)kk * Ptot + pg] : 0.f;   // all loads in flight
+            for (int g4 = 0; g4 < DFE_LEAD / 4; ++g4) {                                   // pixel-major [P][DFE_LEAD]: 4 x 16 B
+                const float4 q4 = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD)[g4];
+                qq[4 * g4] = q4.x; qq[4 * g4 + 1] = q4.y; qq[4 * g4 + 2] = q4.z; qq[4 * g4 + 3] = q4.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < DFE_LEAD; ++kk) qq[kk] = kk < N ? qq[kk] : 0.f;
 #pragma unroll
             for (int kk = 0; kk < DFE_LEAD; ++kk) {
                 if (kk < N && n < M && (double)qq[kk] > threshold) {

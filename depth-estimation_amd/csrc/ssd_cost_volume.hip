@@ -221,18 +221,24 @@ template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], i
 // the part of the fused epilogue that is plain stores: the centre cell's cost and the pixel's first DFE_LEAD cells
 template <int TX>
 __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa) {
-    if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell
-#pragma unroll
-        for (int x = 0; x < TX; ++x) fa.centre[pg0 + x] = vrow[x];
+    // Both are SGPR base + 32-bit lane offset dwordx4 stores: with 64-bit per-lane addresses the address arithmetic of these
+    // few bytes cost the two waves that own them ~6 % of the whole fused row-image kernel (they sit before the barrier).
+    static_assert(TX == 8, "two dwordx4 stores per lane");
+    const f4_t lo = {vrow[0], vrow[1], vrow[2], vrow[3]}, hi = {vrow[4], vrow[5], vrow[6], vrow[7]};
+    if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
+        const float *cb = fa.centre + pg0;
+        asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:16" ::"v"(0u), "v"(lo), "s"(cb), "v"(hi) : "memory");
     }
     if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
-        // the pixel's first cells, for extractOutput: cell-major planes, so a lane's 8 columns are 32 contiguous
-        // bytes (2 stores per row instead of 8) and finalize reads them coalesced
-        int ll = lane;
-        asm volatile("" : "+v"(ll));   // the plane address is rebuilt per row: hoisted, it gets spilled, and a scratch reload waits for every store in flight
-        f4u_t *lp4 = reinterpret_cast<f4u_t *>(fa.lead + (long long)ll * fa.Ptot + pg0);
-        lp4[0] = f4_t{vrow[0], vrow[1], vrow[2], vrow[3]};
-        lp4[1] = f4_t{vrow[4], vrow[5], vrow[6], vrow[7]};
+        // the pixel's first cells, for extractOutput, pixel-major [P][DFE_LEAD]: the 8 pixels of the tile row are 512
+        // contiguous, line-aligned bytes, written back to back by this wave (8 x 64 B) so that they leave L2 as whole
+        // lines.  (Cell-major planes -- 2 dwordx4 stores -- left 16 partial lines per row step, 690 k per VGA launch, and
+        // partial lines that miss L2 are what this memory system is slow at: section 4.2.)
+        const float *lb = fa.lead + pg0 * DFE_LEAD;
+        const unsigned off = (unsigned)lane * 4u;
+#pragma unroll
+        for (int x = 0; x < TX; ++x)
+            asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
     }
 }
 
@@ -936,7 +942,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         const int vmin = wave_min1(best);
                         const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
                         const int bif = __builtin_amdgcn_readlane(bi, f);
-                        if (lane == 0)
+                        if (lane == 0 && !(DFE_ABLATE & 4194304))
                             fa.part[(long long)hh * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xx] =
                                 make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
                     }
