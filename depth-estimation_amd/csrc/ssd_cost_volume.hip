@@ -927,22 +927,34 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         const int c0 = (hh * 64 + lane) * CPL;
                         const float *px = st + xx * D;
                         int cv[CPL];
+                        // This phase is bound by its instruction count (16 waves x ~70 VALU per row step), so the common case
+                        // D = 9 * n (33 x 33 = 9 * 121) drops the per-cell clamps and masks: a lane is either entirely inside
+                        // the window or entirely outside.
+                        bool lane_out = false;                                // fast path: this lane lies entirely outside the window
+                        if (D % CPL == 0) {                                   // block-uniform
+                            lane_out = c0 >= D;
+                            const int *pc = reinterpret_cast<const int *>(px) + (lane_out ? 0 : c0);
 #pragma unroll
-                        for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);   // all reads in flight
+                            for (int i = 0; i < CPL; ++i) cv[i] = pc[i];      // all reads in flight
+                        } else {
 #pragma unroll
-                        for (int i = 0; i < CPL; ++i) cv[i] = c0 + i < D ? cv[i] : 0x7f800000;
+                            for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);
+#pragma unroll
+                            for (int i = 0; i < CPL; ++i) cv[i] = c0 + i < D ? cv[i] : 0x7f800000;
+                        }
                         // shallow dependency chains (every wave of the block is in this phase at once, nothing else hides
                         // latency): the lane minimum as a tree of 3-input minima, its first position independently of
                         // the wave reduction that follows
                         static_assert(CPL == 9, "min tree below is written for 9 cells");
-                        const int best = min(min(min(cv[0], cv[1]), min(cv[2], cv[3])), min(min(min(cv[4], cv[5]), min(cv[6], cv[7])), cv[8]));
+                        int best = min(min(min(cv[0], cv[1]), min(cv[2], cv[3])), min(min(min(cv[4], cv[5]), min(cv[6], cv[7])), cv[8]));
                         int bi = CPL - 1;
 #pragma unroll
                         for (int i = CPL - 2; i >= 0; --i) bi = cv[i] == best ? i : bi;
-                        const int vmin = wave_min1(best);
-                        const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
-                        const int bif = __builtin_amdgcn_readlane(bi, f);
-                        if (lane == 0 && !(DFE_ABLATE & 4194304))
+                        best = lane_out ? 0x7f800000 : best;
+                        const int vmin = (DFE_ABLATE & 16777216) ? best : wave_min1(best);
+                        const int f = (DFE_ABLATE & 33554432) ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
+                        const int bif = (DFE_ABLATE & 33554432) ? bi : __builtin_amdgcn_readlane(bi, f);
+                        if (lane == 0 && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
                             fa.part[(long long)hh * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xx] =
                                 make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
                     }
