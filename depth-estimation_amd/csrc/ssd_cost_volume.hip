@@ -669,7 +669,9 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
     }
 }
 
-template <int C, int K, int TX, int NQ, bool SM, bool FUSE, bool SWEEP>
+// DC: the window's cell count as a compile-time constant (0 = run time).  With D known, the 8 deposit addresses per task row
+// (st + x*D + d), the scan's and the copy-out's become immediate offsets -- instructions of the lock-stepped phases.
+template <int C, int K, int TX, int NQ, bool SM, bool FUSE, bool SWEEP, int DC = 0>
 __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
                                                              float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
     using px_t = typename Px<C>::type;
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
     __syncthreads();
 
-    const int D = p.hWin * p.wWin;
+    const int D = DC ? DC : p.hWin * p.wWin;
     const int RUN = TX * D;                       // floats in the block's run
     const int l16 = lane & 15;
     float av[C][NE];
@@ -1016,7 +1018,9 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
-    auto kern = ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false>;
+    // the +-16 search (33 x 33 = 1089 cells) at the default tile height gets the instantiation with D as a constant
+    auto kern = (NQ == 5 && D == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false, (NQ == 5 ? 1089 : 0)>
+                                       : ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
     {
