@@ -124,7 +124,7 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
 
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
     DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
-    DFE_REQUIRE(ctx, tyq >= 0 && tyq <= 7, DFE_E_ARG, "tile height code %d not in 0..7", tyq);
+    DFE_REQUIRE(ctx, (tyq >= 0 && tyq <= 7) || (tyq > 100 && tyq <= 164), DFE_E_ARG, "tile height code %d not in 0..7 / 101..164", tyq);
     ctx->cv_tyq = tyq;
     return DFE_OK;
 }

@@ -13,7 +13,7 @@ struct dfe_ctx {
     bool own_stream = false;
     int cv_mode = 0;                  // dfe_set_cost_volume_kernel
     int cv_chunk0 = 0;                // tiled kernel covers chunks >= this (set by the row-image launcher for its tail)
-    int cv_tyq = 0;                   // 0 = pick the tile height per shape; 2..5 = force (tuning / tests)
+    int cv_tyq = 0;                   // 0 = pick the tile height per shape; else dfe_set_cost_volume_tile's code (tuning / tests)
     int ncu = 256;                    // compute units of the device
     const char *last_kernel = "";
     void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)

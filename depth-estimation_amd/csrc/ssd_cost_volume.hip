@@ -152,7 +152,7 @@ struct CvTiledArgs {
     int lrows;         // LDS rows = ROWS + hWin - 1
     int lcols;         // staged columns = TX + K - 1 + wWin - 1
     int chunk0;        // tiled kernel: first 64-displacement chunk it covers (0 = all)
-    int seg_rows;      // row-image kernel, column sweep: output rows per block
+    int seg_rows;      // row-image kernel: output rows per block (static tile height / column-sweep segment)
     int tile0_off;     // row-image kernel: byte offset of the frame-0 tile inside dynamic LDS
     int stage_off;     // row-image kernel: byte offset of the run images inside dynamic LDS
     int stage_len;     // row-image kernel: floats per image
@@ -167,6 +167,13 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 #endif
 #ifndef DFE_ABLATE
 #define DFE_ABLATE 0
+#endif
+#ifndef DFE_ST_FLAGS
+// cache-policy bits of the copy-out stores.  The volume streams out and nothing re-reads it from L2: with the non-temporal
+// hint the build measures 268 instead of 285 us at VGA and the step's finalize pass finds its planes still cached
+// (step -4 %); " sc1", " sc0 sc1" and combinations with " nt" measure the same as " nt" alone.  (Whole lines only: on the
+// tiled kernel's 256-B per-wave dword stores the same hint costs 44 % -- 554 against 385 us.)
+#define DFE_ST_FLAGS " nt"
 #endif
 
 
@@ -523,7 +530,7 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
     int best = 0;
     CvTilePlan bp{};
     for (int nq = 2; nq <= 5; ++nq) {
-        if (ctx->cv_tyq && nq != ctx->cv_tyq) continue;
+        if (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5 && nq != ctx->cv_tyq) continue;
         CvTilePlan p4 = plan_cv_tiled<C, K, TX, 4, 8>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
         if (p4.score > bp.score) { bp = p4; best = 40 + nq; }
         CvTilePlan p1 = plan_cv_tiled<C, K, TX, 1, 6>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
@@ -552,7 +559,7 @@ static int launch_cv_tiled_fused(dfe_ctx *ctx, const float *I0, const float *I1,
     int best = 0;
     CvTilePlan bp{};
     for (int nq = 2; nq <= 5; ++nq) {
-        if (ctx->cv_tyq && nq != ctx->cv_tyq) continue;
+        if (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5 && nq != ctx->cv_tyq) continue;
         CvTilePlan p4 = plan_cv_tiled<C, K, TX, 4, 8>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
         if (p4.score > bp.score) { bp = p4; best = nq; }
     }
@@ -671,14 +678,12 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
 
 // DC: the window's cell count as a compile-time constant (0 = run time).  With D known, the 8 deposit addresses per task row
 // (st + x*D + d), the scan's and the copy-out's become immediate offsets -- instructions of the lock-stepped phases.
-template <int C, int K, int TX, int NQ, bool SM, bool FUSE, bool SWEEP, int DC = 0>
+template <int C, int K, int TX, bool SM, bool FUSE, bool SWEEP, int DC = 0>
 __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
                                                              float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
     using px_t = typename Px<C>::type;
     constexpr int NW = 16;
     constexpr int U = VUnroll<K>::value;
-    constexpr int ROWS = U * NQ;                 // static tiles: rows swept per tile
-    constexpr int TY = ROWS - (K - 1);
     constexpr int R0 = 8;                        // column sweep: rows of the frame-0 ring
     constexpr int LW = NW - 1;                   // column sweep: the wave that streams the tiles and never stores
     constexpr int NE = TX + K - 1;
@@ -706,9 +711,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // p.seg_rows output rows of its 8-pixel column, the frame-1 tile is a ring of p.lrows (= 64) rows that wave LW keeps
     // filled a row step ahead, so the K-1 warm-up rows are paid once per segment instead of once per TY rows and no
     // tile staging stalls the CU between tiles.
-    const int x0n = bx * TX, y0n = SWEEP ? by * p.seg_rows : by * TY;
-    const int x0 = min(x0n, p.Wo - TX), y0 = SWEEP ? y0n : min(y0n, p.Ho - TY);
-    const int nsweep = SWEEP ? min(p.seg_rows, p.Ho - y0) + (K - 1) : ROWS;   // rows this block sweeps
+    // (static tiles: p.seg_rows is the tile height, a run-time value -- one instantiation serves every height)
+    const int x0n = bx * TX, y0n = by * p.seg_rows;
+    const int x0 = min(x0n, p.Wo - TX), y0 = SWEEP ? y0n : min(y0n, p.Ho - p.seg_rows);
+    const int nsweep = min(p.seg_rows, p.Ho - y0) + (K - 1);   // rows this block sweeps
+    const int t0rows = SWEEP ? R0 : nsweep;                    // rows of the frame-0 tile
     const long long HW = p.plane;
     const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
 
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
     {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to 32 columns (quarter tasks read at +2w)
         px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
-        for (int r = wave; r < (SWEEP ? R0 : ROWS); r += NW) {
+        for (int r = wave; r < t0rows; r += NW) {
             if (lane < 32) {
                 const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(lane, NE - 1);
                 if constexpr (C == 1) {
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     else if (has_m) __builtin_amdgcn_s_setprio(2);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
-    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + (SWEEP ? R0 : ROWS) * 32 * sizeof(px_t)) + lane;
+    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + t0rows * 32 * sizeof(px_t)) + lane;
     float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
 #pragma unroll
     for (int c = 0; c < C; ++c) hold[c] = 0.f;
@@ -806,12 +813,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         if (wave == 4) rm[i * 64] = 0.f;
     }
 
-    const int nq = SWEEP ? (nsweep + U - 1) / U : NQ;
+    const int nq = (nsweep + U - 1) / U;
     for (int q = 0; q < nq; ++q) {
         static_for<0, U>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const int r = q * U + m;
-            if (SWEEP && r >= nsweep) return;                                // block-uniform
+            if (SWEEP && r >= nsweep) return;                                // block-uniform (static tiles: nsweep is a multiple of U)
             const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
             const int y = y0 + r - (K - 1);
             const bool store_row = emit && y >= y0n;                         // block-uniform
@@ -820,7 +827,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * 32;
-            {
+            if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
                 px_t a;
                 if constexpr (!SM) a = t0[t0r + l16];
                 float v[TX];
@@ -972,15 +979,15 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
-                    constexpr int STR = (SWEEP ? LW : NW) * 64;
                     static_assert(3 * 15 * 64 >= TX * 1096 / 4, "three pieces per thread cover the run");
+                    constexpr int STR = (SWEEP ? LW : NW) * 64;
                     f4_t val[3];
 #pragma unroll
                     for (int i = 0; i < 3; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
                         if (tj + i * STR < nbody4)
-                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = head + (nbody4 << 2), ntail = RUN - tail0;
                         if (wave == 5 && lane < head) out[G0 + lane] = st[lane];
@@ -992,37 +999,49 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
 }
 
-template <int C, int K, int TX, int NQ, bool FUSE>
-static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
-                                float *out, const CvFuseArgs *fa, bool *handled) {
+// LDS bytes of a static-tile block of `ty` output rows (0 = does not apply) and the kernel arguments that go with it
+template <int C, int K, int TX>
+static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int wWin, CvTiledArgs *out_args) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
-    constexpr int ROWS = U * NQ, TY = ROWS - (K - 1);
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
     const int D = hWin * wWin;
-    *handled = false;
     // 16 chunk waves + the quarter/mini tasks cover up to 1096 cells; below 13 chunks too many waves would idle
-    if (D <= 768 || D > 1096 || Ho < TY || Wo < TX) return DFE_OK;
+    const int rows = ty + K - 1;
+    if (D <= 768 || D > 1096 || ty < 1 || Ho < ty || Wo < TX || rows % U != 0) return 0;   // (the kernel sweeps whole groups of U rows)
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
-    a.lrows = ROWS + hWin - 1;
+    a.lrows = rows + hWin - 1;
     a.lcols = TX + K - 1 + wWin - 1;
     const int M = Px<C>::bank_mod;
     a.pitch = a.lcols;
     while ((a.pitch - wWin) % M != 0) ++a.pitch;
+    a.seg_rows = ty;
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
-    a.stage_off = a.tile0_off + (int)(((size_t)ROWS * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
+    a.stage_off = a.tile0_off + (int)(((size_t)rows * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
     a.stage_len = (TX * D + 32 + 31) / 32 * 32;
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
-    if (lds_bytes > 160 * 1024) return DFE_OK;
-    // the +-16 search (33 x 33 = 1089 cells) at the default tile height gets the instantiation with D as a constant
-    auto kern = (NQ == 5 && D == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false, (NQ == 5 ? 1089 : 0)>
-                                       : ssd_cv_rowimg_kernel<C, K, TX, NQ, DFE_RI_SMEM, FUSE, false>;
+    if (lds_bytes > 160 * 1024) return 0;
+    if (out_args) *out_args = a;
+    return lds_bytes;
+}
+
+// static tiles of `ty` output rows
+template <int C, int K, int TX, bool FUSE>
+static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
+                                int ty, float *out, const CvFuseArgs *fa, bool *handled) {
+    *handled = false;
+    CvTiledArgs a;
+    const size_t lds_bytes = rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, &a);
+    if (!lds_bytes) return DFE_OK;
+    // the +-16 search (33 x 33 = 1089 cells) gets the instantiation with D as a constant
+    auto kern = (hWin * wWin == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 1089>
+                                      : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    dim3 grid(dfe_cdiv(Wo, TX), dfe_cdiv(Ho, TY));
+    dim3 grid(dfe_cdiv(a.Wo, TX), dfe_cdiv(a.Ho, ty));
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
@@ -1072,7 +1091,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
     static_assert(!FUSE, "the fused column sweep does not fit the register file");
-    auto kern = ssd_cv_rowimg_kernel<C, K, TX, 0, DFE_RI_SMEM, FUSE, true>;
+    auto kern = ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(ncols, nseg);
     {
@@ -1085,26 +1104,44 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     return DFE_OK;
 }
 
-// row-image kernel, auto: static tiles or the column sweep, see below; dfe_set_cost_volume_tile 3..7 forces static
-// tiles of NQ*6 - 6 rows, 1 forces the column sweep
+// Static tile height for a frame.  Rounds x rows swept (blocks / CUs, rounded up, times ty + K-1) would favour tall tiles
+// -- VGA: ty = 42 -> 836 blocks = 4 rounds x 48 rows against ty = 24 -> 1444 blocks = 6 x 30 -- but measured on MI355X the
+// build takes the same 285-300 us for every height from 24 to 45 rows (the output rows are bound by the store stream, the
+// warm-up rows of a short tile overlap the drain of the previous tile's stores), so the 24-row tile stays: least LDS, and
+// the finest grain for the last round.  ty + K-1 is a multiple of the row unroll U.
+template <int C, int K, int TX>
+static int rowimg_pick_ty(int H, int W, long long plane, int hWin, int wWin) {
+    constexpr int U = VUnroll<K>::value;
+    const int Ho = H - K + 1 - hWin + 1;
+    for (int ty = U * 5 - (K - 1); ty >= 1; ty -= U)
+        if (ty <= Ho && rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, nullptr)) return ty;
+    return 0;
+}
+
+// row-image kernel.  dfe_set_cost_volume_tile: 0 = auto (static tiles of the height rowimg_pick_ty chooses, or the column
+// sweep, see below), 1 = force the column sweep, 3..7 = static tiles of 6n - 6 rows, 100 + ty = static tiles of ty rows
+// (ty + K-1 a multiple of the row unroll)
 template <int C, int K, int TX, bool FUSE>
 static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
                             float *out, const CvFuseArgs *fa, bool *handled) {
     constexpr int U = VUnroll<K>::value;
-    int nq = ctx->cv_tyq;
-    if (nq == 1) {   // forced column sweep (unfused build only: the fused instantiation does not fit 128 VGPRs)
+    const int code = ctx->cv_tyq;
+    *handled = false;
+    if (code == 1) {   // forced column sweep (unfused build only: the fused instantiation does not fit 128 VGPRs)
         if (FUSE) return DFE_OK;
         return launch_cv_rowimg_sweep<C, K, TX, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
     }
-    if (nq == 0) {
-        // Static 24-row tiles or the column sweep?  Rows swept per CU: rounds x 30 against rounds x (segment + 6); a swept
-        // row of the sweep costs ~15 % more (measured: ring addressing, a barrier in every row, 15 copier waves), so it
-        // wins on frames with many rounds (720p +5 %, 1080p +3 %) and loses or ties at VGA (one under-full round).
+    int ty;
+    if (code >= 100) ty = code - 100;
+    else if (code >= 2) ty = U * code - (K - 1);
+    else {
+        // Static tiles or the column sweep?  A swept row of the sweep costs ~15 % more (measured: ring addressing, a
+        // barrier in every row, 15 copier waves), so it only pays when its rounds x rows is clearly smaller.
         const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
-        nq = Ho >= U * 5 - (K - 1) ? 5 : Ho >= U * 4 - (K - 1) ? 4 : 3;
-        if (!FUSE && Ho >= 1 && Wo >= TX) {
-            const int TY = U * nq - (K - 1), ncols = dfe_cdiv(Wo, TX);
-            const double cost_static = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, TY), ctx->ncu) * (U * nq);
+        ty = rowimg_pick_ty<C, K, TX>(H, W, plane, hWin, wWin);
+        if (!FUSE && ty && Wo >= TX) {
+            const int ncols = dfe_cdiv(Wo, TX);
+            const double cost_static = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, ty), ctx->ncu) * (ty + K - 1);
             double cost_sweep = 1e30;
             for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg)
                 cost_sweep = fmin(cost_sweep, (double)dfe_cdiv((long long)ncols * nseg, ctx->ncu) * (dfe_cdiv(Ho, nseg) + K - 1));
@@ -1114,13 +1151,7 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
             }
         }
     }
-    switch (nq) {
-        case 3: return launch_cv_rowimg_one<C, K, TX, 3, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 4: return launch_cv_rowimg_one<C, K, TX, 4, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 6: return launch_cv_rowimg_one<C, K, TX, 6, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        case 7: return launch_cv_rowimg_one<C, K, TX, 7, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-        default: return launch_cv_rowimg_one<C, K, TX, 5, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-    }
+    return launch_cv_rowimg_one<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, ty, out, fa, handled);
 }
 
 // *nparts: planes of fa.part the launched kernel filled -- 2 (the row-image kernel scans a pixel's run in two halves)

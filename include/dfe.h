@@ -61,8 +61,8 @@ int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* s
  * (2/3: DFE_E_UNSUPPORTED from the op when the shape has no such kernel) */
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
 /* tile height of the tiled / row-image kernels: 0 = chosen per shape (default); 2..7 = force NQ (a tile sweeps
- * NQ groups of 6 image rows at k = 7); 1 = force the row-image kernel's column sweep (unfused build only).
- * For tuning and for testing every instantiation. */
+ * NQ groups of 6 image rows at k = 7: 6 NQ - 6 output rows); 100 + ty (101..164) = row-image tiles of ty output
+ * rows (ty a multiple of 6 at k = 7); 1 = force the row-image kernel's column sweep (unfused build only).  For tuning and for testing. */
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* name of the kernel the last cost-volume call launched (static string) */
 const char *dfe_last_kernel(const dfe_ctx *ctx);

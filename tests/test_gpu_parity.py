@@ -90,12 +90,13 @@ def test_cost_volume_every_tile_height_bit_exact(dfe, cuda, tyq):
     assert np.array_equal(out.cpu().numpy(), cpu)
 
 
-@pytest.mark.parametrize("nq", [0, 1, 3, 4, 5, 6])
+@pytest.mark.parametrize("nq", [0, 1, 3, 4, 5, 6, 106, 107, 142])
 @pytest.mark.parametrize("H,W", [(80, 100), (75, 47), (131, 90), (230, 64)])
 def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
     # the row-image kernel (all 1089 cells of a tile row in one block, LDS row image, aligned copy-out), 33x33 window, as a
-    # column sweep (nq = 1; (230, 64): several segments of a column) and with static tiles of every height (0 = auto), on frames whose last tile row / column are shifted
-    # and whose runs start at every alignment mod 128 B
+    # column sweep (nq = 1; (230, 64): several segments of a column) and with static tiles of many heights (0 = auto, 3..6 = 6n - 6
+    # rows, 100 + ty = ty rows: the height is a run-time value, a multiple of 6), on frames whose last tile row / column are shifted and whose
+    # runs start at every alignment mod 128 B
     f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + nq, max_flow=9)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
     ctx = dfe.get_ctx(0)
@@ -104,7 +105,8 @@ def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
     try:
         out = torch.full(cpu.shape, -1.0, device=cuda)
         t0, t1 = T(f0, cuda), T(f1, cuda)
-        if nq != 1 and cpu.shape[0] < (6 * (nq or 3) - 6):   # static tiles need one full tile of rows; the column sweep (nq = 1) does not
+        ty = nq - 100 if nq >= 100 else 6 * nq - 6
+        if nq > 1 and (cpu.shape[0] < ty or ty % 6):   # forced static tiles need one full tile of rows and sweep whole groups of 6 rows; auto and the column sweep (nq = 1) adapt
             with pytest.raises(dfe.DfeError):
                 ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, 33, 33, out.data_ptr()))
             return

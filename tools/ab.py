@@ -12,12 +12,14 @@ for r in range(rounds):
         lib, _, mode = t.partition(":")   # tag[:mode] -- mode forces DFE_CV_MODE
         env = dict(os.environ, DFE_LIB=os.path.join(root, "tools/ubench/libdfe_%s.so" % lib))
         if mode: env["DFE_CV_MODE"] = mode
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "100"], env=env,
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "100"] + os.environ.get("AB_ARGS", "").split(), env=env,
                              capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
             print(t, "FAILED", out.stderr[-500:]); sys.exit(1)
         j = json.loads(out.stdout.strip().splitlines()[-1])
-        res[t].append((j["roofline"]["kernel_ms"], j["ms_per_step"]))
+        res[t].append((j["roofline"]["kernel_ms"], j["ms_per_step"], j.get("roofline_build_only", {}).get("kernel_ms", 0.0)))
 for t in tags:
     k = sorted(x[0] for x in res[t]); s = sorted(x[1] for x in res[t])
-    print("%-10s kernel_ms min %.4f med %.4f | step min %.4f med %.4f" % (t, k[0], statistics.median(k), s[0], statistics.median(s)), flush=True)
+    b = sorted(x[2] for x in res[t])
+    print("%-10s kernel_ms min %.4f med %.4f | step min %.4f med %.4f | build-only min %.4f med %.4f" %
+          (t, k[0], statistics.median(k), s[0], statistics.median(s), b[0], statistics.median(b)), flush=True)

@@ -16,7 +16,8 @@ for wl in (sys.argv[1:] or ["vga"]):
     balg = algorithmic_bytes(H, W, Cc, k, hW, wW)
     mode = int(os.environ.get("CV_MODE", "2"))
     ctx.set_cost_volume_kernel(mode)
-    for tyq in ((5, 5, 1, 5, 1) if mode == 3 else (4, 2, 3, 4, 5)):   # (first entry repeats: clocks ramp up during it)
+    codes = [int(c) for c in os.environ["CV_TILES"].split(",")] if "CV_TILES" in os.environ else None
+    for tyq in (codes or ((0, 0, 5, 1, 0, 5, 1) if mode == 3 else (4, 2, 3, 4, 5))):   # (first entry repeats: clocks ramp up during it)
         ctx.set_cost_volume_tile(tyq)
         for _ in range(3):
             ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hW, wW, out.data_ptr()))
