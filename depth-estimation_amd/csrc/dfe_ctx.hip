@@ -53,6 +53,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *e = getenv("DFE_CV_MODE")) { int m = atoi(e); if (m >= 0 && m <= 3) ctx->cv_mode = m; }   // tuning: initial kernel mode
+    if (const char *e = getenv("DFE_CV_TILE")) { int t = atoi(e); if ((t >= 0 && t <= 7) || (t > 100 && t <= 164)) ctx->cv_tyq = t; }   // tuning: initial tile code
     if (!own_stream) {
         ctx->stream = (hipStream_t)stream;   // NULL = the default stream
     } else {

@@ -1090,8 +1090,10 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
-    static_assert(!FUSE, "the fused column sweep does not fit the register file");
-    auto kern = ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true>;
+    // the fused sweep fits the register file only with D as a constant (33 x 33); other windows: static tiles
+    if (FUSE && D != 1089) return DFE_OK;
+    auto kern = (D == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true, 1089>
+                            : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, false, true>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(ncols, nseg);
     {
@@ -1104,18 +1106,27 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     return DFE_OK;
 }
 
-// Static tile height for a frame.  Rounds x rows swept (blocks / CUs, rounded up, times ty + K-1) would favour tall tiles
-// -- VGA: ty = 42 -> 836 blocks = 4 rounds x 48 rows against ty = 24 -> 1444 blocks = 6 x 30 -- but measured on MI355X the
-// build takes the same 285-300 us for every height from 24 to 45 rows (the output rows are bound by the store stream, the
-// warm-up rows of a short tile overlap the drain of the previous tile's stores), so the 24-row tile stays: least LDS, and
-// the finest grain for the last round.  ty + K-1 is a multiple of the row unroll U.
+// Static tile height for a frame: the kernel's time follows rounds x rows swept -- blocks / CUs, rounded up, times the
+// ty + K-1 rows a block sweeps (the K-1 warm-up rows are the overhead of short tiles, the under-full last round that of
+// a block count that does not fit the CU count).  VGA, 33 x 33: ty = 36 -> 13 x 76 = 988 blocks = 4 rounds x 42 rows
+// against ty = 24 -> 1444 blocks = 6 x 30; measured 260 against 266-293 us (720p / 1080p: 36 or 42 rows, -6 %).
+// (With ordinary instead of non-temporal copy-out stores the height made no difference at all: the store stream was
+// the co-bottleneck, and a short tile's warm-up rows overlapped the drain of the previous tile's stores.)
+// ty + K-1 is a multiple of the row unroll U; LDS (the frame-1 tile grows with ty) allows up to 42 rows at 33 x 33.
 template <int C, int K, int TX>
-static int rowimg_pick_ty(int H, int W, long long plane, int hWin, int wWin) {
+static int rowimg_pick_ty(const dfe_ctx *ctx, int H, int W, long long plane, int hWin, int wWin, double *cost_out) {
     constexpr int U = VUnroll<K>::value;
-    const int Ho = H - K + 1 - hWin + 1;
-    for (int ty = U * 5 - (K - 1); ty >= 1; ty -= U)
-        if (ty <= Ho && rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, nullptr)) return ty;
-    return 0;
+    const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
+    const int ncols = dfe_cdiv(Wo, TX);
+    int best = 0;
+    double best_cost = 1e30;
+    for (int ty = U - (K - 1) % U; ty <= Ho && ty <= 20 * U; ty += U) {
+        if (ty < 1 || !rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, nullptr)) continue;
+        const double cost = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, ty), ctx->ncu) * (ty + K - 1);
+        if (cost < best_cost) { best_cost = cost; best = ty; }   // ties: the shorter tile (less LDS, finer last round)
+    }
+    if (cost_out) *cost_out = best_cost;
+    return best;
 }
 
 // row-image kernel.  dfe_set_cost_volume_tile: 0 = auto (static tiles of the height rowimg_pick_ty chooses, or the column
@@ -1127,26 +1138,26 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
     constexpr int U = VUnroll<K>::value;
     const int code = ctx->cv_tyq;
     *handled = false;
-    if (code == 1) {   // forced column sweep (unfused build only: the fused instantiation does not fit 128 VGPRs)
-        if (FUSE) return DFE_OK;
-        return launch_cv_rowimg_sweep<C, K, TX, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
-    }
+    if (code == 1)     // forced column sweep (fused: 33 x 33 windows only)
+        return launch_cv_rowimg_sweep<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
     int ty;
     if (code >= 100) ty = code - 100;
     else if (code >= 2) ty = U * code - (K - 1);
     else {
-        // Static tiles or the column sweep?  A swept row of the sweep costs ~15 % more (measured: ring addressing, a
-        // barrier in every row, 15 copier waves), so it only pays when its rounds x rows is clearly smaller.
+        // Static tiles or the column sweep?  The sweep pays the K-1 warm-up rows once per segment; a swept
+        // row costs about the same in both (sweep: ring addressing and 15 copier waves; static: tile staging), measured
+        // VGA 241 against 260 us, 1080p 1730 against 1790 us, so the smaller rounds x rows wins.  In the fused build a swept
+        // row of the sweep costs ~14 % more (VGA: sweep 322 us at 154 rows, 36-row tiles 310 us at 168).
         const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
-        ty = rowimg_pick_ty<C, K, TX>(H, W, plane, hWin, wWin);
-        if (!FUSE && ty && Wo >= TX) {
+        double cost_static = 1e30;
+        ty = rowimg_pick_ty<C, K, TX>(ctx, H, W, plane, hWin, wWin, &cost_static);
+        if (ty && Wo >= TX) {
             const int ncols = dfe_cdiv(Wo, TX);
-            const double cost_static = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, ty), ctx->ncu) * (ty + K - 1);
             double cost_sweep = 1e30;
             for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg)
                 cost_sweep = fmin(cost_sweep, (double)dfe_cdiv((long long)ncols * nseg, ctx->ncu) * (dfe_cdiv(Ho, nseg) + K - 1));
-            if (cost_sweep * 1.18 < cost_static) {
-                int rc = launch_cv_rowimg_sweep<C, K, TX, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
+            if (cost_sweep * (FUSE ? 1.16 : 1.04) < cost_static) {
+                int rc = launch_cv_rowimg_sweep<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
                 if (rc != DFE_OK || *handled) return rc;
             }
         }

@@ -255,11 +255,17 @@ def test_fused_flow_entry_bit_exact_on_integer_frames(dfe, cuda):
         (17, 17, 3, 1e12),      # nothing above the threshold anywhere -> scores / imaxs untouched
     ],
 )
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 101, 104])
 def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode):
     """dfe_ssd_flow_f32 through the fused build (minima, centre cost and extractOutput leave the cost-volume kernel)
     == oracle, including the fallback for pixels whose first cells hold too few values above the threshold.  Auto mode
-    takes the row-image kernel at 33x33 / C=3 and the tiled kernel elsewhere; mode 2 forces the tiled kernel."""
+    takes the row-image kernel at 33x33 / C=3 and the tiled kernel elsewhere; mode 2 forces the tiled kernel; 101 / 104 =
+    auto mode with the row-image kernel forced to its column sweep / to static 18-row tiles."""
+    tile = 0
+    if mode >= 100:
+        if not (hWin == 33 and C == 3):
+            pytest.skip("tile codes of the row-image kernel")
+        mode, tile = 0, mode - 100
     H, W = 90, 110
     want = "ssd_cv_rowimg_kernel+fused_tail" if (mode == 0 and hWin == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"
     f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=hWin + C, max_flow=min(hWin, wWin) // 2 - 1, noise_sigma=1.0)
@@ -271,6 +277,7 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode
         if limit:
             ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, limit))
         ctx.set_cost_volume_kernel(mode)
+        ctx.set_cost_volume_tile(tile)
         try:
             idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
             best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
@@ -284,6 +291,7 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode
                 assert ctx.last_kernel() == want
         finally:
             ctx.set_cost_volume_kernel(0)
+            ctx.set_cost_volume_tile(0)
             ctx.check(dfe.lib().dfe_set_scratch_limit(ctx.handle, 16 << 30))
         assert np.array_equal(idx.cpu().numpy(), ref["idx"])
         assert np.array_equal(best.cpu().numpy(), ref["best"])

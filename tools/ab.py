@@ -9,9 +9,10 @@ rounds, tags = int(sys.argv[1]), sys.argv[2:]
 res = {t: [] for t in tags}
 for r in range(rounds):
     for t in tags:
-        lib, _, mode = t.partition(":")   # tag[:mode] -- mode forces DFE_CV_MODE
+        lib, mode, tile = (t.split(":") + ["", ""])[:3]   # tag[:mode[:tile]] -- DFE_CV_MODE / DFE_CV_TILE
         env = dict(os.environ, DFE_LIB=os.path.join(root, "tools/ubench/libdfe_%s.so" % lib))
         if mode: env["DFE_CV_MODE"] = mode
+        if tile: env["DFE_CV_TILE"] = tile
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "100"] + os.environ.get("AB_ARGS", "").split(), env=env,
                              capture_output=True, text=True, timeout=300)
         if out.returncode != 0:
