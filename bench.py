@@ -253,13 +253,15 @@ def main():
         balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin)
         kern_s = cv_ms.value / 1e3 / max(cv_n.value, 1)
         achieved = balg / kern_s / 1e9 if kern_s > 0 else 0.0
-        traffic = None
+        traffic = build_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md)
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_per_launch")
+                build_traffic = tj.get("build_only", {}).get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic = build_traffic = None
         out = {
             "metric": "Mpixels/s dense flow+depth, %dx%d pair, 7x7 patch +-16 search" % (W, H),
             "value": round(world * args.steps * H * W / elapsed / 1e6, 3),
@@ -298,7 +300,8 @@ def main():
         if build_ms:
             out["roofline_build_only"] = {
                 "bound": "hbm", "kernel": build_kernel, "achieved": round(balg / (build_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(balg / (build_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(build_ms, 5),
+                "unit": "GB/s", "frac": round(balg / (build_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": build_traffic,
+                "kernel_ms": round(build_ms, 5),
                 "launches_timed": 20, "note": "dfe_ssd_cost_volume_f32 alone, measured after the timed region",
             }
         if world == 1 and not args.no_cpu_baseline:
