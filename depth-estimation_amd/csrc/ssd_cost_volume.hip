@@ -676,6 +676,9 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
     }
 }
 
+// columns of the frame-0 tile in LDS: the NE = 14 positions of a task row, read at up to +6 (quarter tasks) + 15 (the
+// row of 16 a DPP broadcast reaches)
+constexpr int kT0W = 24;
 // DC: the window's cell count as a compile-time constant (0 = run time).  With D known, the 8 deposit addresses per task row
 // (st + x*D + d), the scan's and the copy-out's become immediate offsets -- instructions of the lock-stepped phases.
 template <int C, int K, int TX, bool SM, bool FUSE, bool SWEEP, int DC = 0>
@@ -729,15 +732,15 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             }
         }
     }
-    {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to 32 columns (quarter tasks read at +2w)
+    {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to kT0W columns (quarter tasks read at +2w)
         px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
         for (int r = wave; r < t0rows; r += NW) {
-            if (lane < 32) {
+            if (lane < kT0W) {
                 const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(lane, NE - 1);
                 if constexpr (C == 1) {
-                    t0w[r * 32 + lane] = src[0];
+                    t0w[r * kT0W + lane] = src[0];
                 } else {
-                    t0w[r * 32 + lane] = make_float4(src[0], src[HW], src[2 * HW], 0.f);
+                    t0w[r * kT0W + lane] = make_float4(src[0], src[HW], src[2 * HW], 0.f);
                 }
             }
         }
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     else if (has_m) __builtin_amdgcn_s_setprio(2);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
-    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + t0rows * 32 * sizeof(px_t)) + lane;
+    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + t0rows * kT0W * sizeof(px_t)) + lane;
     float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
 #pragma unroll
     for (int c = 0; c < C; ++c) hold[c] = 0.f;
@@ -826,7 +829,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const int a0 = (int)(G0 & 31);
             float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
-            const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * 32;
+            const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
             if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
                 px_t a;
                 if constexpr (!SM) a = t0[t0r + l16];
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                             px_t px;
                             if constexpr (C == 1) px = hold[0]; else px = make_float4(hold[0], hold[1], hold[2], 0.f);
                             if (t1lane) lds[((r - 1) & (p.lrows - 1)) * p.pitch + lane] = px;
-                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * 32 + lane - p.lcols] = px;
+                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lane - p.lcols] = px;
                         }
                         const float *src = t1lane ? I1 + (long long)min(y0 + r + p.lrows, p.H - 1) * p.W + x0 + lane
                                                   : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lane - p.lcols);
@@ -1020,7 +1023,7 @@ static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int w
     a.seg_rows = ty;
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
-    a.stage_off = a.tile0_off + (int)(((size_t)rows * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
+    a.stage_off = a.tile0_off + (int)(((size_t)rows * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
     a.stage_len = (TX * D + 32 + 31) / 32 * 32;
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
@@ -1085,7 +1088,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     const int nseg = dfe_cdiv(Ho, a.seg_rows);
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
-    a.stage_off = a.tile0_off + (int)(((size_t)R0 * 32 * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 2 * TX * sizeof(float2) + 127) / 128 * 128);
+    a.stage_off = a.tile0_off + (int)(((size_t)R0 * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
     a.stage_len = (TX * D + 32 + 31) / 32 * 32;
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
@@ -1108,11 +1111,11 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
 
 // Static tile height for a frame: the kernel's time follows rounds x rows swept -- blocks / CUs, rounded up, times the
 // ty + K-1 rows a block sweeps (the K-1 warm-up rows are the overhead of short tiles, the under-full last round that of
-// a block count that does not fit the CU count).  VGA, 33 x 33: ty = 36 -> 13 x 76 = 988 blocks = 4 rounds x 42 rows
-// against ty = 24 -> 1444 blocks = 6 x 30; measured 260 against 266-293 us (720p / 1080p: 36 or 42 rows, -6 %).
+// a block count that does not fit the CU count).  VGA, 33 x 33: ty = 48 -> 10 x 76 = 760 blocks = 3 rounds x 54 rows,
+// ty = 36 -> 988 blocks = 4 x 42, ty = 24 -> 1444 blocks = 6 x 30; measured (fused build) 304 / 309 / 324 us.
 // (With ordinary instead of non-temporal copy-out stores the height made no difference at all: the store stream was
 // the co-bottleneck, and a short tile's warm-up rows overlapped the drain of the previous tile's stores.)
-// ty + K-1 is a multiple of the row unroll U; LDS (the frame-1 tile grows with ty) allows up to 42 rows at 33 x 33.
+// ty + K-1 is a multiple of the row unroll U; LDS (the frame-1 tile grows with ty) allows up to 48 rows at 33 x 33.
 template <int C, int K, int TX>
 static int rowimg_pick_ty(const dfe_ctx *ctx, int H, int W, long long plane, int hWin, int wWin, double *cost_out) {
     constexpr int U = VUnroll<K>::value;
