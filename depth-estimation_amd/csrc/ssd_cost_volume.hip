@@ -535,6 +535,12 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
         if (p4.score > bp.score) { bp = p4; best = 40 + nq; }
         CvTilePlan p1 = plan_cv_tiled<C, K, TX, 1, 6>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
         if (p1.score > bp.score) { bp = p1; best = 10 + nq; }
+        if constexpr (C == 3 && K == 7) {   // windows of one chunk (the pyramid's 8 x 8): 4 tasks on 4 waves, 4 blocks per CU
+            if (hWin * wWin <= 64) {
+                CvTilePlan p44 = plan_cv_tiled<C, K, TX, 4, 4>(nq, Ho, Wo, hWin, wWin, ctx->ncu);
+                if (p44.score > bp.score) { bp = p44; best = 440 + nq; }
+            }
+        }
     }
     if (!best) return DFE_OK;   // no tile fits: caller falls back
     *handled = true;
@@ -543,6 +549,10 @@ static int launch_cv_tiled(dfe_ctx *ctx, const float *I0, const float *I1, int H
         case 43: return launch_cv_tiled_one<C, K, TX, 4, 8, 3>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         case 44: return launch_cv_tiled_one<C, K, TX, 4, 8, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         case 45: return launch_cv_tiled_one<C, K, TX, 4, 8, 5>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 442: if constexpr (C == 3 && K == 7) return launch_cv_tiled_one<C, K, TX, 4, 4, 2>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 443: if constexpr (C == 3 && K == 7) return launch_cv_tiled_one<C, K, TX, 4, 4, 3>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 444: if constexpr (C == 3 && K == 7) return launch_cv_tiled_one<C, K, TX, 4, 4, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
+        case 445: if constexpr (C == 3 && K == 7) return launch_cv_tiled_one<C, K, TX, 4, 4, 5>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         case 12: return launch_cv_tiled_one<C, K, TX, 1, 6, 2>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         case 13: return launch_cv_tiled_one<C, K, TX, 1, 6, 3>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
         case 14: return launch_cv_tiled_one<C, K, TX, 1, 6, 4>(ctx, bp, I0, I1, H, W, plane, hWin, wWin, out);
