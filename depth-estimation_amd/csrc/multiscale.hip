@@ -80,16 +80,6 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
     return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
 }
-__device__ __forceinline__ int wave_min_i32(int v) {
-#define DFE_STEP(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0, v, ctrl, 0xf, 0xf, false))
-    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);
-#undef DFE_STEP
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = min((int)r[0], (int)r[1]);
-    const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return min((int)q[0], (int)q[1]);
-}
-
 // wave sum in the association order of `for (off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off)` -- partners at
 // distance 32, 16, 8, 4, 2, 1 -- on the VALU only (lane swaps + DPP), bit-identical to the shuffle version: after the
 // distance-8 step lanes L and L^8 hold equal values, so row_ror:4 (partner (L+4) mod 16) reads the same number as L^4
@@ -295,7 +285,11 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
         // index arithmetic in 32 bits (a 64-bit divide per pixel cost more than the whole cascade), x / r through a float
         // reciprocal (exact: (x + 0.5) / r is never within 1/(2r) of an integer); class -> displacement from a table
         // built once per block instead of divisions per pixel.
-        constexpr int NPX = 4, MAXS = 5;
+        // Eight pixels per step: their wave reductions share one halving butterfly (dfe_internal.h: wave_min8, ~40 VALU for 8
+        // columns instead of 8 x 12 dependent DPP steps), on keys that order like the floats (sign-folded bits, inverted so
+        // that the minimum is the maximum value); the smallest class among the lanes holding a column's maximum comes
+        // from a second butterfly; lanes 0..7 then finish one pixel each and store together.
+        constexpr int NPX = 8, MAXS = 5;
         int2 *tab = reinterpret_cast<int2 *>(sh);             // [ncls] (oy, ox); the cur/prev buffers are not used on this path
         for (int c = threadIdx.x; c < g.ncls; c += blockDim.x) {
             long long oy = 0, ox = 0;
@@ -312,6 +306,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
             rowp[s] = g.in[s < g.nratios ? s : 0] + (long long)(y / r) * (g.W / r) * N;
             rinv[s] = 1.0f / (float)r;
         }
+        const int mlane = (middle - 1) & 63;
         for (int x0 = (blockIdx.x * kWaves + w) * NPX; x0 < g.W; x0 += gridDim.x * kWaves * NPX) {
             float vin[NPX][MAXS];
 #pragma unroll
@@ -323,10 +318,9 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                     vin[i][s] = (s < g.nratios && lane < N) ? rowp[s][xs * N + lane] : 0.f;
                 }
             }
+            int key[NPX], bcls[NPX], cbits[NPX];
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
-                const int x = x0 + i;
-                if (x >= g.W) break;                              // wave-uniform
                 float bv = -INFINITY, pv = 0.f;
                 int bi = 0x7fffffff;
 #pragma unroll
@@ -338,23 +332,36 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                     const int c = cls[s];
                     if (c >= 0 && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
                 }
-                // wave arg-max on the VALU (DPP / lane swaps, no LDS crossbar): maximum value, then the smallest class
-                // among the lanes that hold it; the centre class sits in a known lane of scale 1
-                const float centre = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), (middle - 1) & 63));
-                const float wmax = wave_max_f32(bv);
-                bi = wave_min_i32(bv == wmax ? bi : 0x7fffffff);
-                if (lane == 0) {
-                    int id = bi + 1;
-                    if (middle > 0 && wmax == centre) id = middle;
-                    const long long p = (long long)y * g.W + x;
-                    if (idx) idx[p] = id;
-                    if (best_out) best_out[p] = wmax;
-                    if (fy) {
-                        const int2 t = tab[id - 1];
-                        const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
-                        fy[fo] = (float)t.x;
-                        fx[fo] = (float)t.y;
-                    }
+                // order-preserving int image of the float (-0 folded onto +0 first, so that equal floats give equal keys),
+                // inverted: the smallest key is the largest value
+                const int bb = __float_as_int(bv + 0.0f);
+                key[i] = ~(bb >= 0 ? bb : bb ^ 0x7fffffff);
+                bcls[i] = bi;
+                cbits[i] = __float_as_int(pv);                // scale-1 value of this lane's cell (the centre class sits in lane mlane)
+            }
+            const int wk = wave_min8<NPX>(key, lane);         // lane L: key of the maximum of pixel L & 7
+            int cand[NPX];
+#pragma unroll
+            for (int i = 0; i < NPX; ++i) cand[i] = key[i] == __builtin_amdgcn_readlane(wk, i) ? bcls[i] : 0x7fffffff;
+            const int wc = wave_min8<NPX>(cand, lane);        // lane L: smallest class holding that maximum
+            int cen = 0;                                      // lane i: the centre class's value of pixel i
+#define DFE_CEN(i) { const int t = __builtin_amdgcn_readlane(cbits[i], mlane); asm("v_writelane_b32 %0, %1, " #i : "+v"(cen) : "s"(t)); }
+            DFE_CEN(0) DFE_CEN(1) DFE_CEN(2) DFE_CEN(3) DFE_CEN(4) DFE_CEN(5) DFE_CEN(6) DFE_CEN(7)
+#undef DFE_CEN
+            const int x = x0 + lane;
+            if (lane < NPX && x < g.W) {
+                const int t = ~wk;
+                const float wmax = __int_as_float(t >= 0 ? t : t ^ 0x7fffffff);
+                int id = wc + 1;
+                if (middle > 0 && wmax == __int_as_float(cen)) id = middle;
+                const long long p = (long long)y * g.W + x;
+                if (idx) idx[p] = id;
+                if (best_out) best_out[p] = wmax;
+                if (fy) {
+                    const int2 d = tab[id - 1];
+                    const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
+                    fy[fo] = (float)d.x;
+                    fx[fo] = (float)d.y;
                 }
             }
         }

@@ -184,42 +184,6 @@ __device__ __forceinline__ void store_uniform_base(const void *base, unsigned la
     asm volatile("global_store_dword %0, %1, %2" ::"v"(lane_bytes), "v"(v), "s"(base) : "memory");
 }
 
-// All-lanes maximum of EIGHT non-negative ints per lane (one per tile column) in ~30 VALU ops instead of 8 x 6:
-// a halving butterfly -- after exchanging with lane^1, lane^2, lane^4 each lane is left with the single column
-// (lane & 7), then lane^8, ^16, ^32 finish it.  lane^1 / lane^2 are DPP quad permutes and lane^8 a row rotate
-// (all fold into v_max_i32_dpp), lane^4 / ^16 are ds_swizzle and lane^32 a ds_bpermute (LDS crossbar, no LDS memory).
-// On return every lane holds the wave maximum of column (lane & 7).
-template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], int lane) {
-    static_assert(TX == 8, "butterfly is written for 8 columns");
-    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
-    int a[4], b[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mine = b0 ? k[2 * i + 1] : k[2 * i], other = b0 ? k[2 * i] : k[2 * i + 1];
-        a[i] = min(mine, __builtin_amdgcn_update_dpp(0, other, 0xB1, 0xf, 0xf, false));     // quad_perm [1,0,3,2]
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int mine = b1 ? a[2 * i + 1] : a[2 * i], other = b1 ? a[2 * i] : a[2 * i + 1];
-        b[i] = min(mine, __builtin_amdgcn_update_dpp(0, other, 0x4E, 0xf, 0xf, false));     // quad_perm [2,3,0,1]
-    }
-    int c;
-    {
-        // row_ror:4 -- quad q takes from quad q+1 (mod 4): even quads (bit2 = 0) read an odd quad and vice versa, and
-        // the following ror:8 completes the row whichever neighbour was used.
-        const int mine = b2 ? b[1] : b[0], other = b2 ? b[0] : b[1];
-        c = min(mine, __builtin_amdgcn_update_dpp(0, other, 0x124, 0xf, 0xf, false));
-    }
-    c = min(c, __builtin_amdgcn_update_dpp(0, c, 0x128, 0xf, 0xf, false));                  // row_ror:8
-    {   // gfx950 lane-swap instructions keep the cross-row steps on the VALU (no LDS-pipe swizzle/bpermute)
-        const auto r = __builtin_amdgcn_permlane16_swap(c, c, false, false);                // rows {0,1} and {2,3} pair up
-        c = min((int)r[0], (int)r[1]);
-        const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);                // halves pair up
-        c = min((int)q[0], (int)q[1]);
-    }
-    return c;
-}
-
 // Fused flow epilogue of one task row (TX columns x 64 cells of chunk `chunk`, pixel pg0 = column 0): leaves, per column,
 // the chunk minimum and the 0-based index of the first cell attaining it in fa.part, plus the centre cell's cost and the
 // pixel's first DFE_LEAD cells.  Costs are >= 0, so their bit patterns order like integers.  The butterfly leaves lane L
