@@ -117,36 +117,37 @@ struct MultiGeom {
     int d[DFE_MAX_RATIOS];   // ring width per scale (index >= 1)
 };
 
-__host__ __device__ inline int multi_decode(const MultiGeom &g, long long id, long long *oy, long long *ox) {
+// (I = int on the device's per-block decode tables: a 64-bit divide costs ~100 instructions there)
+template <class I> __host__ __device__ inline int multi_decode_t(const MultiGeom &g, I id, I *oy, I *ox) {
     // replaces: x2yxMultiNumber opticalflow_model_multiscale.lua:83-132
     const int maxh = g.maxh, maxw = g.maxw;
     const int chh = (maxh + 1) / 2, chw = (maxw + 1) / 2;
-    long long x = id;
+    I x = id;
     if (x < 1) return -1;
-    if (x <= (long long)maxh * maxw) {
+    if (x <= (I)maxh * maxw) {
         *oy = (x - 1) / maxw + 1 - chh;
         *ox = (x - 1) % maxw + 1 - chw;
         return 0;
     }
-    x -= (long long)maxh * maxw;
+    x -= (I)maxh * maxw;
     for (int i = 1; i < g.nratios; ++i) {
         const int d = g.d[i];
-        const long long len = 2ll * d * maxw + 2ll * (maxh - 2 * d) * d;
-        long long ty, tx;
+        const I len = (I)2 * d * maxw + (I)2 * (maxh - 2 * d) * d;
+        I ty, tx;
         if (x <= len) {
-            if (x <= (long long)d * maxw) {
+            if (x <= (I)d * maxw) {
                 ty = (x - 1) / maxw + 1; tx = (x - 1) % maxw + 1;
             } else {
-                x -= (long long)d * maxw;
-                if (x <= (long long)(maxh - 2 * d) * d) {
+                x -= (I)d * maxw;
+                if (x <= (I)(maxh - 2 * d) * d) {
                     ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1;
                 } else {
-                    x -= (long long)(maxh - 2 * d) * d;
-                    if (x <= (long long)(maxh - 2 * d) * d) {
+                    x -= (I)(maxh - 2 * d) * d;
+                    if (x <= (I)(maxh - 2 * d) * d) {
                         ty = (x - 1) / d + 1 + d; tx = (x - 1) % d + 1 + maxw - d;
                     } else {
-                        x -= (long long)(maxh - 2 * d) * d;
-                        if (x > (long long)d * maxw) return -1;
+                        x -= (I)(maxh - 2 * d) * d;
+                        if (x > (I)d * maxw) return -1;
                         ty = (x - 1) / maxw + 1 + maxh - d; tx = (x - 1) % maxw + 1;
                     }
                 }
@@ -158,6 +159,10 @@ __host__ __device__ inline int multi_decode(const MultiGeom &g, long long id, lo
         x -= len;
     }
     return -1;
+}
+
+__host__ __device__ inline int multi_decode(const MultiGeom &g, long long id, long long *oy, long long *ox) {
+    return multi_decode_t<long long>(g, id, oy, ox);
 }
 
 #ifdef __HIPCC__

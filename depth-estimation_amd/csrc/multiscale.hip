@@ -241,6 +241,14 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGe
     }
 }
 
+// launch shape of cascade_argmax_kernel's one-cell-per-lane path: a wave takes 8 adjacent pixels per step and 4 steps of
+// its row, a block of kWaves waves one row (measured at VGA: 1 / 2 / 4 steps per wave 0.2125 / 0.192 / 0.187 ms per pair;
+// blocks that walk down several rows instead 0.203 ms)
+static dim3 cascade_fast_grid(int H, int W) {
+    const int gx = (W + kWaves * 8 * 4 - 1) / (kWaves * 8 * 4);
+    return dim3((unsigned)gx, (unsigned)H);
+}
+
 // A4 + A5 + A6 + A10 in one pass: cascade coarse -> fine exactly like cascade_kernel<true>, but instead of writing the
 // joined [H][W][ncls] tensor the wave keeps the running arg-max over the classes it would have written (first maximum
 // wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
@@ -292,11 +300,12 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
         constexpr int NPX = 8, MAXS = 5;
         int2 *tab = reinterpret_cast<int2 *>(sh);             // [ncls] (oy, ox); the cur/prev buffers are not used on this path
         for (int c = threadIdx.x; c < g.ncls; c += blockDim.x) {
-            long long oy = 0, ox = 0;
-            multi_decode(mg, c + 1, &oy, &ox);
-            tab[c] = make_int2((int)oy, (int)ox);
+            int oy = 0, ox = 0;
+            multi_decode_t<int>(mg, c + 1, &oy, &ox);
+            tab[c] = make_int2(oy, ox);
         }
         __syncthreads();
+        const int mlane = (middle - 1) & 63;
         const int y = blockIdx.y;
         const float *rowp[MAXS];
         float rinv[MAXS];
@@ -306,7 +315,6 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
             rowp[s] = g.in[s < g.nratios ? s : 0] + (long long)(y / r) * (g.W / r) * N;
             rinv[s] = 1.0f / (float)r;
         }
-        const int mlane = (middle - 1) & 63;
         for (int x0 = (blockIdx.x * kWaves + w) * NPX; x0 < g.W; x0 += gridDim.x * kWaves * NPX) {
             float vin[NPX][MAXS];
 #pragma unroll
@@ -549,7 +557,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);
     dim3 grid(grid1d((long long)H * W, kWaves));
-    if (N <= 64 && nratios <= 5) grid = dim3((unsigned)((W + kWaves * 16 - 1) / (kWaves * 16)), (unsigned)H);
+    if (N <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);
     hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
                        flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
@@ -613,7 +621,7 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_cascade_flow_f32: window %dx%d too large", maxh, maxw);
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);   // fast path: class -> displacement table
     dim3 grid(grid1d((long long)H * W, kWaves));
-    if (maxh * maxw <= 64 && nratios <= 5) grid = dim3((unsigned)((W + kWaves * 16 - 1) / (kWaves * 16)), (unsigned)H);   // fast path: one row per blockIdx.y
+    if (maxh * maxw <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);   // fast path: one row per blockIdx.y
     hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
                        (long long *)idx, best, flow_y, flow_x, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
