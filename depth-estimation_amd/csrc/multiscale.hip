@@ -44,8 +44,8 @@ __global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int
 }
 
 // ---- down-sample by r (same arithmetic as downsample_box_kernel) and zero-pad, both frames, one launch ----
-__global__ void prep_scale_kernel(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl, int pt,
-                                  int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
+__device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl,
+                                                int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
 #pragma clang fp contract(off)
     const int Hs = H / r, Ws = W / r;
     const long long total = (long long)C * Hp * Wp;
@@ -67,6 +67,15 @@ __global__ void prep_scale_kernel(const float *__restrict__ I0, const float *__r
         }
         (second ? p1 : p0)[ee] = v;
     }
+}
+// every scale of the pyramid in one launch: blockIdx.y = scale (the scales only read the full-resolution frames)
+struct PrepScales {
+    int r[DFE_MAX_RATIOS], Hp[DFE_MAX_RATIOS], Wp[DFE_MAX_RATIOS];
+    float *p0[DFE_MAX_RATIOS], *p1[DFE_MAX_RATIOS];
+};
+__global__ void prep_scales_kernel(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int pl, int pt, PrepScales ps) {
+    const int s = blockIdx.y;
+    prep_scale_body(I0, I1, C, H, W, ps.r[s], pl, pt, ps.Hp[s], ps.Wp[s], ps.p0[s], ps.p1[s]);
 }
 
 __device__ __forceinline__ float wave_max_f32(float v) {
@@ -97,8 +106,7 @@ __device__ __forceinline__ float wave_sum_f32_ordered(float v) {
 }
 
 // ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
-__global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__restrict__ cost, long long P, int N,
-                                                             float *__restrict__ prob) {
+__device__ __forceinline__ void softmin_body(const float *__restrict__ cost, long long P, int N, float *__restrict__ prob) {
     const int lane = threadIdx.x & 63;
     if (N <= 64) {
         // one cell per lane: NPX pixels per step, all loads issued before the first is used, reductions on the VALU (the
@@ -138,6 +146,21 @@ __global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__res
         const float inv = 1.0f / s;
         for (int n = lane; n < N; n += 64) o[n] *= inv;
     }
+}
+
+__global__ __launch_bounds__(kWaves * 64) void softmin_kernel(const float *__restrict__ cost, long long P, int N,
+                                                             float *__restrict__ prob) {
+    softmin_body(cost, P, N, prob);
+}
+// the soft-min of every scale's volume in one launch: blockIdx.y = scale
+struct SoftScales {
+    const float *cost[DFE_MAX_RATIOS];
+    float *prob[DFE_MAX_RATIOS];
+    long long P[DFE_MAX_RATIOS];
+};
+__global__ __launch_bounds__(kWaves * 64) void softmin_scales_kernel(SoftScales ss, int N) {
+    const int s = blockIdx.y;
+    softmin_body(ss.cost[s], ss.P[s], N, ss.prob[s]);
 }
 
 struct CascadeGeom {
@@ -534,23 +557,35 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     if (rc) return rc;
     MultiGeom mg;
     mg.maxh = maxh; mg.maxw = maxw; mg.nratios = nratios;
+    // the scales are independent until the cascade: one launch prepares every scale's frames, one per scale builds its
+    // volume, one takes every soft-min (2 + nratios launches + the cascade instead of 3 nratios + 1)
+    PrepScales ps;
+    SoftScales ss;
+    long long prep_max = 0, soft_max = 0;
     for (int s = 0; s < nratios; ++s) {
         const int r = ratios[s], Hs = H / r, Ws = W / r, Hp = Hs + hp, Wp = Ws + wp;
-        float *p0 = (float *)((char *)scr + off_p[s]), *p1 = p0 + (size_t)C * Hp * Wp;
-        float *vol = (float *)((char *)scr + off_v[s]), *prob = (float *)((char *)scr + off_q[s]);
-        hipLaunchKernelGGL(prep_scale_kernel, dim3(grid1d(2ll * C * Hp * Wp, 256)), dim3(256), 0, ctx->stream, I0, I1, C, H, W, r, pl, pt, Hp,
-                           Wp, p0, p1);
-        DFE_LAUNCH_CHECK(ctx);
-        rc = cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, k, k, maxh, maxw, vol);
-        if (rc) return rc;
-        const long long P = (long long)Hs * Ws;
-        hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves * (N <= 64 ? 8 : 1))), dim3(kWaves * 64), 0, ctx->stream, vol, P, N, prob);
-        DFE_LAUNCH_CHECK(ctx);
-        g.in[s] = prob;
+        ps.r[s] = r; ps.Hp[s] = Hp; ps.Wp[s] = Wp;
+        ps.p0[s] = (float *)((char *)scr + off_p[s]);
+        ps.p1[s] = ps.p0[s] + (size_t)C * Hp * Wp;
+        ss.cost[s] = (float *)((char *)scr + off_v[s]);
+        ss.prob[s] = (float *)((char *)scr + off_q[s]);
+        ss.P[s] = (long long)Hs * Ws;
+        if (2ll * C * Hp * Wp > prep_max) prep_max = 2ll * C * Hp * Wp;
+        if (ss.P[s] > soft_max) soft_max = ss.P[s];
+        g.in[s] = ss.prob[s];
         g.out_scale[s] = nullptr;
         mg.ratios[s] = r;
         mg.d[s] = g.d[s];
     }
+    hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
+    DFE_LAUNCH_CHECK(ctx);
+    for (int s = 0; s < nratios; ++s) {
+        rc = cv_frames_dispatch(ctx, ps.p0[s], ps.p1[s], C, ps.Hp[s], ps.Wp[s], (long long)ps.Hp[s] * ps.Wp[s], k, k, maxh, maxw,
+                                (float *)ss.cost[s]);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nratios), dim3(kWaves * 64), 0, ctx->stream, ss, N);
+    DFE_LAUNCH_CHECK(ctx);
     g.H = H; g.W = W;
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
     size_t lds = (size_t)kWaves * 2 * N * sizeof(float);
