@@ -514,6 +514,14 @@ def test_full_vga_cost_volume_properties(dfe, cuda):
     assert ctx.last_kernel() == "ssd_cv_rowimg_kernel"
     assert torch.equal(tiled, rowimg)
     del rowimg
+    ctx.set_cost_volume_tile(148)          # the row-image kernel's static 48-row tiles (what the fused build takes at VGA)
+    try:
+        rowimg = op.forward([t0, t1])
+        assert ctx.last_kernel() == "ssd_cv_rowimg_kernel"
+    finally:
+        ctx.set_cost_volume_tile(0)
+    assert torch.equal(tiled, rowimg)
+    del rowimg
     rows = (0, 3, 200, 203, 439, 442)
     for r0, r1 in zip(rows[::2], rows[1::2]):
         cpu = np.zeros((442, 602, 33, 33), np.float32)[r0:r1] * 0
@@ -527,6 +535,15 @@ def test_full_vga_cost_volume_properties(dfe, cuda):
     inner = (slice(12, 442 - 12), slice(12, 602 - 12))
     py, px = flow[0][19:-19, 19:-19], flow[1][19:-19, 19:-19]
     assert ((y == py) & (x == px))[inner].mean() > 0.95   # flow-field seams and smooth-texture ties aside, the plant is recovered
+    # the fused build of the flow pipeline at full size (auto mode) must find exactly these indices and minima
+    fidx = torch.empty((442, 602), dtype=torch.int64, device=cuda)
+    fbest = torch.empty((442, 602), dtype=torch.float32, device=cuda)
+    ffy, ffx = torch.empty_like(fbest), torch.empty_like(fbest)
+    ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, 0.21,
+                                        fidx.data_ptr(), fbest.data_ptr(), ffy.data_ptr(), ffx.data_ptr(), None, None))
+    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel+fused_tail"
+    assert torch.equal(fidx, idx)
+    assert torch.equal(fbest, tiled.reshape(442 * 602, -1).gather(1, (idx.reshape(-1, 1) - 1)).reshape(442, 602))
     del tiled
     same = op.forward([t1, t1])
     centre = same.reshape(442, 602, -1)[:, :, mid - 1]
