@@ -48,6 +48,9 @@ int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...);
 // cost volume of raw frames into `out` (ssd_cost_volume.hip); H = rows visible to this call, plane = channel stride
 int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                        int kw, int hWin, int wWin, float *out);
+// the volumes of n independent pairs (pyramid scales) in one launch where a common block shape exists (*handled)
+int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
+                             int hWin, int wWin, float *const *out, bool *handled);
 int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
 
 #define DFE_HIP(ctx, expr)                                                              \

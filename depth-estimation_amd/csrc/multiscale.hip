@@ -579,7 +579,15 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     }
     hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
     DFE_LAUNCH_CHECK(ctx);
-    for (int s = 0; s < nratios; ++s) {
+    bool merged = false;
+    {
+        const float *f0[DFE_MAX_RATIOS], *f1[DFE_MAX_RATIOS];
+        float *vo[DFE_MAX_RATIOS];
+        for (int s = 0; s < nratios; ++s) { f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s]; }
+        rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, &merged);
+        if (rc) return rc;
+    }
+    for (int s = 0; s < nratios && !merged; ++s) {
         rc = cv_frames_dispatch(ctx, ps.p0[s], ps.p1[s], C, ps.Hp[s], ps.Wp[s], (long long)ps.Hp[s] * ps.Wp[s], k, k, maxh, maxw,
                                 (float *)ss.cost[s]);
         if (rc) return rc;

@@ -264,8 +264,8 @@ template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K;
 // values are still in registers when they are stored.  The wave minimum is a 6-step DPP reduction, the first-index
 // rule a ballot; the arithmetic added (~50 %) hides under the store stream that bounds this kernel.
 template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE>
-__global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
-                                                               float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
+__device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, const float *__restrict__ I1, float *__restrict__ out,
+                                                  const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0n = blockIdx.x * GX, y0n = blockIdx.y * TY;           // nominal origin
+    const int x0n = bx * GX, y0n = by * TY;                           // nominal origin
     const int x0 = min(x0n, p.Wo - GX), y0 = min(y0n, p.Ho - TY);      // shifted inwards at the frame edge
     const long long HW = p.plane;
 
@@ -417,6 +417,27 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
             }
         }
     }
+}
+
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE>
+__global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
+                                                               float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
+    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, FUSE>(I0, I1, out, p, fa, blockIdx.x, blockIdx.y);
+}
+
+// Several independent frame pairs in one launch (the pyramid scales of the multiscale matcher): blockIdx.z = pair.  The
+// coarser scales' grids are tiny (VGA scale 4: 30 blocks); launched one after the other each holds the GPU for ~13 us.
+struct CvTiledMulti {
+    const float *I0[DFE_MAX_RATIOS], *I1[DFE_MAX_RATIOS];
+    float *out[DFE_MAX_RATIOS];
+    CvTiledArgs p[DFE_MAX_RATIOS];
+    int gx[DFE_MAX_RATIOS], gy[DFE_MAX_RATIOS];
+};
+template <int C, int K, int TX, int NT, int NW, int NQ>
+__global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_multi_kernel(CvTiledMulti m) {
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= m.gx[z] || (int)blockIdx.y >= m.gy[z]) return;   // block-uniform
+    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false>(m.I0[z], m.I1[z], m.out[z], m.p[z], CvFuseArgs{}, blockIdx.x, blockIdx.y);
 }
 
 // geometry of one tiled launch
@@ -1140,6 +1161,56 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
         }
     }
     return launch_cv_rowimg_one<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, ty, out, fa, handled);
+}
+
+// the volumes of n independent frame pairs with windows of at most one chunk (C = 3, k = 7) in one launch; *handled = false
+// when some pair has no plan with the common block shape (the caller then launches them one by one)
+template <int NQ>
+static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, const int *H, const int *W,
+                                     int hWin, int wWin, float *const *out, bool *handled) {
+    constexpr int C = 3, K = 7, TX = 8, NT = 4, NW = 4;
+    CvTiledMulti m;
+    size_t lds = 0;
+    int gxm = 0, gym = 0;
+    for (int i = 0; i < n; ++i) {
+        const int Ho = H[i] - K + 1 - hWin + 1, Wo = W[i] - K + 1 - wWin + 1;
+        const CvTilePlan pl = plan_cv_tiled<C, K, TX, NT, NW>(NQ, Ho, Wo, hWin, wWin, ctx->ncu);
+        if (pl.score <= 0) return DFE_OK;
+        CvTiledArgs a;
+        a.plane = (long long)H[i] * W[i];
+        a.H = H[i]; a.W = W[i]; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
+        a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.seg_rows = 0; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
+        a.chunk0 = 0;
+        m.p[i] = a; m.I0[i] = I0[i]; m.I1[i] = I1[i]; m.out[i] = out[i];
+        m.gx[i] = dfe_cdiv(Wo, pl.GX); m.gy[i] = dfe_cdiv(Ho, pl.TY);
+        if (m.gx[i] > gxm) gxm = m.gx[i];
+        if (m.gy[i] > gym) gym = m.gy[i];
+        if (pl.lds_bytes > lds) lds = pl.lds_bytes;
+    }
+    auto kern = ssd_cv_tiled_multi_kernel<C, K, TX, NT, NW, NQ>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, dim3(gxm, gym, n), dim3(NW * 64), lds, ctx->stream, m);
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = "ssd_cv_tiled_kernel";
+    *handled = true;
+    return DFE_OK;
+}
+
+int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
+                             int hWin, int wWin, float *const *out, bool *handled) {
+    *handled = false;
+    if (ctx->cv_mode == 1 || ctx->cv_mode == 3 || C != 3 || k != 7 || hWin * wWin > 64 || n < 2 || n > DFE_MAX_RATIOS) return DFE_OK;
+    // the tile height that suits the largest pair (the first): 3 row groups unless forced / not applicable
+    const int nq = (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5) ? ctx->cv_tyq : 3;
+    switch (nq) {
+        case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
+        case 4: return launch_cv_tiled_multi_one<4>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
+        case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
+        default: return launch_cv_tiled_multi_one<3>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
+    }
 }
 
 // *nparts: planes of fa.part the launched kernel filled -- 2 (the row-image kernel scans a pixel's run in two halves)
