@@ -48,15 +48,17 @@ __device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, co
                                                 int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
 #pragma clang fp contract(off)
     const int Hs = H / r, Ws = W / r;
-    const long long total = (long long)C * Hp * Wp;
+    // 32-bit element indices (the launcher checks 2 * C * Hp * Wp < 2^31): with 64-bit div/mod per element this kernel
+    // spent most of its time dividing
+    const unsigned total = (unsigned)C * Hp * Wp;
     const float inv = 1.0f / (float)(r * r);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * total; e += (long long)gridDim.x * blockDim.x) {
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * total; e += gridDim.x * blockDim.x) {
         const bool second = e >= total;
-        const long long ee = second ? e - total : e;
+        const unsigned ee = second ? e - total : e;
         const float *img = second ? I1 : I0;
-        const int x = (int)(ee % Wp);
-        const long long t = ee / Wp;
-        const int y = (int)(t % Hp), c = (int)(t / Hp);
+        const unsigned t = ee / (unsigned)Wp;
+        const int x = (int)(ee - t * (unsigned)Wp);
+        const int c = (int)(t / (unsigned)Hp), y = (int)(t - (unsigned)c * Hp);
         const int sy = y - pt, sx = x - pl;
         float v = 0.f;
         if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
@@ -570,6 +572,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         ss.cost[s] = (float *)((char *)scr + off_v[s]);
         ss.prob[s] = (float *)((char *)scr + off_q[s]);
         ss.P[s] = (long long)Hs * Ws;
+        DFE_REQUIRE(ctx, 2ll * C * Hp * Wp < (1ll << 31), DFE_E_SHAPE, "dfe_multiscale_flow_pair_f32: frame too large");
         if (2ll * C * Hp * Wp > prep_max) prep_max = 2ll * C * Hp * Wp;
         if (ss.P[s] > soft_max) soft_max = ss.P[s];
         g.in[s] = ss.prob[s];
