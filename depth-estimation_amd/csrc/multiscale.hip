@@ -279,6 +279,10 @@ static dim3 cascade_fast_grid(int H, int W) {
 // wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
 // and decodes the winning class (x2yxMultiNumber).  Values are the same float sums in the same order, so the result is
 // bit-identical to cascade_ring -> argbest_center -> x2yx_multi.
+// SOFT0 (one-cell-per-lane path only): g.in[0] is the RAW scale-1 cost volume and its soft-min is taken here, with the
+// arithmetic of softmin_kernel (wave maximum, expf, wave sum in the same association order, e * (1 / sum)), so the scale-1
+// probabilities -- the largest tensor of the pipeline -- never make their round trip through HBM.
+template <bool SOFT0>
 __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom g, MultiGeom mg, int middle, long long *__restrict__ idx,
                                                                      float *__restrict__ best_out, float *__restrict__ fy,
                                                                      float *__restrict__ fx, int pitch, int pad_t, int pad_l) {
@@ -349,6 +353,17 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                 for (int s = 0; s < MAXS; ++s) {
                     const int xs = (int)(((float)x + 0.5f) * rinv[s]);
                     vin[i][s] = (s < g.nratios && lane < N) ? rowp[s][xs * N + lane] : 0.f;
+                }
+            }
+            if constexpr (SOFT0) {
+                const bool on = lane < N;
+#pragma unroll
+                for (int i = 0; i < NPX; ++i) {
+                    const float c = vin[i][0];
+                    const float m = wave_max_f32(on ? -c : -INFINITY);
+                    const float e = on ? expf(-c - m) : 0.f;
+                    const float sum = wave_sum_f32_ordered(e);
+                    vin[i][0] = on ? e * (1.0f / sum) : 0.f;
                 }
             }
             int key[NPX], bcls[NPX], cbits[NPX];
@@ -595,17 +610,33 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
                                 (float *)ss.cost[s]);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nratios), dim3(kWaves * 64), 0, ctx->stream, ss, N);
-    DFE_LAUNCH_CHECK(ctx);
+    // one-cell-per-lane path: the scale-1 soft-min happens inside the cascade kernel (SOFT0), the coarser scales' here
+    const bool fast = N <= 64 && nratios <= 5;
+    if (fast) {
+        g.in[0] = ss.cost[0];
+        ss.P[0] = 0;
+        soft_max = 0;
+        for (int s = 1; s < nratios; ++s)
+            if (ss.P[s] > soft_max) soft_max = ss.P[s];
+    }
+    if (soft_max > 0) {
+        hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nratios), dim3(kWaves * 64), 0, ctx->stream, ss, N);
+        DFE_LAUNCH_CHECK(ctx);
+    }
     g.H = H; g.W = W;
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
     size_t lds = (size_t)kWaves * 2 * N * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);
     dim3 grid(grid1d((long long)H * W, kWaves));
-    if (N <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);
-    hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
-                       flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+    if (fast) {
+        grid = cascade_fast_grid(H, W);
+        hipLaunchKernelGGL(cascade_argmax_kernel<true>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
+                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+    } else {
+        hipLaunchKernelGGL(cascade_argmax_kernel<false>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
+                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+    }
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }
@@ -668,7 +699,7 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);   // fast path: class -> displacement table
     dim3 grid(grid1d((long long)H * W, kWaves));
     if (maxh * maxw <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);   // fast path: one row per blockIdx.y
-    hipLaunchKernelGGL(cascade_argmax_kernel, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
+    hipLaunchKernelGGL(cascade_argmax_kernel<false>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
                        (long long *)idx, best, flow_y, flow_x, W, 0, 0);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
