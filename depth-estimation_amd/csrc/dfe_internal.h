@@ -103,9 +103,12 @@ struct CvFuseArgs {
     int cmid, lmid;        // chunk / lane of the centre cell
     int row_off;           // output-row offset of this launch inside the pair
 };
+// frame mode of dfe_flow_finalize (one band only): finalize also zeroes the frame border and makes depth / confidence
+struct DfePairDepth { int H, W; float cx, cy; float *depth, *conf; };
 int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
-                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded);
+                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
+                      const struct DfePairDepth *pd = nullptr);
 int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
                           float cy, float *depth, float *conf);
 int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,

@@ -181,7 +181,31 @@ struct TailOut {
     int padded;          // scores addressed full-frame (1) or [P] (0)
     long long p_off;     // pixel offset of this band inside the [P] outputs
     int row_off;         // output-row offset of this band
+    // frame mode (flow_finalize_kernel, one band only): the threads cover the whole H x W frame -- interior pixels run the
+    // pipeline's tail and the flow -> depth formula, border pixels are zeroed -- so the pair step needs no third launch
+    int frame_H, frame_W;     // 0 = off
+    float *depth, *conf;      // [H][W] or null
+    float mw, mh, infty;      // focus of expansion, depth clamp (test_opticalflow.lua:143-216)
 };
+
+// flow -> depth of one pixel (i, j) with displacement (dy, dx): the quirk-preserving cartesian formula of
+// test_opticalflow.lua:143-216 (same arithmetic as flow_to_depth_cartesian_kernel)
+__device__ __forceinline__ void pair_depth_px(int i, int j, float dy, float dx, float mw, float mh, float infty, float *r_out, float *c_out) {
+    const float py = (float)i - mh, px = (float)j - mw;
+    const float pn = (float)sqrt((double)(px * px + py * py));
+    const float dn = (float)sqrt((double)(dx * dx + dy * dy));
+    float r = 0.f, c = 0.f;
+    if (dn >= 0.2f) {
+        const float q = pn / dn;
+        r = q < infty ? q : infty;
+        if (px * dx + dy * dy > 0.125f) c = 1.0f;   // test_opticalflow.lua:181 (sic)
+    } else {
+        c = 1.0f;
+        r = infty;
+    }
+    *r_out = r;
+    *c_out = c;
+}
 
 // Finishes what the fused cost-volume epilogue started; one thread per pixel, everything it normally reads is compact
 // and coalesced (8*nchunks + 4 + 64 bytes per pixel):
@@ -195,7 +219,23 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
                                                             const float *__restrict__ lead, int nchunks, long long Ptot,
                                                             const float *__restrict__ vol, long long Pband, int N, int hWin,
                                                             int wWin, int middle, double threshold, TailOut o) {
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < Pband; p += (long long)gridDim.x * blockDim.x) {
+    const long long nthreads_work = o.frame_H ? (long long)o.frame_H * o.frame_W : Pband;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nthreads_work; q += (long long)gridDim.x * blockDim.x) {
+        long long p = q;
+        int fi = 0, fj = 0;
+        if (o.frame_H) {
+            fi = (int)((unsigned)q / (unsigned)o.frame_W);
+            fj = (int)((unsigned)q - (unsigned)fi * (unsigned)o.frame_W);
+            const int iy = fi - o.pad_t, ix = fj - o.pad_l;
+            if (iy < 0 || ix < 0 || ix >= o.Wo || (long long)iy * o.Wo + ix >= Pband) {   // border pixel
+                o.fy[q] = 0.f;
+                o.fx[q] = 0.f;
+                if (o.scores) o.scores[q] = 0.f;
+                if (o.depth) pair_depth_px(fi, fj, 0.f, 0.f, o.mw, o.mh, o.infty, &o.depth[q], &o.conf[q]);
+                continue;
+            }
+            p = (long long)iy * o.Wo + ix;
+        }
         const long long pg = o.p_off + p;
         float2 b = part[pg];
         for (int c0 = 1; c0 < nchunks; c0 += 6) {   // six loads in flight, compared in chunk order (first chunk wins ties)
@@ -214,8 +254,10 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
         const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
         const long long fo = (long long)(y + o.pad_t) * o.pitch + x + o.pad_l;
         const long long fl = (id - 1) / wWin;
-        if (o.fy) o.fy[fo] = (float)(fl - (hWin - 1) / 2);
-        if (o.fx) o.fx[fo] = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
+        const float dyf = (float)(fl - (hWin - 1) / 2), dxf = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
+        if (o.fy) o.fy[fo] = dyf;
+        if (o.fx) o.fx[fo] = dxf;
+        if (o.frame_H && o.depth) pair_depth_px(fi, fj, dyf, dxf, o.mw, o.mh, o.infty, &o.depth[fo], &o.conf[fo]);
         if (o.scores) {
             float hv[M], hi[M];
 #pragma unroll
@@ -390,22 +432,7 @@ __global__ void pair_border_depth_kernel(float *__restrict__ flow, float *__rest
             flow[p] = 0.f; flow[P + p] = 0.f;
             if (scores) scores[p] = 0.f;
         }
-        if (depth) {
-            const float py = (float)i - mh, px = (float)j - mw;
-            const float pn = (float)sqrt((double)(px * px + py * py));
-            const float dn = (float)sqrt((double)(dx * dx + dy * dy));
-            float r = 0.f, c = 0.f;
-            if (dn >= 0.2f) {
-                const float q = pn / dn;
-                r = q < infty ? q : infty;
-                if (px * dx + dy * dy > 0.125f) c = 1.0f;   // test_opticalflow.lua:181 (sic)
-            } else {
-                c = 1.0f;
-                r = infty;
-            }
-            depth[p] = r;
-            conf[p] = c;
-        }
+        if (depth) pair_depth_px(i, j, dy, dx, mw, mh, infty, &depth[p], &conf[p]);
     }
 }
 
@@ -437,15 +464,21 @@ int grid_for(long long n, int block) {
 
 int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
-                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded) {
+                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
+                      const DfePairDepth *pd) {
     TailOut o;
+    o.frame_H = 0; o.frame_W = 0; o.depth = nullptr; o.conf = nullptr; o.mw = o.mh = o.infty = 0.f;
+    if (pd) {   // frame mode: this call owns the whole frame (one band), fy / fx / scores are full-frame planes
+        o.frame_H = pd->H; o.frame_W = pd->W; o.depth = pd->depth; o.conf = pd->conf;
+        o.mw = pd->cx; o.mh = pd->cy; o.infty = (float)((double)pd->W / 2);   // test_opticalflow.lua:148 geometry.wImg/2
+    }
     o.idx = (long long *)idx; o.best = best; o.fy = fy; o.fx = fx; o.scores = scores; o.imaxs = (long long *)imaxs;
     o.Wo = Wo; o.pitch = pitch; o.pad_t = pad_t; o.pad_l = pad_l; o.padded = scores_padded;
     o.p_off = (long long)row_off * Wo; o.row_off = row_off;
     const long long Pb = (long long)rows * Wo;
     const int N = hWin * wWin;
     const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);
-    const int grid = grid_for(Pb, 256);
+    const int grid = grid_for(pd ? (long long)pd->H * pd->W : Pb, 256);
     if (threshold < 0.2)   // extract_output.cpp:83-85
         hipLaunchKernelGGL(flow_finalize_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
                            hWin, wWin, middle, threshold, o);

@@ -1299,7 +1299,7 @@ static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D) {
 // Fallback (shapes without a fused instantiation): build, then the full pass dfe_flow_tail.
 static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin,
                          double thr, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int pitch,
-                         int pad_t, int pad_l, int scores_padded) {
+                         int pad_t, int pad_l, int scores_padded, const DfePairDepth *pd = nullptr, bool *pd_done = nullptr) {
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
     const int D = hWin * wWin, nch = (D + 63) / 64;
     const long long P = (long long)Ho * Wo;
@@ -1333,8 +1333,11 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
             if (rc) return rc;
         }
         if (fused) {
+            // one band: the finalize launch also zeroes the frame border and makes depth (pair step: 2 launches instead of 3)
+            const bool frame_mode = pd && nr == Ho;
             rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nparts, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
-                                   imaxs, pitch, pad_t, pad_l, scores_padded);
+                                   imaxs, pitch, pad_t, pad_l, scores_padded, frame_mode ? pd : nullptr);
+            if (frame_mode && pd_done) *pd_done = true;
         } else {
             rc = cv_frames_dispatch(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, kw, hWin, wWin, vol);
             if (rc) return rc;
@@ -1377,9 +1380,12 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     //   == radial/radial_opticalflow_groundtruth.lua:27-32 floor((hWin-1)/2)+floor((k-1)/2)
     const int pad_t = (H - Ho) / 2, pad_l = (W - Wo) / 2;
     // the pipeline writes every interior pixel of flow / scores; one pass afterwards zeroes the border and makes depth
+    const DfePairDepth pd{H, W, foe_x, foe_y, depth, depth_conf};
+    bool pd_done = false;
     int rc = flow_pipeline(ctx, I0, I1, C, H, W, k, k, hWin, wWin, extract_threshold, nullptr, nullptr, flow, flow + HW, scores, nullptr,
-                           W, pad_t, pad_l, 1);
-    if (rc) return rc;
+                           W, pad_t, pad_l, 1, &pd, &pd_done);
+    if (rc || pd_done) return rc;
+    // several bands, or no fused build for this shape: one pass afterwards zeroes the border and makes depth
     return dfe_pair_border_depth(ctx, flow, scores, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
 }
 
