@@ -168,6 +168,12 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 #ifndef DFE_ABLATE
 #define DFE_ABLATE 0
 #endif
+#ifndef DFE_NQW
+// waves that share the 17th chunk of a 33 x 33 window.  Measured at VGA: 8 waves x 1 column (shorter critical path, but 7
+// squared differences per output instead of 4) 0.3124 / 0.2529 ms fused / unfused against 0.3079 / 0.2407 ms for 4 x 2;
+// 2 waves x 4 columns spill (24 registers of ring state).
+#define DFE_NQW 4
+#endif
 #ifndef DFE_ST_FLAGS
 // cache-policy bits of the copy-out stores.  The volume streams out and nothing re-reads it from L2: with the non-temporal
 // hint the build measures 268 instead of 285 us at VGA and the step's finalize pass finds its planes still cached
@@ -583,7 +589,8 @@ static int launch_cv_tiled_fused(dfe_ctx *ctx, const float *I0, const float *I1,
 //   * wave w sweeps chunk w (cells 64w..64w+63) exactly like a tiled-kernel task;
 //   * cells 1024..1087 (a 17th chunk that has no wave) are swept as four 2-column quarter tasks by waves 0..3 -- one
 //     per SIMD, so the extra work (0.46 of a task each) stays balanced -- with 12 extra registers of box-filter state;
-//   * cells >= 1088 (one at 33x33, at most 8) are a lane-per-(cell, column) mini task of wave 4.
+//   * cells >= 1088 (one at 33x33, at most 8) are a lane-per-(cell, column) mini task of wave 4 (the first without a
+//     quarter task).
 // Frame-0 values: the tiled kernel's scalar loads go through L2, and behind this kernel's store stream their latency
 // (waited for before every barrier) serialised compute with the copy-out (345 us -> 240 us without them).  Here the
 // frame-0 tile sits in LDS as well; once per row each lane reads the pixel of column (lane & 15), and the subtract
@@ -685,9 +692,10 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     constexpr int R0 = 8;                        // column sweep: rows of the frame-0 ring
     constexpr int LW = NW - 1;                   // column sweep: the wave that streams the tiles and never stores
     constexpr int NE = TX + K - 1;
-    constexpr int TQ = TX / 4;                   // columns of a quarter task
+    constexpr int NQW = DFE_NQW;                 // waves that carry a share of the 17th chunk (tuning: 4 or 8)
+    constexpr int TQ = TX / NQW;                 // columns of such a share ("quarter task")
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
-    static_assert(TX % 4 == 0, "four quarter tasks");
+    static_assert(TX % NQW == 0, "whole columns per quarter task");
     px_t *lds = reinterpret_cast<px_t *>(dfe_smem);                             // frame-1 tile [lrows][pitch]
     const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + p.tile0_off);    // frame-0 tile [ROWS][32]
     float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);          // [2][stage_len], 128-B aligned
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             return lds + packed + r * p.pitch;
     };
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
-    const bool has_q = wave < 4 && D > 1024 && !(DFE_ABLATE & 8192);      // wave-uniform
+    const bool has_q = wave < NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
     const int dq = 1024 + lane;
     const bool validq = dq < D;
     int lpq;
@@ -780,7 +788,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         lpq = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane
-    const bool has_m = wave == 4 && D > 1088 && !(DFE_ABLATE & 8192);     // wave-uniform
+    constexpr int MW = NQW;                      // the mini task's wave: the first one without a quarter task
+    const bool has_m = wave == MW && D > 1088 && !(DFE_ABLATE & 8192);    // wave-uniform
     const int dm = 1088 + (lane >> 3), xm = lane & 7;
     const bool validm = dm < D && xm < TX;
     int lpm;
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         for (int x = 0; x < TX; ++x) ring[i][x] = 0.f;
 #pragma unroll
         for (int x = 0; x < TQ; ++x) ringq[i][x] = 0.f;
-        if (wave == 4) rm[i * 64] = 0.f;
+        if (wave == MW) rm[i * 64] = 0.f;
     }
 
     const int nq = (nsweep + U - 1) / U;
