@@ -30,6 +30,7 @@ WORKLOADS = {
     "vga": (480, 640, 3, 7, 33, 33),
     "720p": (720, 1280, 3, 7, 33, 33),
     "1080p": (1080, 1920, 3, 7, 33, 33),
+    "vga-luma": (480, 640, 1, 7, 33, 33),   # luminance frames (C = 1)
 }
 # BASELINE.json configs[1] literally: 640x480, 3-level pyramid {1,2,4}, 7x7 patch, 8x8 window per scale (= +-16 at the
 # coarsest scale), through dfe_multiscale_flow_pair_f32.  Not the default: the north-star roofline target is stated for

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
             if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
-                px_t a;
+                px_t a{};
                 if constexpr (!SM) a = t0[t0r + l16];
                 float v[TX];
                 rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
@@ -1231,8 +1231,9 @@ int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int
     *nparts = (hWin * wWin + 63) / 64;
     if (ctx->cv_mode == 1) return DFE_OK;
     if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
-    if ((ctx->cv_mode == 0 || ctx->cv_mode == 3) && C == 3 && k == 7) {
-        int rc = launch_cv_rowimg<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled);
+    if ((ctx->cv_mode == 0 || ctx->cv_mode == 3) && (C == 3 || C == 1) && k == 7) {
+        int rc = C == 3 ? launch_cv_rowimg<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled)
+                        : launch_cv_rowimg<1, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled);
         if (*handled) *nparts = 2;
         if (rc != DFE_OK || *handled) return rc;
     }
@@ -1249,9 +1250,10 @@ int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int
 int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                               int kw, int hWin, int wWin, float *out) {
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
-    if ((ctx->cv_mode == 3 || ctx->cv_mode == 0) && kh == kw && C == 3 && kh == 7) {
+    if ((ctx->cv_mode == 3 || ctx->cv_mode == 0) && kh == kw && (C == 3 || C == 1) && kh == 7) {
         bool handled = false;
-        int rc = launch_cv_rowimg<3, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, nullptr, &handled);
+        int rc = C == 3 ? launch_cv_rowimg<3, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, nullptr, &handled)
+                        : launch_cv_rowimg<1, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, out, nullptr, &handled);
         if (rc != DFE_OK || handled) return rc;
         if (ctx->cv_mode == 3)
             return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no row-image cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);

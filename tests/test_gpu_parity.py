@@ -118,6 +118,26 @@ def test_cost_volume_rowimg_kernel_bit_exact(dfe, cuda, nq, H, W):
     assert np.array_equal(out.cpu().numpy(), cpu)
 
 
+@pytest.mark.parametrize("nq", [0, 1, 5])
+def test_cost_volume_rowimg_kernel_luminance_bit_exact(dfe, cuda, nq):
+    # the row-image kernel's C = 1 instantiation (auto / column sweep / static 24-row tiles) against the oracle
+    H, W = 131, 90
+    f0, f1, _, _ = rp.synth_pair(H, W, C=1, seed=nq, max_flow=9)
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_kernel(3)
+    ctx.set_cost_volume_tile(nq)
+    try:
+        out = torch.full(cpu.shape, -1.0, device=cuda)
+        t0, t1 = T(f0, cuda), T(f1, cuda)
+        ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 1, H, W, 7, 7, 33, 33, out.data_ptr()))
+        assert ctx.last_kernel() == "ssd_cv_rowimg_kernel"
+    finally:
+        ctx.set_cost_volume_kernel(0)
+        ctx.set_cost_volume_tile(0)
+    assert np.array_equal(out.cpu().numpy(), cpu)
+
+
 def test_cost_volume_tiled_float_frames_within_tolerance(dfe, cuda):
     f0, f1, _, _ = rp.synth_pair(80, 100, C=3, seed=2, integer=False)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
@@ -427,6 +447,7 @@ def test_golden_fixtures_on_gpu(dfe, cuda):
     "H,W,win,C,thr",
     [
         (96, 128, 33, 3, 0.21),    # row-image kernel, tiles divide the frame
+        (90, 100, 33, 1, 0.21),    # row-image kernel on luminance frames
         (75, 80, 33, 3, 0.21),     # last tile row / column shifted inwards; 37 output rows -> 18-row tiles
         (131, 90, 33, 3, 0.11),    # M = 8
         (64, 50, 33, 3, 0.21),     # Wo = 12, Ho = 26
@@ -449,7 +470,7 @@ def test_flow_depth_pair_matches_oracle(dfe, cuda, H, W, win, C, thr):
     ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, thr,
                                                flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), conf.data_ptr()))
     name = ctx.last_kernel()
-    assert name == ("ssd_cv_rowimg_kernel+fused_tail" if (win == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"), name
+    assert name == ("ssd_cv_rowimg_kernel+fused_tail" if win == 33 else "ssd_cv_tiled_kernel+fused_tail"), name
     eflow = ref["flowp"][:2]
     assert np.array_equal(flow.cpu().numpy(), eflow)
     assert np.array_equal(scores.cpu().numpy(), ref["flowp"][3])
