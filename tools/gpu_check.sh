@@ -22,5 +22,5 @@ which luajit lua th >> gpurun_out/device.log 2>&1
 step pytest_gpu 900 python -m pytest tests -m gpu -q -x
 step smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
 step bench 600 python bench.py
-step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline
+step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline
 find gpurun_out/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -20
