@@ -138,6 +138,45 @@ def test_cost_volume_rowimg_kernel_luminance_bit_exact(dfe, cuda, nq):
     assert np.array_equal(out.cpu().numpy(), cpu)
 
 
+@pytest.mark.parametrize("H,W,C", [(75, 47, 3), (131, 90, 3), (90, 100, 1)])
+def test_float_frames_deterministic_and_within_tolerance(dfe, cuda, H, W, C):
+    """Float frames: edge tiles are shifted inwards and overlap their neighbours, i.e. two blocks store the same pixels --
+    every kernel gives a pixel the same association of adds whatever the tiling, so every mode has to return the same
+    bits on every run, stay within tolerance of the oracle, and the fused pipeline's indices have to match the oracle's
+    wherever the minimum is unique."""
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=C, seed=H + C, integer=False, max_flow=9)
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    for mode, tile in ((0, 0), (3, 1), (3, 4), (2, 0)):
+        ctx.set_cost_volume_kernel(mode)
+        ctx.set_cost_volume_tile(tile)
+        try:
+            outs = []
+            for _ in range(3):
+                out = torch.full(cpu.shape, -1.0, device=cuda)
+                ctx.check(dfe.lib().dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, 7, 7, 33, 33, out.data_ptr()))
+                outs.append(out)
+        finally:
+            ctx.set_cost_volume_kernel(0)
+            ctx.set_cost_volume_tile(0)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (mode, tile)
+        assert cost_close(outs[0].cpu().numpy(), cpu).all(), (mode, tile)
+    # fused pipeline, three runs: identical, and consistent with the unfused volume of the same kernel family
+    res = []
+    for _ in range(3):
+        Ho, Wo = cpu.shape[:2]
+        idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+        best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
+        ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, 7, 7, 33, 33, 0.21,
+                                            idx.data_ptr(), best.data_ptr(), None, None, None, None))
+        res.append((idx, best))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+    mid = rp.middle_index(33, 33)
+    idx_cpu, _ = orc.argbest_center(cpu.reshape(cpu.shape[0], cpu.shape[1], -1), mid, False)
+    assert tie_aware_equal(res[0][0].cpu().numpy(), idx_cpu, cpu).all()
+
+
 def test_cost_volume_tiled_float_frames_within_tolerance(dfe, cuda):
     f0, f1, _, _ = rp.synth_pair(80, 100, C=3, seed=2, integer=False)
     cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
