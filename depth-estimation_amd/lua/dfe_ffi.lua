@@ -6,32 +6,59 @@ local ffi = require 'ffi'
 
 ffi.cdef[[
 typedef struct dfe_ctx dfe_ctx;
+int dfe_version(void);
 int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out);
 void dfe_ctx_destroy(dfe_ctx *ctx);
 const char *dfe_last_error(const dfe_ctx *ctx);
 int dfe_ctx_synchronize(dfe_ctx *ctx);
+void *dfe_ctx_stream(dfe_ctx *ctx);
 int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr);
 int dfe_free(dfe_ctx *ctx, void *dptr);
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
-int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
-                            int kh, int kw, int hWin, int wWin, float *out);
-int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
-                             int W1, int maxh, int maxw, float *out);
-int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
-                            int W, int hWin, float *out);
-int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int middle, int take_max,
-                       int64_t *idx, float *best);
-int dfe_extract_output(dfe_ctx *ctx, const float *input, int H, int W, int N, float *scores,
-                       double threshold, int64_t *imaxs);
-int dfe_extract_output_marginalized(dfe_ctx *ctx, const float *input, int H, int W, int N,
-                                    double threshold, double threshold_acc, int64_t *ret, int64_t *retgd);
-int dfe_x2yx_multi(dfe_ctx *ctx, int maxh, int maxw, const int *ratios, int nratios,
-                   const int64_t *idx, int64_t P, int64_t *y, int64_t *x, int compat_c);
-int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
-                            int k, int hWin, int wWin, float foe_x, float foe_y,
-                            double extract_threshold, float *flow, float *scores, float *depth,
-                            float *depth_conf);
+int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
+int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
+const char *dfe_last_kernel(const dfe_ctx *ctx);
+int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
+int dfe_profile_enable(dfe_ctx *ctx, int on);
+int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
+int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float *out);
+int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
+int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W, int hWin, float *out);
+int dfe_spatial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W1, int maxh, int maxw, float *gradIn1, float *gradIn2);
+int dfe_radial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W, int hWin, float *gradIn1, float *gradIn2);
+int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int middle, int take_max, int64_t *idx, float *best);
+int dfe_extract_output(dfe_ctx *ctx, const float *input, int H, int W, int N, float *scores, double threshold, int64_t *imaxs);
+int dfe_extract_output_marginalized(dfe_ctx *ctx, const float *input, int H, int W, int N, double threshold, double threshold_acc, int64_t *ret, int64_t *retgd);
+int dfe_x2yx(dfe_ctx *ctx, const int64_t *idx, int64_t P, int maxh, int maxw, int64_t *y, int64_t *x);
+int dfe_x2yx_multi(dfe_ctx *ctx, int maxh, int maxw, const int *ratios, int nratios, const int64_t *idx, int64_t P, int64_t *y, int64_t *x, int compat_c);
+int64_t dfe_yx2x_multi(int maxh, int maxw, const int *ratios, int nratios, double y, double x);
+int dfe_x2yx_multi_number(int maxh, int maxw, const int *ratios, int nratios, int64_t id, int64_t *y, int64_t *x);
+int64_t dfe_multi_nclasses(int maxh, int maxw, const int *ratios, int nratios);
+int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, double extract_threshold, int64_t *idx, float *best, float *flow_y, float *flow_x, float *scores, int64_t *imaxs);
+int dfe_flow_tail(dfe_ctx *ctx, const float *vol, int rows, int Wo, int hWin, int wWin, double threshold, int row_off, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded);
+int dfe_flow_to_depth_cartesian(dfe_ctx *ctx, const float *flow, int H, int W, float cx, float cy, int fix_dot, float *depth, float *conf);
+int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, double extract_threshold, float *flow, float *scores, float *depth, float *depth_conf);
+int dfe_downsample_box_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, int r, float *out);
+int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int r, int kh, int kw, int maxh, int maxw, float *out);
+int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob);
+int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *out);
+int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, int64_t *idx, float *best, float *flow_y, float *flow_x);
+int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
+int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *gradIn);
+int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, float *out);
+int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, int lpadding, int rpadding, float rmax, float alpha, float *mask);
+int dfe_polar_grid_p2c_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, float rmax, float alpha, float *mask);
+int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const float *mask, int Hd, int Wd, float *out);
+int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, float xcenter, float ycenter, float infty, float *depth, float *conf);
+int dfe_flow_to_depth_ardrone(dfe_ctx *ctx, const float *xflow, const float *mask, int H, int W, float imu_tx, float *depth, float *conf);
+int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask, int H, int W, int winsize, int method, float *out);
+int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy);
+int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw, float *x, float *y);
+int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
+int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
+int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
+int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out);
 ]]
 
 local M = {}

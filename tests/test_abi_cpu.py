@@ -33,6 +33,17 @@ def test_header_symbols_exported_and_bound(dfe):
     assert exported - set(syms) == set(), "exported but undeclared: %s" % (exported - set(syms))
 
 
+def test_lua_ffi_binding_declares_the_whole_abi():
+    """The LuaJIT-FFI stub a maintainer adds on the reference side declares every entry point of
+    include/dfe.h, and its cdef block is the one tools/gen_lua_cdef.py derives from the header (no drift)."""
+    lua = open(os.path.join(PKG, "lua", "dfe_ffi.lua")).read()
+    cdef = lua[lua.index("ffi.cdef[[") : lua.index("]]")]
+    for s in declared_symbols():
+        assert re.search(r"\b%s\s*\(" % s, cdef), "dfe_ffi.lua does not declare %s" % s
+    rc = subprocess.run(["python", os.path.join(ROOT, "tools", "gen_lua_cdef.py"), "--check"]).returncode
+    assert rc == 0, "dfe_ffi.lua is out of date: run tools/gen_lua_cdef.py"
+
+
 def test_library_is_gfx950_only():
     from depth_estimation_amd import _lib
 
