@@ -1,0 +1,74 @@
+-- Drop-in for the reference's nn.CascadingAddTable on the MI355X path (UNTESTED here: no Lua runtime in the build image).
+-- Same constructor (ratios, trainable, single_beta), same updateOutput(table of (H*W) x Kh x Kw tensors) -> table of the
+-- same shapes, same error texts for the shape checks (CascadingAddTable.lua:108-135); updateGradInput follows :137-154.
+-- HEAD's graph has no trainable parameter, so accGradParameters stays a no-op and `trainable` must be false.
+local dfe = require 'dfe_ffi'
+local ffi = require 'ffi'
+local CascadingAddTable, parent = torch.class('nn.CascadingAddTable', 'nn.Module')
+
+function CascadingAddTable:__init(ratios, trainable, single_beta)
+   parent.__init(self)
+   assert(not trainable, 'nn.CascadingAddTable (dfe): the trainable variant is not part of the accelerated path')
+   self.ratios = ratios
+   self.output = {}
+   self.gradInput = {}
+   for i = 1, #ratios do
+      self.output[i] = torch.FloatTensor()
+      self.gradInput[i] = torch.FloatTensor()
+   end
+   self.cratios = ffi.new('int[?]', #ratios, ratios)
+end
+
+local function check_inputs(self, input)
+   for i = 1, #input do
+      if input[i]:nDimension() ~= 3 then
+         error('nn.CascadingAddTable: input must be a table of 3D-tensors (HxW) x Kh x Kw')
+      end
+   end
+   if #input ~= #self.ratios then
+      error('nn.CascadingAddTable: input and ratios must have the same size')
+   end
+   for i = 1, #input - 1 do
+      local r, r2 = self.ratios[i], self.ratios[i + 1]
+      if (math.fmod(input[i]:size(2) * (r2 - r), 2 * r2) ~= 0) or (math.fmod(input[i]:size(3) * (r2 - r), 2 * r2) ~= 0) then
+         error('nn.CascadingAddTable: ratios and input sizes not compatible')
+      end
+   end
+end
+
+-- runs one of the two C entry points over a table of tensors: stage, call, fetch, free
+local function run(self, fn, src, dst)
+   local n = #src
+   local P, maxh, maxw = src[1]:size(1), src[1]:size(2), src[1]:size(3)
+   local din, dout = ffi.new('const float*[?]', n), ffi.new('float*[?]', n)
+   local held = {}
+   for i = 1, n do
+      local p = dfe.upload(src[i])
+      din[i - 1] = ffi.cast('const float*', p)
+      local q = ffi.new('void*[1]')
+      dfe.check(dfe.lib.dfe_malloc(dfe.ctx, src[i]:nElement() * 4, q))
+      dout[i - 1] = ffi.cast('float*', q[0])
+      held[#held + 1] = p
+      held[#held + 1] = q[0]
+   end
+   dfe.check(fn(dfe.ctx, din, self.cratios, n, P, maxh, maxw, dout))
+   for i = 1, n do
+      dst[i]:resizeAs(src[i])
+      dfe.download(dst[i], dout[i - 1])
+   end
+   for _, p in ipairs(held) do dfe.free(p) end
+end
+
+function CascadingAddTable:updateOutput(input)
+   check_inputs(self, input)
+   run(self, dfe.lib.dfe_cascading_add_f32, input, self.output)
+   return self.output
+end
+
+function CascadingAddTable:updateGradInput(input, gradOutput)
+   run(self, dfe.lib.dfe_cascading_add_backward_f32, gradOutput, self.gradInput)
+   return self.gradInput
+end
+
+function CascadingAddTable:accGradParameters(input, gradOutput, scale)
+end
