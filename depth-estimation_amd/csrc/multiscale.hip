@@ -266,26 +266,35 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_backward_kernel(CascadeGe
     }
 }
 
-// launch shape of cascade_argmax_kernel's one-cell-per-lane path: a wave takes 8 adjacent pixels per step and 4 steps of
-// its row, a block of kWaves waves one row (measured at VGA: 1 / 2 / 4 steps per wave 0.2125 / 0.192 / 0.187 ms per pair;
-// blocks that walk down several rows instead 0.203 ms)
+// launch shape of cascade_argmax_kernel's one-cell-per-lane path: a wave takes 8 adjacent pixels per step, a block of kWaves
+// waves one row; 2 steps per wave while that keeps the grid under ~8k blocks, else 4 (measured: VGA 1 / 2 / 4 steps ->
+// 0.1507 / 0.142 / 0.1456 ms per pair, 1080p 2 / 4 steps -> 0.973 / 0.933 ms; blocks that walk down several rows
+// instead measured slower)
 static dim3 cascade_fast_grid(int H, int W) {
-    const int gx = (W + kWaves * 8 * 4 - 1) / (kWaves * 8 * 4);
+    int spw = 2;
+    if ((long long)((W + kWaves * 8 * spw - 1) / (kWaves * 8 * spw)) * H > 8192) spw = 4;
+    const int gx = (W + kWaves * 8 * spw - 1) / (kWaves * 8 * spw);
     return dim3((unsigned)gx, (unsigned)H);
 }
 
-// A4 + A5 + A6 + A10 in one pass: cascade coarse -> fine exactly like cascade_kernel<true>, but instead of writing the
-// joined [H][W][ncls] tensor the wave keeps the running arg-max over the classes it would have written (first maximum
-// wins = smallest class id among equal values, opticalflow_model.lua:153-161 via TH max), applies the centre tie-break
-// and decodes the winning class (x2yxMultiNumber).  Values are the same float sums in the same order, so the result is
-// bit-identical to cascade_ring -> argbest_center -> x2yx_multi.
+// class id -> decoded displacement, (oy << 16) | (ox & 0xffff), for the one-cell-per-lane path (at most 5 scales of <= 64 cells)
+constexpr int kMaxDecode = 5 * 64;
+struct DecodeTab { int v[kMaxDecode]; };
+static void fill_decode_tab(const MultiGeom &mg, int ncls, DecodeTab &dt) {
+    for (int c = 0; c < ncls && c < kMaxDecode; ++c) {
+        long long oy = 0, ox = 0;
+        multi_decode(mg, c + 1, &oy, &ox);
+        dt.v[c] = (int)((unsigned)((int)oy << 16) | ((unsigned)(int)ox & 0xffffu));
+    }
+}
+
 // SOFT0 (one-cell-per-lane path only): g.in[0] is the RAW scale-1 cost volume and its soft-min is taken here, with the
 // arithmetic of softmin_kernel (wave maximum, expf, wave sum in the same association order, e * (1 / sum)), so the scale-1
 // probabilities -- the largest tensor of the pipeline -- never make their round trip through HBM.
 template <bool SOFT0>
 __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom g, MultiGeom mg, int middle, long long *__restrict__ idx,
                                                                      float *__restrict__ best_out, float *__restrict__ fy,
-                                                                     float *__restrict__ fx, int pitch, int pad_t, int pad_l) {
+                                                                     float *__restrict__ fx, int pitch, int pad_t, int pad_l, DecodeTab dt) {
     extern __shared__ float sh[];
     const int N = g.maxh * g.maxw;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -327,13 +336,8 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
         // that the minimum is the maximum value); the smallest class among the lanes holding a column's maximum comes
         // from a second butterfly; lanes 0..7 then finish one pixel each and store together.
         constexpr int NPX = 8, MAXS = 5;
-        int2 *tab = reinterpret_cast<int2 *>(sh);             // [ncls] (oy, ox); the cur/prev buffers are not used on this path
-        for (int c = threadIdx.x; c < g.ncls; c += blockDim.x) {
-            int oy = 0, ox = 0;
-            multi_decode_t<int>(mg, c + 1, &oy, &ox);
-            tab[c] = make_int2(oy, ox);
-        }
-        __syncthreads();
+        // class -> displacement: a table the host built once per launch, passed by value (kernel arguments live in constant
+        // memory): no per-block rebuild, no barrier on this path
         const int mlane = (middle - 1) & 63;
         const int y = blockIdx.y;
         const float *rowp[MAXS];
@@ -406,10 +410,10 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                 if (idx) idx[p] = id;
                 if (best_out) best_out[p] = wmax;
                 if (fy) {
-                    const int2 d = tab[id - 1];
+                    const int d = dt.v[id - 1];                         // (oy << 16) | (ox & 0xffff)
                     const long long fo = (long long)(y + pad_t) * pitch + x + pad_l;
-                    fy[fo] = (float)d.x;
-                    fx[fo] = (float)d.y;
+                    fy[fo] = (float)(d >> 16);
+                    fx[fo] = (float)(short)(d & 0xffff);
                 }
             }
         }
@@ -629,13 +633,15 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);
     dim3 grid(grid1d((long long)H * W, kWaves));
+    DecodeTab dt;
+    fill_decode_tab(mg, g.ncls, dt);
     if (fast) {
         grid = cascade_fast_grid(H, W);
         hipLaunchKernelGGL(cascade_argmax_kernel<true>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
-                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0, dt);
     } else {
         hipLaunchKernelGGL(cascade_argmax_kernel<false>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
-                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0);
+                           flow, flow ? flow + (size_t)H * W : nullptr, W, 0, 0, dt);
     }
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
@@ -699,8 +705,10 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);   // fast path: class -> displacement table
     dim3 grid(grid1d((long long)H * W, kWaves));
     if (maxh * maxw <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);   // fast path: one row per blockIdx.y
+    DecodeTab dt;
+    fill_decode_tab(mg, g.ncls, dt);
     hipLaunchKernelGGL(cascade_argmax_kernel<false>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
-                       (long long *)idx, best, flow_y, flow_x, W, 0, 0);
+                       (long long *)idx, best, flow_y, flow_x, W, 0, 0, dt);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }
