@@ -279,7 +279,35 @@ static dim3 cascade_fast_grid(int H, int W) {
 
 // class id -> decoded displacement, (oy << 16) | (ox & 0xffff), for the one-cell-per-lane path (at most 5 scales of <= 64 cells)
 constexpr int kMaxDecode = 5 * 64;
-struct DecodeTab { int v[kMaxDecode]; };
+struct DecodeTab {
+    int v[kMaxDecode];
+    unsigned short cell[5][64];   // per (scale, lane = cell): (class in the joined vector + 1) << 6 | lane it reads the coarser window from
+};
+// What depends on the cell only: where it reads the coarser window (crop + replicate, CascadingAddTable.lua:117-132) and which
+// class it is in the joined vector (ring blocks top, left, right, bottom: opticalflow_model_multiscale.lua:301-315; -1 =
+// inside the ring hole).
+static void fill_cell_maps(const CascadeGeom &g, DecodeTab &dt) {
+    const int N = g.maxh * g.maxw;
+    for (int s = 0; s < 5; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            int gsrc = 0, c = -1;
+            if (s < g.nratios && lane < N) {
+                const int a = lane / g.maxw, b = lane - a * g.maxw, d = g.d[s], mh = g.maxh, mw = g.maxw;
+                if (s < g.nratios - 1) {
+                    const int r = g.ratios[s], r2 = g.ratios[s + 1], q = r2 / r;
+                    const int dh = mh * (r2 - r) / (2 * r2), dw = mw * (r2 - r) / (2 * r2);
+                    gsrc = (dh + a / q) * mw + dw + b / q;
+                }
+                if (s == 0) c = lane;
+                else if (a < d) c = a * mw + b;
+                else if (a >= mh - d) c = d * mw + 2 * (mh - 2 * d) * d + (a - (mh - d)) * mw + b;
+                else if (b < d) c = d * mw + (a - d) * d + b;
+                else if (b >= mw - d) c = d * mw + (mh - 2 * d) * d + (a - d) * d + (b - (mw - d));
+                if (c >= 0) c += g.base[s];
+            }
+            dt.cell[s][lane] = (unsigned short)(((c + 1) << 6) | (gsrc & 0x3f));   // c + 1 <= 320, gsrc <= 63
+        }
+}
 static void fill_decode_tab(const MultiGeom &mg, int ncls, DecodeTab &dt) {
     for (int c = 0; c < ncls && c < kMaxDecode; ++c) {
         long long oy = 0, ox = 0;
@@ -305,26 +333,13 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
         // replicate) and which class it is in the joined vector -- is worked out once per wave; per pixel and scale
         // remain one coalesced load, one cross-lane read of the coarser result (no LDS buffer, no barrier), one add and
         // the running arg-max.
-        int gsrc[DFE_MAX_RATIOS], cls[DFE_MAX_RATIOS];
-        const int a = lane / g.maxw, b = lane - a * g.maxw;
-        for (int s = 0; s < g.nratios; ++s) {
-            const int d = g.d[s], mh = g.maxh, mw = g.maxw;
-            gsrc[s] = 0;
-            if (s < g.nratios - 1) {
-                const int r = g.ratios[s], r2 = g.ratios[s + 1], q = r2 / r;
-                const int dh = mh * (r2 - r) / (2 * r2), dw = mw * (r2 - r) / (2 * r2);
-                gsrc[s] = lane < N ? (dh + a / q) * mw + dw + b / q : 0;
-            }
-            int c = -1;
-            if (lane < N) {
-                if (s == 0) c = lane;
-                else if (a < d) c = a * mw + b;
-                else if (a >= mh - d) c = d * mw + 2 * (mh - 2 * d) * d + (a - (mh - d)) * mw + b;
-                else if (b < d) c = d * mw + (a - d) * d + b;
-                else if (b >= mw - d) c = d * mw + (mh - 2 * d) * d + (a - d) * d + (b - (mw - d));
-                if (c >= 0) c += g.base[s];
-            }
-            cls[s] = c;
+        // (both maps come from the host, packed per (scale, lane) in the kernel arguments: fill_decode_tab)
+        int gsrc[5], cls[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int pk = dt.cell[s][lane];                   // (cls + 1) << 6 | gsrc
+            gsrc[s] = pk & 0x3f;
+            cls[s] = (pk >> 6) - 1;
         }
         // 2-D launch on this path: blockIdx.y = row, a wave takes NPX adjacent pixels per step and issues all of their
         // loads before it touches any (one pixel at a time the kernel was bound by load latency: 154 us at VGA); all
@@ -635,6 +650,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     dim3 grid(grid1d((long long)H * W, kWaves));
     DecodeTab dt;
     fill_decode_tab(mg, g.ncls, dt);
+    if (g.maxh * g.maxw <= 64 && g.nratios <= 5) fill_cell_maps(g, dt);
     if (fast) {
         grid = cascade_fast_grid(H, W);
         hipLaunchKernelGGL(cascade_argmax_kernel<true>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle, (long long *)idx, (float *)nullptr,
@@ -707,6 +723,7 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
     if (maxh * maxw <= 64 && nratios <= 5) grid = cascade_fast_grid(H, W);   // fast path: one row per blockIdx.y
     DecodeTab dt;
     fill_decode_tab(mg, g.ncls, dt);
+    if (g.maxh * g.maxw <= 64 && g.nratios <= 5) fill_cell_maps(g, dt);
     hipLaunchKernelGGL(cascade_argmax_kernel<false>, grid, dim3(kWaves * 64), lds, ctx->stream, g, mg, middle,
                        (long long *)idx, best, flow_y, flow_x, W, 0, 0, dt);
     DFE_LAUNCH_CHECK(ctx);
