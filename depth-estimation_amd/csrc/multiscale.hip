@@ -614,7 +614,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         mg.ratios[s] = r;
         mg.d[s] = g.d[s];
     }
-    hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
+    hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
     DFE_LAUNCH_CHECK(ctx);
     bool merged = false;
     {
@@ -631,15 +631,18 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     }
     // one-cell-per-lane path: the scale-1 soft-min happens inside the cascade kernel (SOFT0), the coarser scales' here
     const bool fast = N <= 64 && nratios <= 5;
-    if (fast) {
+    int nsoft = nratios;
+    if (fast) {   // scale 1 is skipped here: the remaining scales move up one slot, so that no idle blocks are launched for it
         g.in[0] = ss.cost[0];
-        ss.P[0] = 0;
         soft_max = 0;
-        for (int s = 1; s < nratios; ++s)
+        for (int s = 1; s < nratios; ++s) {
+            ss.cost[s - 1] = ss.cost[s]; ss.prob[s - 1] = ss.prob[s]; ss.P[s - 1] = ss.P[s];
             if (ss.P[s] > soft_max) soft_max = ss.P[s];
+        }
+        nsoft = nratios - 1;
     }
-    if (soft_max > 0) {
-        hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nratios), dim3(kWaves * 64), 0, ctx->stream, ss, N);
+    if (soft_max > 0 && nsoft > 0) {
+        hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nsoft), dim3(kWaves * 64), 0, ctx->stream, ss, N);
         DFE_LAUNCH_CHECK(ctx);
     }
     g.H = H; g.W = W;
