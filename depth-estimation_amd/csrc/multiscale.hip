@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
 #pragma unroll
         for (int s = 0; s < 5; ++s) {
             const int pk = dt.cell[s][lane];                   // (cls + 1) << 6 | gsrc
-            gsrc[s] = pk & 0x3f;
+            gsrc[s] = (pk & 0x3f) << 2;                        // byte address for ds_bpermute
             cls[s] = (pk >> 6) - 1;
         }
         // 2-D launch on this path: blockIdx.y = row, a wave takes NPX adjacent pixels per step and issues all of their
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                 for (int s = MAXS - 1; s >= 0; --s) {
                     if (s >= g.nratios) continue;
                     float v = vin[i][s];
-                    if (s < g.nratios - 1) v += __shfl(pv, gsrc[s]);
+                    if (s < g.nratios - 1) v += __int_as_float(__builtin_amdgcn_ds_bpermute(gsrc[s], __float_as_int(pv)));
                     pv = v;
                     const int c = cls[s];
                     if (c >= 0 && (v > bv || (v == bv && c < bi))) { bv = v; bi = c; }
