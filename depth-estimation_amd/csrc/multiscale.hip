@@ -7,11 +7,18 @@
 // H x W x 64 temporaries; here volumes stay at native scale and one kernel per finest pixel gathers its
 // window from each scale, cascades and ring-selects in LDS, writing only the H x W x nclasses result.
 #include "dfe_internal.h"
+#include <type_traits>
 #include <cmath>
 
 namespace {
 
 constexpr int kWaves = 4;
+template <int I, int N, class F> __device__ __forceinline__ void static_for_ms(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_ms<I + 1, N>(f);
+    }
+}
 
 // ---- nn.SpatialDownSampling(r,r): mean of r x r blocks (row-major accumulation, then * 1/(r*r)) ----
 __global__ void downsample_box_kernel(const float *__restrict__ img, int C, int H, int W, int r, float *__restrict__ out) {
@@ -281,6 +288,7 @@ static dim3 cascade_fast_grid(int H, int W) {
 constexpr int kMaxDecode = 5 * 64;
 struct DecodeTab {
     int v[kMaxDecode];
+    int pow2;                     // ratios are exactly 1, 2, 4, ... (the coarse pixels under 8 aligned fine pixels are shared)
     unsigned short cell[5][64];   // per (scale, lane = cell): (class in the joined vector + 1) << 6 | lane it reads the coarser window from
 };
 // What depends on the cell only: where it reads the coarser window (crop + replicate, CascadingAddTable.lua:117-132) and which
@@ -288,6 +296,9 @@ struct DecodeTab {
 // inside the ring hole).
 static void fill_cell_maps(const CascadeGeom &g, DecodeTab &dt) {
     const int N = g.maxh * g.maxw;
+    dt.pow2 = 1;
+    for (int s = 0; s < g.nratios; ++s)
+        if (g.ratios[s] != (1 << s)) dt.pow2 = 0;
     for (int s = 0; s < 5; ++s)
         for (int lane = 0; lane < 64; ++lane) {
             int gsrc = 0, c = -1;
@@ -313,6 +324,60 @@ static void fill_decode_tab(const MultiGeom &mg, int ncls, DecodeTab &dt) {
         long long oy = 0, ox = 0;
         multi_decode(mg, c + 1, &oy, &ox);
         dt.v[c] = (int)((unsigned)((int)oy << 16) | ((unsigned)(int)ox & 0xffffu));
+    }
+}
+
+// One cascade step for ratios 1, 2, 4, ... and 8 aligned pixels x0 .. x0+7 inside the row: the coarse pixel of scale s under
+// fine pixel i is (x0 >> s) + (i >> s), so scale s has only max(1, 8 >> s) distinct inputs -- each is loaded (immediate
+// offsets from one address per scale), cascaded and compared ONCE and shared by the fine pixels below it.  Same adds and
+// comparisons per fine pixel, in the same order, as the generic loop: bit-identical.
+template <int NR, bool SOFT0>
+__device__ __forceinline__ void cascade_inputs_pow2(const CascadeGeom &g, const int (&gsrc)[5], const int (&cls)[5], int lane, int N, int y, int x0,
+                                                    int (&key)[8], int (&bcls)[8], int (&cbits)[8]) {
+    float pv[8], bv[8];
+    int bi[8];
+    static_for_ms<0, NR>([&](auto sc) {
+        constexpr int s = NR - 1 - decltype(sc)::value;          // coarse -> fine
+        constexpr int cnt = (8 >> s) > 0 ? (8 >> s) : 1;
+        const float *src = g.in[s] + ((long long)(y >> s) * (g.W >> s) + (x0 >> s)) * N + lane;
+        float v[cnt];
+#pragma unroll
+        for (int j = 0; j < cnt; ++j) v[j] = lane < N ? src[j * N] : 0.f;
+        if constexpr (SOFT0 && s == 0) {
+            const bool on = lane < N;
+#pragma unroll
+            for (int j = 0; j < cnt; ++j) {
+                const float c = v[j];
+                const float m = wave_max_f32(on ? -c : -INFINITY);
+                const float e = on ? expf(-c - m) : 0.f;
+                const float sum = wave_sum_f32_ordered(e);
+                v[j] = on ? e * (1.0f / sum) : 0.f;
+            }
+        }
+        // children first (descending j): slot j of this scale reads the parent slot j >> 1 of the coarser scale before it is overwritten
+#pragma unroll
+        for (int j = cnt - 1; j >= 0; --j) {
+            float val = v[j];
+            float pbv = -INFINITY;
+            int pbi = 0x7fffffff;
+            if constexpr (s < NR - 1) {
+                constexpr int pcnt = (8 >> (s + 1)) > 0 ? (8 >> (s + 1)) : 1;
+                const int pj = (cnt == 2 * pcnt) ? (j >> 1) : j;   // (cnt == pcnt == 1 above ratio 8)
+                val += __int_as_float(__builtin_amdgcn_ds_bpermute(gsrc[s], __float_as_int(pv[pj])));
+                pbv = bv[pj];
+                pbi = bi[pj];
+            }
+            const int c = cls[s];
+            if (c >= 0 && (val > pbv || (val == pbv && c < pbi))) { pbv = val; pbi = c; }
+            pv[j] = val; bv[j] = pbv; bi[j] = pbi;
+        }
+    });
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int bb = __float_as_int(bv[i] + 0.0f);
+        key[i] = ~(bb >= 0 ? bb : bb ^ 0x7fffffff);
+        bcls[i] = bi[i];
+        cbits[i] = __float_as_int(pv[i]);
     }
 }
 
@@ -364,6 +429,13 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
             rinv[s] = 1.0f / (float)r;
         }
         for (int x0 = (blockIdx.x * kWaves + w) * NPX; x0 < g.W; x0 += gridDim.x * kWaves * NPX) {
+            int key[NPX], bcls[NPX], cbits[NPX];
+            if (dt.pow2 && x0 + NPX <= g.W && g.nratios >= 2) {   // wave-uniform
+                if (g.nratios == 2) cascade_inputs_pow2<2, SOFT0>(g, gsrc, cls, lane, N, y, x0, key, bcls, cbits);
+                else if (g.nratios == 3) cascade_inputs_pow2<3, SOFT0>(g, gsrc, cls, lane, N, y, x0, key, bcls, cbits);
+                else if (g.nratios == 4) cascade_inputs_pow2<4, SOFT0>(g, gsrc, cls, lane, N, y, x0, key, bcls, cbits);
+                else cascade_inputs_pow2<5, SOFT0>(g, gsrc, cls, lane, N, y, x0, key, bcls, cbits);
+            } else {
             float vin[NPX][MAXS];
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
@@ -385,7 +457,6 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                     vin[i][0] = on ? e * (1.0f / sum) : 0.f;
                 }
             }
-            int key[NPX], bcls[NPX], cbits[NPX];
 #pragma unroll
             for (int i = 0; i < NPX; ++i) {
                 float bv = -INFINITY, pv = 0.f;
@@ -405,6 +476,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                 key[i] = ~(bb >= 0 ? bb : bb ^ 0x7fffffff);
                 bcls[i] = bi;
                 cbits[i] = __float_as_int(pv);                // scale-1 value of this lane's cell (the centre class sits in lane mlane)
+            }
             }
             const int wk = wave_min8<NPX>(key, lane);         // lane L: key of the maximum of pixel L & 7
             int cand[NPX];
