@@ -51,6 +51,20 @@ __global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int
 }
 
 // ---- down-sample by r (same arithmetic as downsample_box_kernel) and zero-pad, both frames, one launch ----
+// the r x r box of one output pixel, summed row-major like the generic loop; for the usual ratios every load is issued
+// before the first add (a run-time loop of load-add pairs makes the r = 4 scale a chain of 16 memory latencies)
+template <int R> __device__ __forceinline__ float box_sum(const float *__restrict__ src, int W) {
+#pragma clang fp contract(off)
+    float t[R * R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) t[i * R + j] = src[(long long)i * W + j];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < R * R; ++k) s = s + t[k];
+    return s;
+}
 __device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl,
                                                 int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
 #pragma clang fp contract(off)
@@ -69,9 +83,16 @@ __device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, co
         const int sy = y - pt, sx = x - pl;
         float v = 0.f;
         if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
+            const float *src = img + ((long long)c * H + sy * r) * W + sx * r;
             float s = 0.f;
-            for (int i = 0; i < r; ++i)
-                for (int j = 0; j < r; ++j) s = s + img[((long long)c * H + sy * r + i) * W + sx * r + j];
+            if (r == 1) s = 0.f + src[0];
+            else if (r == 2) s = box_sum<2>(src, W);
+            else if (r == 4) s = box_sum<4>(src, W);
+            else if (r == 8) s = box_sum<8>(src, W);
+            else {
+                for (int i = 0; i < r; ++i)
+                    for (int j = 0; j < r; ++j) s = s + src[(long long)i * W + j];
+            }
             v = r > 1 ? s * inv : s;
         }
         (second ? p1 : p0)[ee] = v;
