@@ -21,6 +21,20 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for_ms(F
 }
 
 // ---- nn.SpatialDownSampling(r,r): mean of r x r blocks (row-major accumulation, then * 1/(r*r)) ----
+// the r x r box of one output pixel, summed row-major like the generic loop; for the usual ratios every load is issued
+// before the first add (a run-time loop of load-add pairs makes the r = 4 scale a chain of 16 memory latencies)
+template <int R> __device__ __forceinline__ float box_sum(const float *__restrict__ src, int W) {
+#pragma clang fp contract(off)
+    float t[R * R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) t[i * R + j] = src[(long long)i * W + j];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < R * R; ++k) s = s + t[k];
+    return s;
+}
 __global__ void downsample_box_kernel(const float *__restrict__ img, int C, int H, int W, int r, float *__restrict__ out) {
 #pragma clang fp contract(off)
     const int Ho = H / r, Wo = W / r;
@@ -30,9 +44,15 @@ __global__ void downsample_box_kernel(const float *__restrict__ img, int C, int 
         int x = (int)(e % Wo);
         long long t = e / Wo;
         int y = (int)(t % Ho), c = (int)(t / Ho);
+        const float *src = img + ((long long)c * H + y * r) * W + x * r;
         float s = 0.f;
-        for (int i = 0; i < r; ++i)
-            for (int j = 0; j < r; ++j) s = s + img[((long long)c * H + y * r + i) * W + x * r + j];
+        if (r == 2) s = box_sum<2>(src, W);
+        else if (r == 4) s = box_sum<4>(src, W);
+        else if (r == 8) s = box_sum<8>(src, W);
+        else {
+            for (int i = 0; i < r; ++i)
+                for (int j = 0; j < r; ++j) s = s + src[(long long)i * W + j];
+        }
         out[e] = s * inv;
     }
 }
@@ -51,20 +71,6 @@ __global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int
 }
 
 // ---- down-sample by r (same arithmetic as downsample_box_kernel) and zero-pad, both frames, one launch ----
-// the r x r box of one output pixel, summed row-major like the generic loop; for the usual ratios every load is issued
-// before the first add (a run-time loop of load-add pairs makes the r = 4 scale a chain of 16 memory latencies)
-template <int R> __device__ __forceinline__ float box_sum(const float *__restrict__ src, int W) {
-#pragma clang fp contract(off)
-    float t[R * R];
-#pragma unroll
-    for (int i = 0; i < R; ++i)
-#pragma unroll
-        for (int j = 0; j < R; ++j) t[i * R + j] = src[(long long)i * W + j];
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < R * R; ++k) s = s + t[k];
-    return s;
-}
 __device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl,
                                                 int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
 #pragma clang fp contract(off)
