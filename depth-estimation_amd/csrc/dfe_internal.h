@@ -49,8 +49,10 @@ int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...);
 int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int kh,
                        int kw, int hWin, int wWin, float *out);
 // the volumes of n independent pairs (pyramid scales) in one launch where a common block shape exists (*handled)
+// prob (may be NULL): per pair, non-null = leave soft-min probabilities there instead of the costs in out[i] -- if the
+// launcher finds that worthwhile for the shape (*prob_used)
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, bool *handled);
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used);
 int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
 
 #define DFE_HIP(ctx, expr)                                                              \
@@ -206,6 +208,34 @@ template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], i
         c = min((int)q[0], (int)q[1]);
     }
     return c;
+}
+
+// wave reductions of the soft-min (multiscale.hip and the volume kernel's soft-min epilogue): everything on the VALU
+__device__ __forceinline__ float wave_max_f32(float v) {
+#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
+#undef DFE_STEP
+    const int b = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = fmaxf(__int_as_float((int)r[0]), __int_as_float((int)r[1]));
+    const int c = __float_as_int(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
+    return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
+}
+// wave sum in the association order of `for (off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off)` -- partners at
+// distance 32, 16, 8, 4, 2, 1 -- on the VALU only (lane swaps + DPP), bit-identical to the shuffle version: after the
+// distance-8 step lanes L and L^8 hold equal values, so row_ror:4 (partner (L+4) mod 16) reads the same number as L^4
+__device__ __forceinline__ float wave_sum_f32_ordered(float v) {
+    int b = __float_as_int(v);
+    const auto q = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    v = __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
+    b = __float_as_int(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+#define DFE_STEP(ctrl) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);   // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
+#undef DFE_STEP
+    return v;
 }
 
 #endif  // __HIPCC__

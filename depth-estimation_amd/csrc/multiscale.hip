@@ -114,33 +114,6 @@ __global__ void prep_scales_kernel(const float *__restrict__ I0, const float *__
     prep_scale_body(I0, I1, C, H, W, ps.r[s], pl, pt, ps.Hp[s], ps.Wp[s], ps.p0[s], ps.p1[s]);
 }
 
-__device__ __forceinline__ float wave_max_f32(float v) {
-#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
-    DFE_STEP(0xB1); DFE_STEP(0x4E); DFE_STEP(0x124); DFE_STEP(0x128);   // quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8
-#undef DFE_STEP
-    const int b = __float_as_int(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-    v = fmaxf(__int_as_float((int)r[0]), __int_as_float((int)r[1]));
-    const int c = __float_as_int(v);
-    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);
-    return fmaxf(__int_as_float((int)q[0]), __int_as_float((int)q[1]));
-}
-// wave sum in the association order of `for (off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off)` -- partners at
-// distance 32, 16, 8, 4, 2, 1 -- on the VALU only (lane swaps + DPP), bit-identical to the shuffle version: after the
-// distance-8 step lanes L and L^8 hold equal values, so row_ror:4 (partner (L+4) mod 16) reads the same number as L^4
-__device__ __forceinline__ float wave_sum_f32_ordered(float v) {
-    int b = __float_as_int(v);
-    const auto q = __builtin_amdgcn_permlane32_swap(b, b, false, false);
-    v = __int_as_float((int)q[0]) + __int_as_float((int)q[1]);
-    b = __float_as_int(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
-    v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
-#define DFE_STEP(ctrl) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
-    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);   // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
-#undef DFE_STEP
-    return v;
-}
-
 // ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
 __device__ __forceinline__ void softmin_body(const float *__restrict__ cost, long long P, int N, float *__restrict__ prob) {
     const int lane = threadIdx.x & 63;
@@ -715,12 +688,18 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     }
     hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
     DFE_LAUNCH_CHECK(ctx);
-    bool merged = false;
+    bool merged = false, soft_done = false;
+    const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
     {
+        // one launch for every scale's volume; on the fast path the coarser scales leave it as soft-min probabilities already
+        // (their blocks run next to the scale-1 blocks that dominate the launch), scale 1 as costs for the cascade's SOFT0
         const float *f0[DFE_MAX_RATIOS], *f1[DFE_MAX_RATIOS];
-        float *vo[DFE_MAX_RATIOS];
-        for (int s = 0; s < nratios; ++s) { f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s]; }
-        rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, &merged);
+        float *vo[DFE_MAX_RATIOS], *pr[DFE_MAX_RATIOS];
+        for (int s = 0; s < nratios; ++s) {
+            f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s];
+            pr[s] = (fast && s > 0) ? ss.prob[s] : nullptr;
+        }
+        rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, pr, &merged, &soft_done);
         if (rc) return rc;
     }
     for (int s = 0; s < nratios && !merged; ++s) {
@@ -729,7 +708,6 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         if (rc) return rc;
     }
     // one-cell-per-lane path: the scale-1 soft-min happens inside the cascade kernel (SOFT0), the coarser scales' here
-    const bool fast = N <= 64 && nratios <= 5;
     int nsoft = nratios;
     if (fast) {   // scale 1 is skipped here: the remaining scales move up one slot, so that no idle blocks are launched for it
         g.in[0] = ss.cost[0];
@@ -740,7 +718,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         }
         nsoft = nratios - 1;
     }
-    if (soft_max > 0 && nsoft > 0) {
+    if (soft_max > 0 && nsoft > 0 && !soft_done) {   // (soft_done: the volume launch has taken the coarser scales' soft-mins)
         hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nsoft), dim3(kWaves * 64), 0, ctx->stream, ss, N);
         DFE_LAUNCH_CHECK(ctx);
     }

@@ -269,9 +269,12 @@ template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K;
 // the wave that holds chunk 0) the extractOutput score, so the flow needs no second pass over the 1.16 GB volume: the
 // values are still in registers when they are stored.  The wave minimum is a 6-step DPP reduction, the first-index
 // rule a ballot; the arithmetic added (~50 %) hides under the store stream that bounds this kernel.
-template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE>
+// SOFT (windows of at most one chunk): where `prob` is given, a task row leaves as soft-min probabilities instead of costs --
+// p = e / sum(e), e = expf(-c - max(-c)) over the cells of a pixel = the lanes of the wave, with the arithmetic of
+// softmin_kernel (multiscale.hip), so the result is bit-identical to running that kernel on the stored volume.
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE, bool SOFT = false>
 __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, const float *__restrict__ I1, float *__restrict__ out,
-                                                  const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by) {
+                                                  const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by, float *__restrict__ prob = nullptr) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ;
@@ -315,7 +318,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
         const bool valid = d < D;
         // plain build: one divergent region per task (only the last chunk is partial).  FUSE: every lane runs
         // (idle lanes shadow the last cell) because the wave reductions need the full wave; their stores are masked.
-        if (FUSE || valid) {
+        if (FUSE || (SOFT && prob) || valid) {   // (wave reductions need the whole wave: idle lanes shadow the last cell, masked)
             const int dc = valid ? d : D - 1;
             const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
             const px_t *lp = lds + dy * p.pitch + dx + tile * TX;
@@ -412,7 +415,17 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                             vrow[x] = t;
                         }
                     }
-                    if (store_row) {
+                    if (SOFT && prob && store_row) {   // (wave-uniform)
+                        const char *prow = (const char *)(prob + ((long long)y * p.Wo + xt) * D);
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) {
+                            const float c = vrow[x];
+                            const float m = wave_max_f32(valid ? -c : -INFINITY);
+                            const float e = valid ? expf(-c - m) : 0.f;
+                            const float sum = wave_sum_f32_ordered(e);
+                            if (valid) store_uniform_base(prow + (long long)x * D * 4, dbytes, e * (1.0f / sum));
+                        }
+                    } else if (store_row) {
 #pragma unroll
                         for (int x = 0; x < TX; ++x)
                             if (!FUSE || valid) store_uniform_base(orow + (long long)x * D * 4, dbytes, vrow[x]);
@@ -436,14 +449,17 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_kernel(const float *__re
 struct CvTiledMulti {
     const float *I0[DFE_MAX_RATIOS], *I1[DFE_MAX_RATIOS];
     float *out[DFE_MAX_RATIOS];
+    float *prob[DFE_MAX_RATIOS];   // non-null: this pair leaves as soft-min probabilities (out[] is then not written)
     CvTiledArgs p[DFE_MAX_RATIOS];
     int gx[DFE_MAX_RATIOS], gy[DFE_MAX_RATIOS];
 };
 template <int C, int K, int TX, int NT, int NW, int NQ>
 __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_multi_kernel(CvTiledMulti m) {
-    const int z = blockIdx.z;
+    // (last pair first: blocks are dispatched in z order, and the coarser scales' few blocks, which carry the soft-min
+    //  epilogue and run ~3x longer, must not form the tail of the launch)
+    const int z = gridDim.z - 1 - blockIdx.z;
     if ((int)blockIdx.x >= m.gx[z] || (int)blockIdx.y >= m.gy[z]) return;   // block-uniform
-    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false>(m.I0[z], m.I1[z], m.out[z], m.p[z], CvFuseArgs{}, blockIdx.x, blockIdx.y);
+    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, true>(m.I0[z], m.I1[z], m.out[z], m.p[z], CvFuseArgs{}, blockIdx.x, blockIdx.y, m.prob[z]);
 }
 
 // geometry of one tiled launch
@@ -1176,7 +1192,7 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
 // when some pair has no plan with the common block shape (the caller then launches them one by one)
 template <int NQ>
 static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, const int *H, const int *W,
-                                     int hWin, int wWin, float *const *out, bool *handled) {
+                                     int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used) {
     constexpr int C = 3, K = 7, TX = 8, NT = 4, NW = 4;
     CvTiledMulti m;
     size_t lds = 0;
@@ -1190,12 +1206,20 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         a.H = H[i]; a.W = W[i]; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
         a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.seg_rows = 0; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
         a.chunk0 = 0;
-        m.p[i] = a; m.I0[i] = I0[i]; m.I1[i] = I1[i]; m.out[i] = out[i];
+        m.p[i] = a; m.I0[i] = I0[i]; m.I1[i] = I1[i]; m.out[i] = out[i]; m.prob[i] = prob ? prob[i] : nullptr;
         m.gx[i] = dfe_cdiv(Wo, pl.GX); m.gy[i] = dfe_cdiv(Ho, pl.TY);
         if (m.gx[i] > gxm) gxm = m.gx[i];
         if (m.gy[i] > gym) gym = m.gy[i];
         if (pl.lds_bytes > lds) lds = pl.lds_bytes;
     }
+    // The soft-min epilogue makes a block ~3x longer.  It pays when the first (largest) pair has enough blocks to hide the
+    // other pairs' few long ones behind (1080p: 3600 blocks, -9 % on the step); at VGA (540 blocks) those long blocks set
+    // the launch time and the separate soft-min launch is faster (0.119 against 0.134 ms per pair).
+    bool use_prob = prob && m.gx[0] * m.gy[0] >= 2000;
+    if (const char *e = getenv("DFE_SOFT_EPILOGUE")) use_prob = prob && atoi(e) != 0;   // tuning / tests: force on (1) or off (0)
+    if (!use_prob)
+        for (int i = 0; i < n; ++i) m.prob[i] = nullptr;
+    if (prob_used) *prob_used = use_prob;
     auto kern = ssd_cv_tiled_multi_kernel<C, K, TX, NT, NW, NQ>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
@@ -1209,17 +1233,18 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
 }
 
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, bool *handled) {
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used) {
     *handled = false;
+    if (prob_used) *prob_used = false;
     if (ctx->cv_mode == 1 || ctx->cv_mode == 3 || C != 3 || k != 7 || hWin * wWin > 64 || n < 2 || n > DFE_MAX_RATIOS) return DFE_OK;
     // 4 row groups (18-row tiles) unless forced: measured at VGA, 3 scales, 2 / 3 / 4 / 5 groups -> 0.161 / 0.159 / 0.151 /
     // 0.155 ms per pair (short tiles pay the K-1 warm-up rows too often, tall ones leave the coarse scales too few blocks)
     const int nq = (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5) ? ctx->cv_tyq : 4;
     switch (nq) {
-        case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
-        case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
-        case 3: return launch_cv_tiled_multi_one<3>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
-        default: return launch_cv_tiled_multi_one<4>(ctx, n, I0, I1, H, W, hWin, wWin, out, handled);
+        case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
+        case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
+        case 3: return launch_cv_tiled_multi_one<3>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
+        default: return launch_cv_tiled_multi_one<4>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
     }
 }
 

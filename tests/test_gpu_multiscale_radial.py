@@ -225,6 +225,22 @@ def test_multiscale_model_forward_flow_equals_forward_plus_process_output(dfe, c
     assert tuple(a["index"].shape) == (52, 72) and torch.equal(a["index"], b["index"]) and torch.equal(a["y"], b["y"]) and torch.equal(a["x"], b["x"])
 
 
+@pytest.mark.parametrize("force", ["1", "0"])
+def test_multiscale_one_call_soft_epilogue_both_ways(dfe, cuda, monkeypatch, force):
+    """The one-call matcher lets the merged volume launch write the coarser scales' soft-min probabilities directly when the
+    frame is large enough (1080p); forced on and off here (DFE_SOFT_EPILOGUE), both must equal the staged path bit for bit."""
+    H, W = 96, 128
+    geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4], multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=11, max_flow=10, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    model = dfe.getModelMultiscale(geo)
+    staged = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False)
+    monkeypatch.setenv("DFE_SOFT_EPILOGUE", force)
+    one = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=True)
+    for k in ("index", "y", "x"):
+        assert torch.equal(staged[k], one[k]), (k, force)
+
+
 def test_multiscale_model_pads_to_a_multiple_of_the_coarsest_ratio(dfe, cuda):
     """opticalflow_model_multiscale.lua:234-248: frames whose size is not a multiple of rmax are zero-padded at the
     bottom / right and the output keeps the padded size -- identical to running the padded frames."""
