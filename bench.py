@@ -37,6 +37,7 @@ WORKLOADS = {
 # the single-scale cost-volume build, which is what `vga` measures.
 PYRAMIDS = {
     "vga-pyramid": (480, 640, 3, 7, 8, 8, (1, 2, 4)),
+    "720p-pyramid": (720, 1280, 3, 7, 8, 8, (1, 2, 4, 8)),
     "1080p-pyramid": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

@@ -1213,9 +1213,9 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         if (pl.lds_bytes > lds) lds = pl.lds_bytes;
     }
     // The soft-min epilogue makes a block ~3x longer.  It pays when the first (largest) pair has enough blocks to hide the
-    // other pairs' few long ones behind (1080p: 3600 blocks, -9 % on the step); at VGA (540 blocks) those long blocks set
-    // the launch time and the separate soft-min launch is faster (0.119 against 0.134 ms per pair).
-    bool use_prob = prob && m.gx[0] * m.gy[0] >= 2000;
+    // other pairs' few long ones behind (1080p: 3600 blocks, -5.5 % on the step; 720p: 1600 blocks, -5.6 %); at VGA (540
+    // blocks) those long blocks set the launch time and the separate soft-min launch is faster (0.119 against 0.134 ms).
+    bool use_prob = prob && m.gx[0] * m.gy[0] >= 1000;
     if (const char *e = getenv("DFE_SOFT_EPILOGUE")) use_prob = prob && atoi(e) != 0;   // tuning / tests: force on (1) or off (0)
     if (!use_prob)
         for (int i = 0; i < n; ++i) m.prob[i] = nullptr;
