@@ -115,6 +115,34 @@ template <int K, int TX> __device__ __forceinline__ void hsum(const float (&e)[T
     }
 }
 
+// Row-image kernel: the same K-sums in block form (van Herk): the window of K = 7 over TX = 8 columns spans exactly two
+// blocks of 7 positions, so h[x] = (suffix sum of block A from x) + (prefix sum of block B up to x-1): 18 adds per 8 outputs
+// instead of 40.  Only non-negative terms are added (no running-sum cancellation), but the association depends on the
+// column's position in its tile -- the row-image kernel therefore stores every pixel from exactly one tile (the shifted last
+// tile skips the columns it shares with its neighbour), so results stay deterministic and independent of the schedule; on
+// float frames they differ from the tiled kernel's by reassociation (integer-valued frames: exact either way).
+template <int K, int TX> __device__ __forceinline__ void hsum_vh(const float (&e)[TX + K - 1], float (&h)[TX]) {
+    if constexpr (K == 7 && TX == 8) {
+        float sa[7], pb[7];
+        sa[6] = e[6];
+#pragma unroll
+        for (int i = 5; i >= 0; --i) sa[i] = e[i] + sa[i + 1];
+        pb[0] = e[7];
+#pragma unroll
+        for (int j = 1; j < 7; ++j) pb[j] = pb[j - 1] + e[7 + j];
+        h[0] = sa[0];
+#pragma unroll
+        for (int x = 1; x < 7; ++x) h[x] = sa[x] + pb[x - 1];
+        h[7] = pb[6];
+    } else if constexpr (K == 7 && TX == 2) {
+        const float s = ((e[1] + e[2]) + (e[3] + e[4])) + (e[5] + e[6]);
+        h[0] = e[0] + s;
+        h[1] = s + e[7];
+    } else {
+        hsum<K, TX>(e, h);
+    }
+}
+
 // Wave-uniform loads of N consecutive floats through the scalar cache (s_load_dwordx8/x4/x2/x1).
 // The constant address space makes the backend select SMEM; dword alignment is all SMEM needs.
 typedef const float __attribute__((address_space(4))) *cfptr;
@@ -156,7 +184,25 @@ struct CvTiledArgs {
     int tile0_off;     // row-image kernel: byte offset of the frame-0 tile inside dynamic LDS
     int stage_off;     // row-image kernel: byte offset of the run images inside dynamic LDS
     int stage_len;     // row-image kernel: floats per image
+    int sw_ovh;        // column sweep: cost of starting a piece, in row steps (warm-up rows + ring staging)
+    int sw_min;        // column sweep: a piece is never shorter than this many output rows
 };
+
+// Persistent column sweep: the (column, output row) grid is walked column-major as one linear sequence of ncols*Ho row
+// steps and cut into B contiguous ranges, one per block.  A range is swept as pieces -- one per column it touches -- and
+// every piece pays `ovh` row steps (K-1 warm-up rows + staging the rings), so the cuts are taken uniformly in the
+// weighted coordinate u = pos + ovh * column(pos): every block then has the same rows + pieces*ovh.  Cuts closer than
+// `minr` rows to a column's first or last row snap to the column boundary (no piece shorter than minr).
+// (32-bit arithmetic: the launcher checks (Ho + ovh) * ncols * B < 2^31)
+__host__ __device__ inline int sweep_cut(int b, int B, int ncols, int Ho, int ovh, int minr) {
+    if (b >= B) return ncols * Ho;
+    const int Lc = Ho + ovh, u = Lc * ncols * b / B;
+    int col = u / Lc;
+    int row = u - col * Lc - ovh;
+    if (row < minr) row = 0;
+    else if (Ho - row < minr) { ++col; row = 0; }
+    return col * Ho + row;
+}
 
 extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 
@@ -197,14 +243,20 @@ __device__ __forceinline__ void store_uniform_base(const void *base, unsigned la
 // with the column minimum (a v_cmp IS a ballot), take the lowest set bit on the scalar unit and drop it into lane x.
 // the part of the fused epilogue that is plain stores: the centre cell's cost and the pixel's first DFE_LEAD cells
 template <int TX>
-__device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa) {
+__device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa, int nover = 0) {
     // Both are SGPR base + 32-bit lane offset dwordx4 stores: with 64-bit per-lane addresses the address arithmetic of these
     // few bytes cost the two waves that own them ~6 % of the whole fused row-image kernel (they sit before the barrier).
     static_assert(TX == 8, "two dwordx4 stores per lane");
     const f4_t lo = {vrow[0], vrow[1], vrow[2], vrow[3]}, hi = {vrow[4], vrow[5], vrow[6], vrow[7]};
     if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
         const float *cb = fa.centre + pg0;
-        asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:16" ::"v"(0u), "v"(lo), "s"(cb), "v"(hi) : "memory");
+        if (nover == 0) {   // (wave-uniform)
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:16" ::"v"(0u), "v"(lo), "s"(cb), "v"(hi) : "memory");
+        } else {            // row-image kernel, shifted last tile: the first nover columns are the neighbour's
+#pragma unroll
+            for (int x = 0; x < TX; ++x)
+                if (x >= nover) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(0u), "v"(vrow[x]), "s"(cb), "n"(x * 4) : "memory");
+        }
     }
     if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
         // the pixel's first cells, for extractOutput, pixel-major [P][DFE_LEAD]: the 8 pixels of the tile row are 512
@@ -215,7 +267,7 @@ __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int l
         const unsigned off = (unsigned)lane * 4u;
 #pragma unroll
         for (int x = 0; x < TX; ++x)
-            asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
+            if (x >= nover) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
     }
 }
 
@@ -671,7 +723,7 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
         __builtin_amdgcn_sched_barrier(0);
     });
     float h[TXL];
-    hsum<K, TXL>(e, h);
+    hsum_vh<K, TXL>(e, h);
     if constexpr (K == 7) {
         // ring holds the pair sums P_{r-5}..P_{r-1} and, in the slot whose P has just been consumed, H_{r-1}
         // (which becomes P_{r-1} = H_{r-1} + H_r in place)
@@ -716,34 +768,60 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + p.tile0_off);    // frame-0 tile [ROWS][32]
     float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);          // [2][stage_len], 128-B aligned
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-aware block order: hardware deals linear block ids round-robin to the 8 XCDs; give every XCD a
-    // contiguous range of tiles (x fastest) instead, so neighbours in x share an L2.
-    int bx, by;
-    {
+    const long long HW = p.plane;
+    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
+    // Tail-line ownership (33 x 33 instantiation): the run of 8 pixels ends inside a 128-B line whose other part belongs to the
+    // NEXT pixel of the image row.  Two blocks writing the two parts of such a line only works while both parts meet in one
+    // L2 (partial lines that miss L2 cost a read-modify-write at the memory, section 4.2), which ties the schedule to the
+    // XCD layout.  Instead the block also computes the <= 31 leading cells of pixel x0+8 that complete its last line (31
+    // idle lanes of the mini task: one output per lane, no extra instructions) and writes that line whole; its right
+    // neighbour skips its head.  Left: two partial lines per IMAGE row (first and last column) instead of two per tile row.
+    constexpr bool TOWN = DC == 1089;
+    // Static tiles: one piece per block, XCD-aware block order (hardware deals linear block ids round-robin to the 8 XCDs; give
+    // every XCD a contiguous range of tiles, x fastest, so neighbours in x share an L2), TY output rows per block, the last
+    // tile row shifted inwards.  Column sweep: the block walks down its range of the column-major (column, row) sequence
+    // (sweep_cut), one piece per column it touches; the frame-1 tile is a ring of p.lrows (= 64) rows that wave LW keeps
+    // filled a row step ahead, so the K-1 warm-up rows are paid once per piece instead of once per TY rows.
+    // (static tiles: p.seg_rows is the tile height, a run-time value -- one instantiation serves every height)
+    int pos = 0, pend = 1, bx = 0, by = 0;
+    if constexpr (SWEEP) {
+        const int ncols = (p.Wo + TX - 1) / TX;
+        pos = sweep_cut(blockIdx.x, gridDim.x, ncols, p.Ho, p.sw_ovh, p.sw_min);
+        pend = sweep_cut(blockIdx.x + 1, gridDim.x, ncols, p.Ho, p.sw_ovh, p.sw_min);
+        if (pos >= pend) return;                                     // block-uniform
+    } else {
         const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
         const int per = nb >> 3, rem = nb & 7, xcd = lin & 7, slot = lin >> 3;
         const int t = xcd * per + min(xcd, rem) + slot;      // XCDs 0..rem-1 own per+1 tiles, the others per
         by = t / (int)gridDim.x;
         bx = t - by * (int)gridDim.x;
     }
-    // static tiles: TY output rows per block, the last tile row shifted inwards.  Column sweep: the block walks down
-    // p.seg_rows output rows of its 8-pixel column, the frame-1 tile is a ring of p.lrows (= 64) rows that wave LW keeps
-    // filled a row step ahead, so the K-1 warm-up rows are paid once per segment instead of once per TY rows and no
-    // tile staging stalls the CU between tiles.
-    // (static tiles: p.seg_rows is the tile height, a run-time value -- one instantiation serves every height)
-    const int x0n = bx * TX, y0n = by * p.seg_rows;
+  for (;;) {   // pieces of this block (static tiles: one)
+    // Every per-lane quantity is derived afresh from the thread id in each piece: nothing per-lane is then live across the
+    // piece loop's back edge, and the register allocation of a piece is that of a one-piece kernel (with the ids taken
+    // outside the loop the hoisted lane geometry pushed the 3-channel sweep 50 registers into scratch).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int prows = p.seg_rows;
+    if constexpr (SWEEP) {
+        bx = pos / p.Ho;
+        by = pos - bx * p.Ho;                                        // first output row of the piece
+        prows = min(pend - pos, p.Ho - by);
+    }
+    const int x0n = bx * TX, y0n = SWEEP ? by : by * p.seg_rows;
     const int x0 = min(x0n, p.Wo - TX), y0 = SWEEP ? y0n : min(y0n, p.Ho - p.seg_rows);
-    const int nsweep = min(p.seg_rows, p.Ho - y0) + (K - 1);   // rows this block sweeps
+    const int nsweep = min(prows, p.Ho - y0) + (K - 1);        // rows this piece sweeps
     const int t0rows = SWEEP ? R0 : nsweep;                    // rows of the frame-0 tile
-    const long long HW = p.plane;
-    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
+    const int nover = x0n - x0;                                // leading columns of a shifted last tile: its neighbour's, not stored from here
+    const bool has_next = TOWN && x0 + TX < p.Wo;              // the pixel after the run is in the same image row: own the tail line
+    const bool skip_head = TOWN && x0n > 0;                    // ... and the left neighbour owns the line my (stored) run starts in
 
+    const int ls = lane;
     for (int r = wave; r < p.lrows; r += NW) {
         const float *src = I1 + (long long)min(y0 + r, p.H - 1) * p.W + x0;
-        for (int s = lane; s < p.lcols; s += 64) {
+        for (int s = ls; s < p.lcols; s += 64) {
             if constexpr (C == 1) {
                 lds[r * p.pitch + s] = src[s];
             } else {
@@ -751,15 +829,16 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             }
         }
     }
-    {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE-1, padded to kT0W columns (quarter tasks read at +2w)
+    {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE (one more than a task row's NE: the tail cells belong to
+        // pixel x0+TX), padded to kT0W columns (quarter tasks read at +2w)
         px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
         for (int r = wave; r < t0rows; r += NW) {
-            if (lane < kT0W) {
-                const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(lane, NE - 1);
+            if (ls < kT0W) {
+                const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(ls, NE);
                 if constexpr (C == 1) {
-                    t0w[r * kT0W + lane] = src[0];
+                    t0w[r * kT0W + ls] = src[0];
                 } else {
-                    t0w[r * kT0W + lane] = make_float4(src[0], src[HW], src[2 * HW], 0.f);
+                    t0w[r * kT0W + ls] = make_float4(src[0], src[HW], src[2 * HW], 0.f);
                 }
             }
         }
@@ -777,8 +856,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
 
     // main task: chunk `wave`
+    // (lane predicates that do not change from row to row are either compile-time constants -- D = 1089: every lane of a
+    //  chunk and of the quarter tasks is inside the window -- or recomputed at their use from a laundered lane id: hoisted
+    //  out of the row loop each of them holds an SGPR pair for the whole sweep, and the scalar file is what this kernel
+    //  runs out of: 42 frame-0 scalars + pointers; a spilled pair costs two v_readlane per use)
     const int d = wave * 64 + lane;
-    const bool valid = d < D;
+    const bool valid = DC >= 1024 ? true : d < D;
     // lane address of a task: static tiles lds + (dy + r)*pitch + dx; column sweep lds + ((dy + r) & (lrows-1))*pitch + dx,
     // kept as the pair (dy, dx + column offset) packed into one register
     int lp;
@@ -796,18 +879,20 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
     const bool has_q = wave < NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
     const int dq = 1024 + lane;
-    const bool validq = dq < D;
+    const bool validq = DC >= 1088 ? true : dq < D;
     int lpq;
     {
         const int dc = validq ? dq : D - 1;
         const int dy = dc / p.wWin, dx = dc - dy * p.wWin + TQ * wave;
         lpq = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
     }
-    // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane
+    // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane; with tail-line ownership its
+    // lanes 32..62 are the cells 0..30 of the pixel after the run (column TX)
     constexpr int MW = NQW;                      // the mini task's wave: the first one without a quarter task
-    const bool has_m = wave == MW && D > 1088 && !(DFE_ABLATE & 8192);    // wave-uniform
-    const int dm = 1088 + (lane >> 3), xm = lane & 7;
-    const bool validm = dm < D && xm < TX;
+    const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
+    const bool mtail = TOWN && lane >= 32;
+    const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
+    const bool validm = mtail ? lane < 63 : (dm < D && xm < TX && (!TOWN || lane < 32));
     int lpm;
     {
         const int dc = validm ? dm : D - 1;
@@ -836,6 +921,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         if (wave == MW) rm[i * 64] = 0.f;
     }
 
+    long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
+    long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
     const int nq = (nsweep + U - 1) / U;
     for (int q = 0; q < nq; ++q) {
         static_for<0, U>([&](auto mc) {
@@ -845,7 +932,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
             const int y = y0 + r - (K - 1);
             const bool store_row = emit && y >= y0n;                         // block-uniform
-            const long long G0 = ((long long)y * p.Wo + x0) * D;             // global float index of the run
+            // (G0 = ((long long)y * p.Wo + x0) * D, the global float index of the run, and pg_run, the row's first entry of the
+            //  fused per-pixel planes, are carried from row to row: one 64-bit add each instead of two 64-bit multiplies)
+            const long long G0 = G0_run;
+            G0_run += (long long)p.Wo * D;
+            const long long pg_run = pg_next;
+            if constexpr (FUSE) pg_next += p.Wo;
             const int a0 = (int)(G0 & 31);
             float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
@@ -865,7 +957,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
                 }
                 if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
-                    if (store_row) fuse_plain_stores<TX>(v, lane, wave, (long long)(fa.row_off + y) * p.Wo + x0, fa);
+                    if (store_row) {
+                        int lf = lane;
+                        asm volatile("" : "+v"(lf));
+                        fuse_plain_stores<TX>(v, lf, wave, pg_run, fa, nover);
+                    }
                 }
             }
             if (has_q) {
@@ -897,8 +993,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         e[j] = sqdiff<3>(a3, bv);
                     }
                 }
+                // right-to-left chain = the association of column 0 of a main task (hsum_vh: sa[0]): the tail cells this task
+                // computes for the pixel after the run are bit-identical to what that pixel's own tile holds in its image
                 float h[1], v;
-                hsum<K, 1>(e, h);
+                h[0] = e[K - 1];
+#pragma unroll
+                for (int j = K - 2; j >= 0; --j) h[0] = e[j] + h[0];
                 if constexpr (K == 7) {
                     const float r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
                     v = (r0 + r2) + (r4 + h[0]);
@@ -910,10 +1010,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
                     for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
                 }
-                if (store_row && validm) {
+                if (store_row) {
                     int lm = lane;
-                    asm volatile("" : "+v"(lm));   // (same reason: keep this address out of the spill slots)
-                    st[(lm & 7) * D + 1088 + (lm >> 3)] = v;
+                    asm volatile("" : "+v"(lm));   // (keeps this address and the lane masks out of the scalar file / the spill slots)
+                    const bool mt = TOWN && lm >= 32;
+                    // (tail cells: only those that complete the run's last line, a0 + RUN + ntl == 0 mod 32)
+                    const bool ok = mt ? has_next && lm - 32 < ((-(a0 + RUN)) & 31) : 1088 + (lm >> 3) < D && (!TOWN || lm < 32);
+                    if (ok) st[mt ? TX * D + (lm - 32) : (lm & 7) * D + 1088 + (lm >> 3)] = v;
                 }
             }
             if (SWEEP || store_row) {
@@ -930,15 +1033,17 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         // that will take the slots of row r are requested.  This wave issues no stores at all, so waiting
                         // for its loads never waits for the store stream (loads and stores share vmcnt on gfx9).
                         px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
-                        const bool t1lane = lane < p.lcols, t0lane = !t1lane && lane - p.lcols < NE;
+                        int lw = lane;
+                        asm volatile("" : "+v"(lw));
+                        const bool t1lane = lw < p.lcols, t0lane = !t1lane && lw - p.lcols <= NE;
                         if (r >= 1 && !(DFE_ABLATE & 262144)) {
                             px_t px;
                             if constexpr (C == 1) px = hold[0]; else px = make_float4(hold[0], hold[1], hold[2], 0.f);
-                            if (t1lane) lds[((r - 1) & (p.lrows - 1)) * p.pitch + lane] = px;
-                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lane - p.lcols] = px;
+                            if (t1lane) lds[((r - 1) & (p.lrows - 1)) * p.pitch + lw] = px;
+                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lw - p.lcols] = px;
                         }
-                        const float *src = t1lane ? I1 + (long long)min(y0 + r + p.lrows, p.H - 1) * p.W + x0 + lane
-                                                  : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lane - p.lcols);
+                        const float *src = t1lane ? I1 + (long long)min(y0 + r + p.lrows, p.H - 1) * p.W + x0 + lw
+                                                  : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lw - p.lcols);
                         if (t1lane || t0lane) {
 #pragma unroll
                             for (int c = 0; c < C; ++c) hold[c] = src[c * HW];
@@ -956,7 +1061,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         // half 1 go to the two planes; finalize keeps the smaller, the first on ties.
                         constexpr int CPL = 9;                                // cells per lane: 128 lanes x 9 >= 1096
                         const int xx = wave >> 1, hh = wave & 1;
-                        const int c0 = (hh * 64 + lane) * CPL;
+                        int lsc = lane;
+                        asm volatile("" : "+v"(lsc));
+                        const int c0 = (hh * 64 + lsc) * CPL;
                         const float *px = st + xx * D;
                         int cv[CPL];
                         // This phase is bound by its instruction count (16 waves x ~70 VALU per row step), so the common case
@@ -986,23 +1093,25 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         const int vmin = (DFE_ABLATE & 16777216) ? best : wave_min1(best);
                         const int f = (DFE_ABLATE & 33554432) ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
                         const int bif = (DFE_ABLATE & 33554432) ? bi : __builtin_amdgcn_readlane(bi, f);
-                        if (lane == 0 && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
-                            fa.part[(long long)hh * fa.Ptot + (long long)(fa.row_off + y) * p.Wo + x0 + xx] =
+                        if (lsc == 0 && xx >= nover && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
+                            fa.part[(long long)hh * fa.Ptot + pg_run + xx] =
                                 make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
                     }
                 }
                 if (store_row && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
-                    const int head = (32 - a0) & 31;                         // floats before the first whole line
-                    const int nbody4 = ((RUN - head) >> 5) << 3;             // float4 pieces in whole 128-B lines
-                    const f4_t *sb = reinterpret_cast<const f4_t *>(st + head);
-                    const float *gb = out + G0 + head;
+                    const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
+                    const int head = (32 - (a0 + ov)) & 31;                  // floats before the first whole line
+                    const int ntl = has_next ? (-(a0 + RUN)) & 31 : 0;       // cells of the next pixel that complete the last line
+                    const int nbody4 = ((RUN - ov - head + ntl) >> 5) << 3;  // float4 pieces in whole 128-B lines
+                    const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
+                    const float *gb = out + G0 + ov + head;
                     int tj = tid;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
                     // at most 3 pieces per thread (TX*D/4 <= 2192 float4 over >= 960 threads): all LDS reads first, then the
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
-                    static_assert(3 * 15 * 64 >= TX * 1096 / 4, "three pieces per thread cover the run");
+                    static_assert(3 * 15 * 64 >= (TX * 1096 + 32) / 4, "three pieces per thread cover the run");
                     constexpr int STR = (SWEEP ? LW : NW) * 64;
                     f4_t val[3];
 #pragma unroll
@@ -1012,14 +1121,20 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         if (tj + i * STR < nbody4)
                             asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
-                        const int tail0 = head + (nbody4 << 2), ntail = RUN - tail0;
-                        if (wave == 5 && lane < head) out[G0 + lane] = st[lane];
+                        const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
+                        if (wave == 5 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
                         if (wave == 6 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
                     }
                 }
             }
         });
     }
+    if constexpr (!SWEEP) break;
+    pos += prows;
+    if (pos >= pend) break;
+    // next piece: every wave is past its last reads of the rings and the images (LDS-only barrier, the stores drain on)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
 }
 
 // LDS bytes of a static-tile block of `ty` output rows (0 = does not apply) and the kernel arguments that go with it
@@ -1075,8 +1190,18 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     return DFE_OK;
 }
 
-// Column sweep: one block per (8-pixel column, row segment).  The segment count is chosen so that rounds x rows swept
-// per block is smallest (VGA: 76 columns x 3 segments = 228 blocks on 256 CUs, 154 row steps instead of 6 x 30).
+// Column sweep, persistent: one block per CU, each walks its share of the column-major (8-pixel column, row) sequence
+// (sweep_cut).  Row steps per block ~ (ncols*Ho + ovh*(ncols + B)) / B -- VGA: 141 instead of the 3 x 51 of a 76 x 10 grid
+// of one-segment blocks; every CU ends within one row step of the others.
+constexpr int kSweepOvh = 9;    // row steps a piece costs before its first stored row: K-1 = 6 warm-up rows + ~3 for staging the rings
+constexpr int kSweepMin = 8;    // no piece shorter than this
+constexpr double kSweepFusedPenalty = 1.14;   // fused build: cost of a swept row of the sweep relative to static tiles
+static double sweep_cost(int ncols, int Ho, int B) { return ((double)ncols * Ho + (double)kSweepOvh * (ncols + B)) / B; }
+static int sweep_blocks(const dfe_ctx *ctx, int ncols, int Ho) {
+    long long b = (long long)ncols * Ho / 24;          // at least ~24 rows of work per block
+    if (b > ctx->ncu) b = ctx->ncu;
+    return b < 1 ? 1 : (int)b;
+}
 template <int C, int K, int TX, bool FUSE>
 static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
                                   float *out, const CvFuseArgs *fa, bool *handled) {
@@ -1092,20 +1217,15 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
     a.lrows = R;
     a.lcols = TX + K - 1 + wWin - 1;
-    if (a.lcols + TX + K - 1 > 64) return DFE_OK;   // one wave streams a tile row and a frame-0 row per step
+    if (a.lcols + TX + K > 64) return DFE_OK;   // one wave streams a tile row and a frame-0 row (NE + 1 pixels) per step
     const int M = Px<C>::bank_mod;
     a.pitch = a.lcols;
     while ((a.pitch - wWin) % M != 0) ++a.pitch;
     const int ncols = dfe_cdiv(Wo, TX);
-    int best_seg = 1;
-    long long best_cost = -1;
-    for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg) {
-        const long long rounds = dfe_cdiv(ncols * nseg, ctx->ncu);
-        const long long cost = rounds * (dfe_cdiv(Ho, nseg) + K - 1);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_seg = nseg; }
-    }
-    a.seg_rows = dfe_cdiv(Ho, best_seg);
-    const int nseg = dfe_cdiv(Ho, a.seg_rows);
+    a.seg_rows = 0;
+    a.sw_ovh = kSweepOvh; a.sw_min = kSweepMin;
+    if (const char *e = getenv("DFE_SWEEP_OVH")) a.sw_ovh = atoi(e);   // tuning
+    const int nblk = sweep_blocks(ctx, ncols, Ho);
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
     a.stage_off = a.tile0_off + (int)(((size_t)R0 * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
@@ -1118,7 +1238,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     auto kern = (D == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true, 1089>
                             : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, false, true>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    dim3 grid(ncols, nseg);
+    dim3 grid(nblk, 1);
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
@@ -1167,19 +1287,16 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
     if (code >= 100) ty = code - 100;
     else if (code >= 2) ty = U * code - (K - 1);
     else {
-        // Static tiles or the column sweep?  The sweep pays the K-1 warm-up rows once per segment; a swept
-        // row costs about the same in both (sweep: ring addressing and 15 copier waves; static: tile staging), measured
-        // VGA 241 against 260 us, 1080p 1730 against 1790 us, so the smaller rounds x rows wins.  In the fused build a swept
-        // row of the sweep costs ~14 % more (VGA: sweep 322 us at 154 rows, 36-row tiles 310 us at 168).
+        // Static tiles or the persistent column sweep?  Both cost about the same per swept row in the plain build; the sweep pays
+        // the K-1 warm-up rows once per piece and ends all CUs together, so the smaller count of row steps per CU wins.  In the
+        // fused build a swept row of the sweep costs more (128 VGPRs + spilled scalars), DFE_SWEEP_FUSED_PENALTY.
         const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
         double cost_static = 1e30;
         ty = rowimg_pick_ty<C, K, TX>(ctx, H, W, plane, hWin, wWin, &cost_static);
         if (ty && Wo >= TX) {
             const int ncols = dfe_cdiv(Wo, TX);
-            double cost_sweep = 1e30;
-            for (int nseg = 1; nseg <= 64 && (nseg == 1 || dfe_cdiv(Ho, nseg) >= 12); ++nseg)
-                cost_sweep = fmin(cost_sweep, (double)dfe_cdiv((long long)ncols * nseg, ctx->ncu) * (dfe_cdiv(Ho, nseg) + K - 1));
-            if (cost_sweep * (FUSE ? 1.16 : 1.04) < cost_static) {
+            const double cost_sweep = sweep_cost(ncols, Ho, sweep_blocks(ctx, ncols, Ho));
+            if (cost_sweep * (FUSE ? kSweepFusedPenalty : 1.0) < cost_static) {
                 int rc = launch_cv_rowimg_sweep<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
                 if (rc != DFE_OK || *handled) return rc;
             }
