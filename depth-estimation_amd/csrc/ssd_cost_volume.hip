@@ -220,6 +220,9 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
+#ifndef DFE_CW0
+#define DFE_CW0 5    // row-image kernel: first wave that takes part in the copy-out (0 = all waves)
+#endif
 #ifndef DFE_ST_FLAGS
 // cache-policy bits of the copy-out stores.  The volume streams out and nothing re-reads it from L2: with the non-temporal
 // hint the build measures 268 instead of 285 us at VGA and the step's finalize pass finds its planes still cached
@@ -243,19 +246,25 @@ __device__ __forceinline__ void store_uniform_base(const void *base, unsigned la
 // with the column minimum (a v_cmp IS a ballot), take the lowest set bit on the scalar unit and drop it into lane x.
 // the part of the fused epilogue that is plain stores: the centre cell's cost and the pixel's first DFE_LEAD cells
 template <int TX>
-__device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa, int nover = 0) {
+__device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int lane, int chunk, long long pg0, const CvFuseArgs &fa, int nover,
+                                                  int cmid, int lmid) {
     // Both are SGPR base + 32-bit lane offset dwordx4 stores: with 64-bit per-lane addresses the address arithmetic of these
     // few bytes cost the two waves that own them ~6 % of the whole fused row-image kernel (they sit before the barrier).
     static_assert(TX == 8, "two dwordx4 stores per lane");
     const f4_t lo = {vrow[0], vrow[1], vrow[2], vrow[3]}, hi = {vrow[4], vrow[5], vrow[6], vrow[7]};
-    if (!(DFE_ABLATE & 128) && chunk == fa.cmid && lane == fa.lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
+    // (row-image kernel, shifted last tile: the first nover columns are the neighbour's and are not stored from here.  That
+    //  rare path takes its column count through an asm barrier so that its per-column masks cannot be hoisted out of the
+    //  caller's row loop -- eight SGPR pairs held across the sweep, as first written, cost every tile ~30 v_readlane per row)
+    if (!(DFE_ABLATE & 128) && chunk == cmid && lane == lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
         const float *cb = fa.centre + pg0;
         if (nover == 0) {   // (wave-uniform)
             asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:16" ::"v"(0u), "v"(lo), "s"(cb), "v"(hi) : "memory");
-        } else {            // row-image kernel, shifted last tile: the first nover columns are the neighbour's
+        } else {
+            int nv = nover;
+            asm volatile("" : "+s"(nv));
 #pragma unroll
             for (int x = 0; x < TX; ++x)
-                if (x >= nover) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(0u), "v"(vrow[x]), "s"(cb), "n"(x * 4) : "memory");
+                if (x >= nv) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(0u), "v"(vrow[x]), "s"(cb), "n"(x * 4) : "memory");
         }
     }
     if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
@@ -265,9 +274,17 @@ __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int l
         // partial lines that miss L2 are what this memory system is slow at: section 4.2.)
         const float *lb = fa.lead + pg0 * DFE_LEAD;
         const unsigned off = (unsigned)lane * 4u;
+        if (nover == 0) {
 #pragma unroll
-        for (int x = 0; x < TX; ++x)
-            if (x >= nover) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
+            for (int x = 0; x < TX; ++x)
+                asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
+        } else {
+            int nv = nover;
+            asm volatile("" : "+s"(nv));
+#pragma unroll
+            for (int x = 0; x < TX; ++x)
+                if (x >= nv) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(vrow[x]), "s"(lb), "n"(x * DFE_LEAD * 4) : "memory");
+        }
     }
 }
 
@@ -275,7 +292,7 @@ template <int TX>
 __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool valid, int lane, int chunk, long long pg0,
                                               const CvFuseArgs &fa) {
     // (plain stores first: after them the values are only needed as keys)
-    fuse_plain_stores<TX>(vrow, lane, chunk, pg0, fa);
+    fuse_plain_stores<TX>(vrow, lane, chunk, pg0, fa, 0, fa.cmid, fa.lmid);
     __builtin_amdgcn_sched_barrier(0);
     int key[TX];
 #pragma unroll
@@ -749,6 +766,17 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
 // columns of the frame-0 tile in LDS: the NE = 14 positions of a task row, read at up to +6 (quarter tasks) + 15 (the
 // row of 16 a DPP broadcast reaches)
 constexpr int kT0W = 24;
+// compile-time LDS geometry of the 33 x 33 instantiations (what rowimg_plan / launch_cv_rowimg_sweep compute at run time)
+template <int C, int K, int TX> struct RowimgGeom {
+    static constexpr int R = 64, R0 = 8;                                   // column sweep: rows of the frame-1 / frame-0 rings
+    static constexpr int lcols33 = TX + K - 1 + 32;
+    static constexpr int M = Px<C>::bank_mod;
+    static constexpr int pitch33 = 33 + (lcols33 - 33 + M - 1) / M * M;    // smallest pitch >= lcols with pitch == wWin (mod M)
+    static constexpr int px_bytes = sizeof(typename Px<C>::type);
+    static constexpr int sweep_tile0_off = (R * pitch33 * px_bytes + 127) / 128 * 128;
+    static constexpr int sweep_stage_off = sweep_tile0_off + (R0 * kT0W * px_bytes + VUnroll<K>::value * 64 * 4 + 127) / 128 * 128;
+    static constexpr int stage_len33 = (TX * 1089 + 32 + 31) / 32 * 32;
+};
 // DC: the window's cell count as a compile-time constant (0 = run time).  With D known, the 8 deposit addresses per task row
 // (st + x*D + d), the scan's and the copy-out's become immediate offsets -- instructions of the lock-stepped phases.
 template <int C, int K, int TX, bool SM, bool FUSE, bool SWEEP, int DC = 0>
@@ -764,12 +792,22 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     constexpr int TQ = TX / NQW;                 // columns of such a share ("quarter task")
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
+    // 33 x 33 instantiation: the LDS geometry is a compile-time constant (rowimg_plan / launch_cv_rowimg_sweep compute the same
+    // numbers) -- fewer scalars to keep, immediate offsets instead of address arithmetic
+    constexpr bool CG = DC == 1089;
+    const int g_wWin = CG ? 33 : p.wWin, g_hWin = CG ? 33 : p.hWin;
+    const int g_lcols = CG ? TX + K - 1 + 32 : p.lcols;
+    const int g_pitch = CG ? RowimgGeom<C, K, TX>::pitch33 : p.pitch;
+    const int g_lrows = (CG && SWEEP) ? RowimgGeom<C, K, TX>::R : p.lrows;
+    const int g_tile0_off = (CG && SWEEP) ? RowimgGeom<C, K, TX>::sweep_tile0_off : p.tile0_off;
+    const int g_stage_off = (CG && SWEEP) ? RowimgGeom<C, K, TX>::sweep_stage_off : p.stage_off;
+    const int g_stage_len = CG ? RowimgGeom<C, K, TX>::stage_len33 : p.stage_len;
     px_t *lds = reinterpret_cast<px_t *>(dfe_smem);                             // frame-1 tile [lrows][pitch]
-    const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + p.tile0_off);    // frame-0 tile [ROWS][32]
-    float *stage = reinterpret_cast<float *>(dfe_smem + p.stage_off);          // [2][stage_len], 128-B aligned
+    const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + g_tile0_off);    // frame-0 tile [ROWS][32]
+    float *stage = reinterpret_cast<float *>(dfe_smem + g_stage_off);          // [2][stage_len], 128-B aligned
 
     const long long HW = p.plane;
-    const int oy = (p.hWin - 1) >> 1, ox = (p.wWin - 1) >> 1;
+    const int oy = (g_hWin - 1) >> 1, ox = (g_wWin - 1) >> 1;
     // Tail-line ownership (33 x 33 instantiation): the run of 8 pixels ends inside a 128-B line whose other part belongs to the
     // NEXT pixel of the image row.  Two blocks writing the two parts of such a line only works while both parts meet in one
     // L2 (partial lines that miss L2 cost a read-modify-write at the memory, section 4.2), which ties the schedule to the
@@ -780,7 +818,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // Static tiles: one piece per block, XCD-aware block order (hardware deals linear block ids round-robin to the 8 XCDs; give
     // every XCD a contiguous range of tiles, x fastest, so neighbours in x share an L2), TY output rows per block, the last
     // tile row shifted inwards.  Column sweep: the block walks down its range of the column-major (column, row) sequence
-    // (sweep_cut), one piece per column it touches; the frame-1 tile is a ring of p.lrows (= 64) rows that wave LW keeps
+    // (sweep_cut), one piece per column it touches; the frame-1 tile is a ring of g_lrows (= 64) rows that wave LW keeps
     // filled a row step ahead, so the K-1 warm-up rows are paid once per piece instead of once per TY rows.
     // (static tiles: p.seg_rows is the tile height, a run-time value -- one instantiation serves every height)
     int pos = 0, pend = 1, bx = 0, by = 0;
@@ -819,19 +857,19 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const bool skip_head = TOWN && x0n > 0;                    // ... and the left neighbour owns the line my (stored) run starts in
 
     const int ls = lane;
-    for (int r = wave; r < p.lrows; r += NW) {
+    for (int r = wave; r < g_lrows; r += NW) {
         const float *src = I1 + (long long)min(y0 + r, p.H - 1) * p.W + x0;
-        for (int s = ls; s < p.lcols; s += 64) {
+        for (int s = ls; s < g_lcols; s += 64) {
             if constexpr (C == 1) {
-                lds[r * p.pitch + s] = src[s];
+                lds[r * g_pitch + s] = src[s];
             } else {
-                lds[r * p.pitch + s] = make_float4(src[s], src[HW + s], src[2 * HW + s], 0.f);
+                lds[r * g_pitch + s] = make_float4(src[s], src[HW + s], src[2 * HW + s], 0.f);
             }
         }
     }
     {   // frame-0 tile: rows y0+oy.., columns x0+ox..x0+ox+NE (one more than a task row's NE: the tail cells belong to
         // pixel x0+TX), padded to kT0W columns (quarter tasks read at +2w)
-        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
+        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + g_tile0_off);
         for (int r = wave; r < t0rows; r += NW) {
             if (ls < kT0W) {
                 const float *src = I0 + (long long)min(y0 + oy + r, p.H - 1) * p.W + (x0 + ox) + min(ls, NE);
@@ -846,7 +884,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const long long a_base = (long long)(y0 + oy) * p.W + (x0 + ox);
     __syncthreads();
 
-    const int D = DC ? DC : p.hWin * p.wWin;
+    const int D = DC ? DC : g_hWin * g_wWin;
     const int RUN = TX * D;                       // floats in the block's run
     const int l16 = lane & 15;
     float av[C][NE];
@@ -867,14 +905,24 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     int lp;
     {
         const int dc = valid ? d : D - 1;         // idle lanes shadow the last cell, their deposits are masked
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
-        lp = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
+        const int dy = dc / g_wWin, dx = dc - dy * g_wWin;
+        lp = SWEEP ? (dy << 16 | dx) : dy * g_pitch + dx;
     }
+    // Column sweep: a task's lane address is carried as a byte offset into the ring and stepped one ring row per sweep row
+    // (add, subtract the ring size, unsigned minimum: three full-rate ops, no multiply, no per-row unpacking of (dy, dx)).
+    const unsigned ringB = (unsigned)(g_lrows * g_pitch) * (unsigned)sizeof(px_t), pitchB = (unsigned)g_pitch * (unsigned)sizeof(px_t);
+    auto ring_off0 = [&](int packed) -> int {   // (dy, dx) -> byte offset of ring row dy, column dx (sweep row 0)
+        return (int)((unsigned)(packed >> 16) * pitchB + (unsigned)(packed & 0xffff) * (unsigned)sizeof(px_t));
+    };
+    auto ring_step = [&](int &off) {
+        const unsigned t = (unsigned)off + pitchB;
+        off = (int)min(t, t - ringB);           // t < ringB: t - ringB wraps to a huge number
+    };
     auto row_ptr = [&](int packed, int r) -> const px_t * {
-        if constexpr (SWEEP)   // (a 24-bit multiply here measured 15 % SLOWER at 720p than the plain one)
-            return lds + (((packed >> 16) + r) & (p.lrows - 1)) * p.pitch + (packed & 0xffff);
+        if constexpr (SWEEP)
+            return reinterpret_cast<const px_t *>(reinterpret_cast<const char *>(lds) + packed);
         else
-            return lds + packed + r * p.pitch;
+            return lds + packed + r * g_pitch;
     };
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
     const bool has_q = wave < NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
@@ -883,8 +931,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     int lpq;
     {
         const int dc = validq ? dq : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin + TQ * wave;
-        lpq = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
+        const int dy = dc / g_wWin, dx = dc - dy * g_wWin + TQ * wave;
+        lpq = SWEEP ? (dy << 16 | dx) : dy * g_pitch + dx;
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane; with tail-line ownership its
     // lanes 32..62 are the cells 0..30 of the pixel after the run (column TX)
@@ -896,10 +944,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     int lpm;
     {
         const int dc = validm ? dm : D - 1;
-        const int dy = dc / p.wWin, dx = dc - dy * p.wWin + xm;
-        lpm = SWEEP ? (dy << 16 | dx) : dy * p.pitch + dx;
+        const int dy = dc / g_wWin, dx = dc - dy * g_wWin + xm;
+        lpm = SWEEP ? (dy << 16 | dx) : dy * g_pitch + dx;
     }
 
+    if constexpr (SWEEP) { lp = ring_off0(lp); lpq = ring_off0(lpq); lpm = ring_off0(lpm); }
     // waves with an extra task get issue priority: they run ahead while their three SIMD-mates fill the gaps, instead of
     // finishing their surplus alone (one wave per SIMD hides no latency) while 15 waves sit at the barrier.
     // (Tried and dropped: letting the odd waves run a row's flow epilogue after the barrier, from the row image, to
@@ -908,7 +957,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     else if (has_m) __builtin_amdgcn_s_setprio(2);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
-    float *rm = reinterpret_cast<float *>(dfe_smem + p.tile0_off + t0rows * kT0W * sizeof(px_t)) + lane;
+    float *rm = reinterpret_cast<float *>(dfe_smem + g_tile0_off + t0rows * kT0W * sizeof(px_t)) + lane;
     float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
 #pragma unroll
     for (int c = 0; c < C; ++c) hold[c] = 0.f;
@@ -921,6 +970,51 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         if (wave == MW) rm[i * 64] = 0.f;
     }
 
+    // Flow epilogue from the row image (FUSE): after the barrier of row r the run of every pixel of that row is complete in
+    // image (r & 1), so two waves per pixel scan it -- every lane 9 consecutive cells (strict '<' keeps the lane's first
+    // minimum), one wave minimum, the lowest lane attaining it owns the first index; half 0 / half 1 go to the two planes
+    // of fa.part, finalize keeps the smaller, the first on ties.  ~55 VALU per wave and row, but a chain (LDS latency, min
+    // tree, 6 DPP steps, ballot, readlane) that nothing overlaps where it sits, between the barrier and the copy-out:
+    // 0.39 us of a 2.06 us row step (ablation, VGA, persistent sweep).  Moving it does not help: run for row r-1 inside the
+    // sweep of row r on the twelve waves without a quarter task (one or two half-pixel units each, at the end of their row
+    // body, the last row of a piece scanned after the loop) it was bit-identical and 9 % SLOWER (316 against 290 us) -- the
+    // chain then sits on the critical path of 12 waves instead of being shared by 16; after the copy-out, split around
+    // it, or with its reads issued with the copy-out's it measured +3..5 % (round 1).
+    auto scan_row = [&](const float *stp, long long pgp) {   // stp: image of the row to scan (+ its a0), pgp: its first entry in the planes
+        if (DFE_ABLATE & 512) return;
+        constexpr int CPL = 9;                                         // cells per lane: 128 lanes x 9 >= 1096
+        int lsc = lane;
+        asm volatile("" : "+v"(lsc));
+        {
+            const int xx = wave >> 1, hh = wave & 1;
+            const int c0 = (hh * 64 + lsc) * CPL;
+            const float *px = stp + xx * D;
+            int cv[CPL];
+            bool lane_out = false;                                     // fast path (D = 9 n): this lane lies entirely outside the window
+            if (D % CPL == 0) {                                        // block-uniform
+                lane_out = c0 >= D;
+                const int *pc = reinterpret_cast<const int *>(px) + (lane_out ? 0 : c0);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) cv[i] = pc[i];           // all reads in flight
+            } else {
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) cv[i] = c0 + i < D ? cv[i] : 0x7f800000;
+            }
+            static_assert(CPL == 9, "min tree below is written for 9 cells");
+            int best = min(min(min(cv[0], cv[1]), min(cv[2], cv[3])), min(min(min(cv[4], cv[5]), min(cv[6], cv[7])), cv[8]));
+            int bi = CPL - 1;
+#pragma unroll
+            for (int i = CPL - 2; i >= 0; --i) bi = cv[i] == best ? i : bi;
+            best = lane_out ? 0x7f800000 : best;
+            const int vmin = (DFE_ABLATE & 16777216) ? best : wave_min1(best);
+            const int f = (DFE_ABLATE & 33554432) ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
+            const int bif = (DFE_ABLATE & 33554432) ? bi : __builtin_amdgcn_readlane(bi, f);
+            if (lsc == 0 && xx >= nover && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
+                fa.part[(long long)hh * fa.Ptot + pgp + xx] = make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
+        }
+    };
     long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
     long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
     const int nq = (nsweep + U - 1) / U;
@@ -939,7 +1033,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const long long pg_run = pg_next;
             if constexpr (FUSE) pg_next += p.Wo;
             const int a0 = (int)(G0 & 31);
-            float *st = stage + (r & 1) * p.stage_len + a0;                  // image of the run, congruent mod 32
+            float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
             if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
@@ -947,6 +1041,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 if constexpr (!SM) a = t0[t0r + l16];
                 float v[TX];
                 rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
+                if constexpr (SWEEP) ring_step(lp);
                 if constexpr (SM) {   // next row's scalars
 #pragma unroll
                     for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
@@ -960,7 +1055,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     if (store_row) {
                         int lf = lane;
                         asm volatile("" : "+v"(lf));
-                        fuse_plain_stores<TX>(v, lf, wave, pg_run, fa, nover);
+                        // (33 x 33: the centre cell, 1-based 545, is lane 32 of chunk 8)
+                        fuse_plain_stores<TX>(v, lf, wave, pg_run, fa, nover, CG ? 8 : fa.cmid, CG ? 32 : fa.lmid);
                     }
                 }
             }
@@ -971,6 +1067,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 const float avq[C][TQ + K - 1] = {};
                 float v[TQ];
                 rowimg_task_row<C, K, TQ, m, false>(row_ptr(lpq, r), a, avq, ringq, v);
+                if constexpr (SWEEP) ring_step(lpq);
                 if (store_row && validq) {
 #pragma unroll
                     for (int x = 0; x < TQ; ++x) st[(TQ * wave + x) * D + dq] = v[x];
@@ -979,6 +1076,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             if (has_m) {
                 // per-lane frame-0 pixels: no broadcast here, every lane has its own column
                 const px_t *lr = row_ptr(lpm, r);
+                if constexpr (SWEEP) ring_step(lpm);
                 const px_t *ar = t0 + t0r + xm;
                 float e[K];
 #pragma unroll
@@ -1032,18 +1130,20 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         // left at r-1 (no wave reads them again; their first use is >= 2 barriers away), then the rows
                         // that will take the slots of row r are requested.  This wave issues no stores at all, so waiting
                         // for its loads never waits for the store stream (loads and stores share vmcnt on gfx9).
-                        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + p.tile0_off);
+                        px_t *t0w = reinterpret_cast<px_t *>(dfe_smem + g_tile0_off);
                         int lw = lane;
                         asm volatile("" : "+v"(lw));
-                        const bool t1lane = lw < p.lcols, t0lane = !t1lane && lw - p.lcols <= NE;
+                        const bool t1lane = lw < g_lcols, t0lane = !t1lane && lw - g_lcols <= NE;
                         if (r >= 1 && !(DFE_ABLATE & 262144)) {
                             px_t px;
                             if constexpr (C == 1) px = hold[0]; else px = make_float4(hold[0], hold[1], hold[2], 0.f);
-                            if (t1lane) lds[((r - 1) & (p.lrows - 1)) * p.pitch + lw] = px;
-                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lw - p.lcols] = px;
+                            if (t1lane) lds[((r - 1) & (g_lrows - 1)) * g_pitch + lw] = px;
+                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lw - g_lcols] = px;
                         }
-                        const float *src = t1lane ? I1 + (long long)min(y0 + r + p.lrows, p.H - 1) * p.W + x0 + lw
-                                                  : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lw - p.lcols);
+                        // (running row pointers instead of these multiplies -- one add per row, fewer scalars to keep -- measured 4 %
+                        //  slower on the plain build and changed nothing in the spill count)
+                        const float *src = t1lane ? I1 + (long long)min(y0 + r + g_lrows, p.H - 1) * p.W + x0 + lw
+                                                  : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lw - g_lcols);
                         if (t1lane || t0lane) {
 #pragma unroll
                             for (int c = 0; c < C; ++c) hold[c] = src[c * HW];
@@ -1051,79 +1151,43 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     }
                 }
                 if constexpr (FUSE) {
-                    if (store_row && !(DFE_ABLATE & 512)) {
-                        // Flow epilogue from the row image: the run of pixel x is complete in LDS, so two waves per pixel
-                        // scan it -- every lane 9 consecutive cells (strict '<' keeps the lane's first minimum), one wave
-                        // minimum, the lowest lane attaining it owns the first index.  ~55 VALU per wave and row instead of
-                        // a butterfly + 8 ballots per TASK and row on values in registers (~95); in time the two are equal
-                        // (the scan sits between the barrier and the copy-out, its LDS latency exposed; after the
-                        // copy-out it measured 5 % slower, split around it it spills), but finalize reads 2 planes of fa.part instead of 18.  Half 0 /
-                        // half 1 go to the two planes; finalize keeps the smaller, the first on ties.
-                        constexpr int CPL = 9;                                // cells per lane: 128 lanes x 9 >= 1096
-                        const int xx = wave >> 1, hh = wave & 1;
-                        int lsc = lane;
-                        asm volatile("" : "+v"(lsc));
-                        const int c0 = (hh * 64 + lsc) * CPL;
-                        const float *px = st + xx * D;
-                        int cv[CPL];
-                        // This phase is bound by its instruction count (16 waves x ~70 VALU per row step), so the common case
-                        // D = 9 * n (33 x 33 = 9 * 121) drops the per-cell clamps and masks: a lane is either entirely inside
-                        // the window or entirely outside.
-                        bool lane_out = false;                                // fast path: this lane lies entirely outside the window
-                        if (D % CPL == 0) {                                   // block-uniform
-                            lane_out = c0 >= D;
-                            const int *pc = reinterpret_cast<const int *>(px) + (lane_out ? 0 : c0);
-#pragma unroll
-                            for (int i = 0; i < CPL; ++i) cv[i] = pc[i];      // all reads in flight
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < CPL; ++i) cv[i] = __float_as_int(px[min(c0 + i, D - 1)]);
-#pragma unroll
-                            for (int i = 0; i < CPL; ++i) cv[i] = c0 + i < D ? cv[i] : 0x7f800000;
-                        }
-                        // shallow dependency chains (every wave of the block is in this phase at once, nothing else hides
-                        // latency): the lane minimum as a tree of 3-input minima, its first position independently of
-                        // the wave reduction that follows
-                        static_assert(CPL == 9, "min tree below is written for 9 cells");
-                        int best = min(min(min(cv[0], cv[1]), min(cv[2], cv[3])), min(min(min(cv[4], cv[5]), min(cv[6], cv[7])), cv[8]));
-                        int bi = CPL - 1;
-#pragma unroll
-                        for (int i = CPL - 2; i >= 0; --i) bi = cv[i] == best ? i : bi;
-                        best = lane_out ? 0x7f800000 : best;
-                        const int vmin = (DFE_ABLATE & 16777216) ? best : wave_min1(best);
-                        const int f = (DFE_ABLATE & 33554432) ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
-                        const int bif = (DFE_ABLATE & 33554432) ? bi : __builtin_amdgcn_readlane(bi, f);
-                        if (lsc == 0 && xx >= nover && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
-                            fa.part[(long long)hh * fa.Ptot + pg_run + xx] =
-                                make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
-                    }
+                    if (store_row) scan_row(st, pg_run);
                 }
-                if (store_row && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
+                // Copy-out by the waves WITHOUT an extra task (DFE_CW0.., 10 or 11 of them): a CU's vector-memory path takes 64 B
+                // per clock, i.e. ~545 cycles for the 34 848 B of a row, and every wave that stores waits its turn in it.  With all
+                // waves copying, the four quarter-task waves -- the critical path of the sweep -- started the next row up to 0.2 us
+                // late (per-CU row step 1.48 us against 1.27 us of compute, measured with the memory unsaturated); the copier waves
+                // have that much slack before the next barrier.
+                // (Fused build: all waves copy -- they are all held by the scan before it, and fewer copiers then only take
+                //  longer: 298 against 290 us.)
+                constexpr int CW0 = FUSE ? 0 : DFE_CW0;                      // first copier wave
+                constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
+                if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
                     const int head = (32 - (a0 + ov)) & 31;                  // floats before the first whole line
                     const int ntl = has_next ? (-(a0 + RUN)) & 31 : 0;       // cells of the next pixel that complete the last line
                     const int nbody4 = ((RUN - ov - head + ntl) >> 5) << 3;  // float4 pieces in whole 128-B lines
                     const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
                     const float *gb = out + G0 + ov + head;
-                    int tj = tid;
+                    int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
                     // at most 3 pieces per thread (TX*D/4 <= 2192 float4 over >= 960 threads): all LDS reads first, then the
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
-                    static_assert(3 * 15 * 64 >= (TX * 1096 + 32) / 4, "three pieces per thread cover the run");
-                    constexpr int STR = (SWEEP ? LW : NW) * 64;
-                    f4_t val[3];
+                    constexpr int STR = NCW * 64;
+                    constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
+                    f4_t val[NPC];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
+                    for (int i = 0; i < NPC; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
 #pragma unroll
-                    for (int i = 0; i < 3; ++i)
+                    for (int i = 0; i < NPC; ++i)
                         if (tj + i * STR < nbody4)
                             asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
-                        if (wave == 5 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
-                        if (wave == 6 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
+                        if (wave == CW0 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
+                        if (wave == CW0 + 1 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
                     }
                 }
             }
@@ -1176,7 +1240,9 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     const size_t lds_bytes = rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, &a);
     if (!lds_bytes) return DFE_OK;
     // the +-16 search (33 x 33 = 1089 cells) gets the instantiation with D as a constant
-    auto kern = (hWin * wWin == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 1089>
+    if (hWin == 33 && wWin == 33 && (a.pitch != RowimgGeom<C, K, TX>::pitch33 || a.stage_len != RowimgGeom<C, K, TX>::stage_len33))
+        return dfe_fail(ctx, DFE_E_UNSUPPORTED, "row-image kernel: LDS geometry differs from the kernel's constants");
+    auto kern = (hWin == 33 && wWin == 33) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 1089>
                                       : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(a.Wo, TX), dfe_cdiv(a.Ho, ty));
@@ -1195,12 +1261,23 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
 // of one-segment blocks; every CU ends within one row step of the others.
 constexpr int kSweepOvh = 9;    // row steps a piece costs before its first stored row: K-1 = 6 warm-up rows + ~3 for staging the rings
 constexpr int kSweepMin = 8;    // no piece shorter than this
-constexpr double kSweepFusedPenalty = 1.14;   // fused build: cost of a swept row of the sweep relative to static tiles
+constexpr double kSweepFusedPenalty = 1.08;   // fused build: cost of a swept row of the sweep relative to static tiles (VGA: 2.05 against 1.88 us)
 static double sweep_cost(int ncols, int Ho, int B) { return ((double)ncols * Ho + (double)kSweepOvh * (ncols + B)) / B; }
 static int sweep_blocks(const dfe_ctx *ctx, int ncols, int Ho) {
     long long b = (long long)ncols * Ho / 24;          // at least ~24 rows of work per block
     if (b > ctx->ncu) b = ctx->ncu;
     return b < 1 ? 1 : (int)b;
+}
+// Aligned fronts: with k = CUs / columns >= 2 whole segments per column, k * ncols blocks cut every column into k equal
+// segments (ovh = 0 in sweep_cut), so the blocks of one segment index walk down their columns in lockstep and write a
+// CONTIGUOUS image row (ncols x 34 KB) at a time -- k moving fronts instead of one per CU.  The memory system prefers that
+// by far (tools/ubench/stores11.hip, whole-line nt stores paced like the kernel: 3 fronts of 76 runs 6.1 TB/s, 256
+// scattered 34-KB fronts 4.7-5.3 TB/s, one contiguous 8.9-MB front 6.6 TB/s), and the plain build is bound by its store
+// stream: VGA, 228 aligned blocks x 154 row steps measures the same as or better than 256 balanced blocks x 141 (222 / 221 us,
+// 228 / 238 us on two boxes).  The fused build is bound by its arithmetic and keeps the balanced cut.
+static int sweep_aligned_k(const dfe_ctx *ctx, int ncols, int Ho) {
+    const int k = ctx->ncu / ncols;
+    return (k >= 2 && Ho / k >= 24) ? k : 0;
 }
 template <int C, int K, int TX, bool FUSE>
 static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
@@ -1211,7 +1288,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
     const int D = hWin * wWin;
     *handled = false;
-    if (D <= 768 || D > 1096 || Ho < 1 || Wo < TX || hWin + 2 > R) return DFE_OK;
+    if (D <= 768 || D > 1096 || Ho < 1 || Wo < TX || hWin + 2 > R || (hWin - 1) / 2 + R0 > hWin - 1) return DFE_OK;
     CvTiledArgs a;
     a.plane = plane;
     a.H = H; a.W = W; a.hWin = hWin; a.wWin = wWin; a.Ho = Ho; a.Wo = Wo;
@@ -1224,8 +1301,11 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     const int ncols = dfe_cdiv(Wo, TX);
     a.seg_rows = 0;
     a.sw_ovh = kSweepOvh; a.sw_min = kSweepMin;
+    int nblk = sweep_blocks(ctx, ncols, Ho);
+    if (const int k = FUSE ? 0 : sweep_aligned_k(ctx, ncols, Ho)) { nblk = k * ncols; a.sw_ovh = 0; }
     if (const char *e = getenv("DFE_SWEEP_OVH")) a.sw_ovh = atoi(e);   // tuning
-    const int nblk = sweep_blocks(ctx, ncols, Ho);
+    if (const char *e = getenv("DFE_SWEEP_BLOCKS")) nblk = atoi(e);    // tuning
+    if (nblk < 1 || (long long)(Ho + a.sw_ovh) * ncols * nblk >= (1ll << 31)) return DFE_OK;   // sweep_cut works in 32 bits
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
     a.stage_off = a.tile0_off + (int)(((size_t)R0 * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
@@ -1233,9 +1313,13 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     a.chunk0 = 0;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return DFE_OK;
+    const bool sq33 = hWin == 33 && wWin == 33;
+    if (sq33 && (a.pitch != RowimgGeom<C, K, TX>::pitch33 || a.tile0_off != RowimgGeom<C, K, TX>::sweep_tile0_off ||
+                 a.stage_off != RowimgGeom<C, K, TX>::sweep_stage_off || a.stage_len != RowimgGeom<C, K, TX>::stage_len33))
+        return dfe_fail(ctx, DFE_E_UNSUPPORTED, "row-image sweep: LDS geometry differs from the kernel's constants");
     // the fused sweep fits the register file only with D as a constant (33 x 33); other windows: static tiles
-    if (FUSE && D != 1089) return DFE_OK;
-    auto kern = (D == 1089) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true, 1089>
+    if (FUSE && !sq33) return DFE_OK;
+    auto kern = sq33 ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, true, 1089>
                             : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, false, true>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(nblk, 1);
@@ -1295,7 +1379,8 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
         ty = rowimg_pick_ty<C, K, TX>(ctx, H, W, plane, hWin, wWin, &cost_static);
         if (ty && Wo >= TX) {
             const int ncols = dfe_cdiv(Wo, TX);
-            const double cost_sweep = sweep_cost(ncols, Ho, sweep_blocks(ctx, ncols, Ho));
+            const int ka = FUSE ? 0 : sweep_aligned_k(ctx, ncols, Ho);
+            const double cost_sweep = ka ? dfe_cdiv(Ho, ka) + K - 1 : sweep_cost(ncols, Ho, sweep_blocks(ctx, ncols, Ho));
             if (cost_sweep * (FUSE ? kSweepFusedPenalty : 1.0) < cost_static) {
                 int rc = launch_cv_rowimg_sweep<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
                 if (rc != DFE_OK || *handled) return rc;
