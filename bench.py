@@ -48,6 +48,98 @@ def algorithmic_bytes(H, W, Cc, k, hWin, wWin):
     return 2 * Cc * H * W * 4 + Ho * Wo * hWin * wWin * 4
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# multi-GPU protocol: pairs are independent -> pair p runs on rank p mod world, no data-path collective;
+# the only collectives are the barrier / max-over-ranks of the timing and the optional gather of the results to rank 0.
+# These functions take the process group, the device and the synchronise callable from the caller, so that
+# tests/test_dist_cpu.py drives exactly this code on gloo / CPU with an injected step.
+# ------------------------------------------------------------------------------------------------------------------
+def shard_pairs(n_pairs, world, rank):
+    """Pair ids this rank processes: p -> rank p mod world (north_star: one pair per GPU when a batch splits naturally)."""
+    return [p for p in range(n_pairs) if p % world == rank]
+
+
+def free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def timed_region(step, steps, warmup, world, dist, device, sync, spin_s=0.08, before_timed=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + sync on both sides; returns the MAX over ranks of
+    the elapsed seconds (every rank gets it).  `spin_s` of untimed steps first: the GPU needs ~50 ms of work to reach its
+    sustained clocks (after 20 steps alone the same run reads 2.5 % low)."""
+    import torch
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < spin_s:
+        for _ in range(20):
+            step()
+        sync()
+    for _ in range(warmup):
+        step()
+    barrier()
+    if before_timed:
+        before_timed()
+        barrier()
+    t_start = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item())
+
+
+def gather_results(tensors, world, rank, dist, sync):
+    """Optional result gather: every rank's per-pair outputs -- flow as int16 x 2, confidence and depth fp32 --
+    to rank 0 over the process group (RCCL gather over xGMI on the GPU box), timed on its own, outside the timed region.
+    Returns (list of per-rank tensor lists on rank 0 / None elsewhere, seconds, bytes received by rank 0)."""
+    import torch
+
+    if world == 1:
+        return [tensors], 0.0, 0
+    dist.barrier()
+    sync()
+    t = time.perf_counter()
+    out, nbytes = [], 0
+    for x in tensors:
+        wire = x.contiguous().view(torch.uint8) if x.dtype == torch.int16 else x   # (neither RCCL nor gloo has an int16 type: bytes)
+        dst = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
+        dist.gather(wire, dst, dst=0)
+        out.append([t.view(x.dtype) for t in dst] if rank == 0 else None)
+        nbytes += x.numel() * x.element_size() * (world - 1)
+    sync()
+    dist.barrier()
+    secs = time.perf_counter() - t
+    if rank != 0:
+        return None, secs, nbytes
+    return [[out[i][r] for i in range(len(tensors))] for r in range(world)], secs, nbytes
+
+
+def launch_ranks(gpus, argv):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes under torch.distributed.run (one per GPU,
+    RCCL) and relay their output and exit code.  Called before this process touches torch.cuda or libdfe -- the ranks are
+    children, never a re-exec of a process that has initialised the GPU."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(f0, f1, k, hWin, wWin, cx, cy, budget_s=12.0):
     """The oracle (a port of the reference's CPU loop nest: 5-deep SSD loop with OpenMP over output
     rows + min/tie-break + extractOutput + decode + depth), timed on a band of output rows sized
@@ -120,30 +212,7 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
         ctx.check(lib.dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, k, maxh, maxw, rr, len(ratios),
                                                   flow.data_ptr(), None))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # clock ramp: the GPU needs ~50 ms of work to reach its sustained clocks (after 20 steps the same run reads 2.5 % low), so
-    # a short untimed spin precedes the W warm-up steps whatever W is
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.08:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize)
     if rank == 0:
         balg = 2 * Cc * Hp * Wp * 4 + sum((Hp // r) * (Wp // r) * maxh * maxw * 4 for r in ratios)
         step_s = elapsed / args.steps
@@ -171,7 +240,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed) gather of the results to rank 0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher (nothing below has touched the GPU yet)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -184,7 +258,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdfe has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -195,7 +269,8 @@ def main():
     if args.workload in PYRAMIDS:
         return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
     H, W, Cc, k, hWin, wWin = WORKLOADS[args.workload]
-    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=rank, max_flow=12)  # one seeded pair per rank
+    (pair_id,) = shard_pairs(world, world, rank)                              # a batch of `world` pairs, pair p on rank p
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=pair_id, max_flow=12)  # one seeded pair per rank
     t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
     flow = torch.empty((2, H, W), device=dev)
     scores = torch.empty((H, W), device=dev)
@@ -212,29 +287,14 @@ def main():
             )
         )
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    kernel = [None]
 
-    # clock ramp: the GPU needs ~50 ms of work to reach its sustained clocks (after 20 steps the same run reads 2.5 % low), so
-    # a short untimed spin precedes the W warm-up steps whatever W is
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 0.08:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    kernel = ctx.last_kernel()
-    ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t_start
+    def before_timed():
+        kernel[0] = ctx.last_kernel()
+        ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
+
+    elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize, before_timed=before_timed)
+    kernel = kernel[0]
     cv_ms, cv_n = C.c_double(), C.c_int()
     ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(cv_ms), C.byref(cv_n)))
     ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
@@ -260,10 +320,13 @@ def main():
         except torch.OutOfMemoryError:
             pass
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    gather = None
+    if world > 1 and not args.no_gather:
+        # results of the batch to rank 0 (flow as int16 x 2 -- displacements are integers in +-16 --, scores and depth fp32)
+        res, g_s, g_bytes = gather_results([flow.to(torch.int16), scores, depth], world, rank, dist, torch.cuda.synchronize)
+        if rank == 0:
+            assert len(res) == world and torch.equal(res[0][1], scores)
+            gather = {"ms": round(g_s * 1e3, 3), "bytes_to_rank0": g_bytes, "note": "untimed: after the K steps, one gather of every pair's {flow int16 x2, scores, depth}"}
 
     if rank == 0:
         balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin)
@@ -320,6 +383,8 @@ def main():
                 "kernel_ms": round(build_ms, 5),
                 "launches_timed": 20, "note": "dfe_ssd_cost_volume_f32 alone, measured after the timed region",
             }
+        if gather:
+            out["gather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(f0, f1, k, hWin, wWin, cx, cy)
         print(json.dumps(out), flush=True)

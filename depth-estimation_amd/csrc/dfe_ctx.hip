@@ -42,6 +42,9 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
         return dfe_fail(nullptr, DFE_E_HIP, "dfe_ctx_create: no HIP device (%s); libdfe has no CPU fallback",
                         e != hipSuccess ? hipGetErrorString(e) : "device count 0");
     if (device < 0 || device >= n) return dfe_fail(nullptr, DFE_E_ARG, "dfe_ctx_create: device %d of %d", device, n);
+    int prev_device = -1;
+    (void)hipGetDevice(&prev_device);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev_device};   // the caller's current device is not ours to change
     e = hipSetDevice(device);
     if (e != hipSuccess) return dfe_fail(nullptr, DFE_E_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
     hipDeviceProp_t prop;
@@ -69,7 +72,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
 
 void dfe_ctx_destroy(dfe_ctx *ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DfeDeviceGuard guard(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -81,7 +84,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
 const char *dfe_last_error(const dfe_ctx *ctx) { return ctx ? ctx->err : g_create_err; }
 
 int dfe_ctx_synchronize(dfe_ctx *ctx) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DFE_OK;
 }
@@ -90,20 +93,21 @@ void *dfe_ctx_stream(dfe_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr;
 
 int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr) {
     DFE_REQUIRE(ctx, ctx && dptr, DFE_E_ARG, "dfe_malloc: NULL argument");
-    DFE_HIP(ctx, hipSetDevice(ctx->device));
+    DfeDeviceGuard guard(ctx);
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     return DFE_OK;
 }
 
 int dfe_free(dfe_ctx *ctx, void *dptr) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     if (dptr) DFE_HIP(ctx, hipFree(dptr));
     return DFE_OK;
 }
 
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
     DFE_REQUIRE(ctx, ctx && (bytes == 0 || (dst && src)), DFE_E_ARG, "dfe_memcpy_h2d: NULL argument");
+    DfeDeviceGuard guard(ctx);
     DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DFE_OK;
@@ -111,20 +115,21 @@ int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
     DFE_REQUIRE(ctx, ctx && (bytes == 0 || (dst && src)), DFE_E_ARG, "dfe_memcpy_d2h: NULL argument");
+    DfeDeviceGuard guard(ctx);
     DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DFE_OK;
 }
 
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, mode >= 0 && mode <= 3, DFE_E_ARG, "cost-volume kernel mode %d not in 0..3", mode);
     ctx->cv_mode = mode;
     return DFE_OK;
 }
 
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, (tyq >= 0 && tyq <= 7) || (tyq > 100 && tyq <= 164), DFE_E_ARG, "tile height code %d not in 0..7 / 101..164", tyq);
     ctx->cv_tyq = tyq;
     return DFE_OK;
@@ -133,20 +138,21 @@ int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
 const char *dfe_last_kernel(const dfe_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, bytes >= ((size_t)1 << 20), DFE_E_ARG, "scratch limit %zu below 1 MiB", bytes);
     ctx->scratch_limit = bytes;
     return DFE_OK;
 }
 
 int dfe_profile_enable(dfe_ctx *ctx, int on) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     ctx->profile = on != 0;
     return DFE_OK;
 }
 
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches) {
     DFE_REQUIRE(ctx, ctx && total_ms && launches, DFE_E_ARG, "dfe_profile_read: NULL argument");
+    DfeDeviceGuard guard(ctx);
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0;
     int n = 0;

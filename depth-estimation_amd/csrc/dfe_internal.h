@@ -70,6 +70,26 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least 
 
 #define DFE_LAUNCH_CHECK(ctx) DFE_HIP(ctx, hipGetLastError())
 
+// Every extern "C" entry point runs on ITS ctx's device whatever the caller's current device is (one ctx per GPU, several
+// ctxs per host thread are legal: include/dfe.h), and leaves the caller's current device as it found it.
+struct DfeDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DfeDeviceGuard(const dfe_ctx *c) {
+        if (c && hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DfeDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DfeDeviceGuard(const DfeDeviceGuard &) = delete;
+    DfeDeviceGuard &operator=(const DfeDeviceGuard &) = delete;
+};
+// first statement of an entry point: NULL check + device guard for the rest of the call
+#define DFE_ENTER(ctx)                                          \
+    DFE_REQUIRE((ctx), (ctx), DFE_E_ARG, "ctx is NULL");        \
+    DfeDeviceGuard dfe_device_guard_(ctx)
+
+
 static inline int dfe_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 

@@ -62,7 +62,7 @@ extern "C" {
 
 int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W,
                                 int kH, int kW, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in && weight && out, DFE_E_ARG, "dfe_spatial_convolution_f32: NULL tensor");
     DFE_REQUIRE(ctx, nIn > 0 && nOut > 0 && kH > 0 && kW > 0 && H >= kH && W >= kW, DFE_E_SHAPE,
                 "dfe_spatial_convolution_f32: %d->%d planes, %dx%d kernel on %dx%d", nIn, nOut, kH, kW, H, W);
@@ -74,7 +74,7 @@ int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weig
 
 int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, const int32_t *conn, int nConn,
                                     int nIn, int nOut, int H, int W, int kH, int kW, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in && weight && conn && out, DFE_E_ARG, "dfe_spatial_convolution_map_f32: NULL tensor");
     DFE_REQUIRE(ctx, nIn > 0 && nOut > 0 && nConn > 0 && kH > 0 && kW > 0 && H >= kH && W >= kW, DFE_E_SHAPE,
                 "dfe_spatial_convolution_map_f32: %d connections %d->%d planes, %dx%d kernel on %dx%d", nConn, nIn, nOut, kH, kW, H, W);
@@ -85,7 +85,7 @@ int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *
 }
 
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, n >= 0, DFE_E_SHAPE, "dfe_tanh_f32: n=%lld", (long long)n);
     if (n == 0) return DFE_OK;
     DFE_REQUIRE(ctx, in && out, DFE_E_ARG, "dfe_tanh_f32: NULL tensor");

@@ -67,7 +67,7 @@ extern "C" {
 
 int dfe_spatial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W1,
                                       int maxh, int maxw, float *gradIn1, float *gradIn2) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in1 && in2 && gradOut && (gradIn1 || gradIn2), DFE_E_ARG, "dfe_spatial_matching_backward_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE,
                 "dfe_spatial_matching_backward_f32: K=%d H1=%d W1=%d window %dx%d must be positive", K, H1, W1, maxh, maxw);
@@ -84,7 +84,7 @@ int dfe_spatial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const floa
 
 int dfe_radial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W, int hWin,
                                      float *gradIn1, float *gradIn2) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, hWin > 0, DFE_E_SHAPE, "dfe_radial_matching_backward_f32: hWin=%d must be positive", hWin);
     return dfe_spatial_matching_backward_f32(ctx, in1, in2, gradOut, K, H1, W, hWin, 1, gradIn1, gradIn2);
 }

@@ -600,7 +600,7 @@ int grid1d(long long n, int per_block) {
 extern "C" {
 
 int dfe_downsample_box_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, int r, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, img && out && C > 0 && r > 0 && H >= r && W >= r, DFE_E_ARG, "dfe_downsample_box_f32: bad argument");
     hipLaunchKernelGGL(downsample_box_kernel, dim3(grid1d((long long)C * (H / r) * (W / r), 256)), dim3(256), 0, ctx->stream, img, C, H, W,
                        r, out);
@@ -610,7 +610,7 @@ int dfe_downsample_box_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, 
 
 int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int r, int kh, int kw,
                                  int maxh, int maxw, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1 && out, DFE_E_ARG, "dfe_pyramid_scale_volume_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && r > 0 && kh > 0 && kw > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_pyramid_scale_volume_f32: bad size");
     DFE_REQUIRE(ctx, H % r == 0 && W % r == 0, DFE_E_SHAPE,
@@ -639,7 +639,7 @@ int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1,
 
 int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
                                  const int *ratios, int nratios, float *flow, int64_t *idx) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1 && (flow || idx), DFE_E_ARG, "dfe_multiscale_flow_pair_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && k > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_f32: bad size");
     CascadeGeom g;
@@ -744,7 +744,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
 }
 
 int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, P >= 0 && N > 0, DFE_E_SHAPE, "dfe_softmin_f32: P=%lld N=%d", (long long)P, N);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, cost && prob, DFE_E_ARG, "dfe_softmin_f32: NULL tensor");
@@ -755,7 +755,7 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
 
 int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw,
                          float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     CascadeGeom g;
     int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
     if (rc) return rc;
@@ -776,7 +776,7 @@ int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
 
 int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw,
                          int64_t *idx, float *best, float *flow_y, float *flow_x) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     CascadeGeom g;
     int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
     if (rc) return rc;
@@ -812,7 +812,7 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
 
 int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios, int64_t P, int maxh, int maxw,
                           float *const *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     CascadeGeom g;
     int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
     if (rc) return rc;
@@ -834,7 +834,7 @@ int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratio
 
 int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh,
                                    int maxw, float *const *gradIn) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     CascadeGeom g;
     int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
     if (rc) return rc;

@@ -139,7 +139,7 @@ extern "C" {
 int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, int lpadding,
                            int rpadding, float rmax, float alpha, float *mask) {
     (void)wsrc; (void)hsrc;
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, mask && wdst > 0 && hdst > 0 && lpadding >= 0 && rpadding >= 0 && lpadding <= wdst && rpadding <= wdst,
                 DFE_E_ARG, "dfe_polar_grid_c2p_f32: bad argument");
     const int Wp = wdst + lpadding + rpadding;
@@ -156,7 +156,7 @@ int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst,
 
 int dfe_polar_grid_p2c_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, float rmax,
                            float alpha, float *mask) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, mask && wdst > 0 && hdst > 0 && rmax > 0 && alpha > 0, DFE_E_ARG, "dfe_polar_grid_p2c_f32: bad argument");
     const float pi2 = (float)(2 * M_PI);                                                   // :58
     const float kx = (float)((double)wsrc / (2 * M_PI));                                   // :59
@@ -169,7 +169,7 @@ int dfe_polar_grid_p2c_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst,
 }
 
 int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const float *mask, int Hd, int Wd, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && Hd >= 0 && Wd >= 0, DFE_E_SHAPE, "dfe_warp_bilinear_f32: bad shape");
     if ((long long)Hd * Wd == 0) return DFE_OK;
     DFE_REQUIRE(ctx, img && mask && out, DFE_E_ARG, "dfe_warp_bilinear_f32: NULL tensor");
@@ -180,7 +180,7 @@ int dfe_warp_bilinear_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, c
 
 int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, float xcenter, float ycenter, float infty, float *depth,
                              float *conf) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0, DFE_E_SHAPE, "dfe_flow_to_depth_radial: H=%d W=%d", H, W);
     if ((long long)H * W == 0) return DFE_OK;
     DFE_REQUIRE(ctx, rflow && depth && conf, DFE_E_ARG, "dfe_flow_to_depth_radial: NULL tensor");
@@ -192,7 +192,7 @@ int dfe_flow_to_depth_radial(dfe_ctx *ctx, const float *rflow, int H, int W, flo
 
 int dfe_flow_to_depth_ardrone(dfe_ctx *ctx, const float *xflow, const float *mask, int H, int W, float imu_tx, float *depth,
                               float *conf) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0, DFE_E_SHAPE, "dfe_flow_to_depth_ardrone: H=%d W=%d", H, W);
     if ((long long)H * W == 0) return DFE_OK;
     DFE_REQUIRE(ctx, xflow && mask && depth && conf, DFE_E_ARG, "dfe_flow_to_depth_ardrone: NULL tensor");

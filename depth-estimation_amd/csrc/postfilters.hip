@@ -147,7 +147,7 @@ extern "C" {
 
 int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask, int H, int W, int winsize, int method,
                               float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, flow && mask && out && H > 0 && W > 0 && winsize > 0, DFE_E_ARG, "dfe_postprocess_image_f32: bad argument");
     DFE_REQUIRE(ctx, method == 0 || method == 1, DFE_E_ARG, "dfe_postprocess_image_f32: method %d (0 = 'max', 1 = median)", method);
     const long long HW = (long long)H * W;
@@ -182,7 +182,7 @@ int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask
 }
 
 int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0, DFE_E_SHAPE, "dfe_enlarge_mask_f32: H=%d W=%d", H, W);
     if ((long long)H * W == 0) return DFE_OK;
     DFE_REQUIRE(ctx, mask, DFE_E_ARG, "dfe_enlarge_mask_f32: NULL tensor");
@@ -193,7 +193,7 @@ int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy
 }
 
 int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw, float *x, float *y) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, P >= 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE, "dfe_output_extractor_f32: P=%lld window %dx%d", (long long)P, maxh, maxw);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, input && x && y, DFE_E_ARG, "dfe_output_extractor_f32: NULL tensor");
@@ -203,7 +203,7 @@ int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int ma
 }
 
 int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, P >= 0 && A > 0 && B > 0, DFE_E_SHAPE, "dfe_marginal_sum_f32: P=%lld A=%d B=%d", (long long)P, A, B);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, in && out, DFE_E_ARG, "dfe_marginal_sum_f32: NULL tensor");

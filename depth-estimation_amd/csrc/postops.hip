@@ -502,7 +502,7 @@ extern "C" {
 
 int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int middle, int take_max, int64_t *idx,
                        float *best) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, P >= 0 && N > 0, DFE_E_SHAPE, "dfe_argbest_center: P=%lld N=%d", (long long)P, N);
     DFE_REQUIRE(ctx, middle <= N, DFE_E_ARG, "dfe_argbest_center: middle=%d > N=%d", middle, N);
     if (P == 0) return DFE_OK;
@@ -520,7 +520,7 @@ int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int mid
 
 int dfe_extract_output(dfe_ctx *ctx, const float *input, int H, int W, int N, float *scores, double threshold,
                        int64_t *imaxs) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0 && N > 0, DFE_E_SHAPE, "dfe_extract_output: H=%d W=%d N=%d", H, W, N);
     long long P = (long long)H * W;
     if (P == 0) return DFE_OK;
@@ -538,7 +538,7 @@ int dfe_extract_output(dfe_ctx *ctx, const float *input, int H, int W, int N, fl
 
 int dfe_extract_output_marginalized(dfe_ctx *ctx, const float *input, int H, int W, int N, double threshold,
                                     double threshold_acc, int64_t *ret, int64_t *retgd) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0 && N > 0, DFE_E_SHAPE, "dfe_extract_output_marginalized: H=%d W=%d N=%d", H, W, N);
     long long P = (long long)H * W;
     if (P == 0) return DFE_OK;
@@ -556,7 +556,7 @@ int dfe_extract_output_marginalized(dfe_ctx *ctx, const float *input, int H, int
 }
 
 int dfe_x2yx(dfe_ctx *ctx, const int64_t *idx, int64_t P, int maxh, int maxw, int64_t *y, int64_t *x) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, P >= 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_x2yx: P=%lld maxh=%d maxw=%d", (long long)P, maxh, maxw);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, idx && y && x, DFE_E_ARG, "dfe_x2yx: NULL tensor");
@@ -568,7 +568,7 @@ int dfe_x2yx(dfe_ctx *ctx, const int64_t *idx, int64_t P, int maxh, int maxw, in
 
 int dfe_x2yx_multi(dfe_ctx *ctx, int maxh, int maxw, const int *ratios, int nratios, const int64_t *idx, int64_t P,
                    int64_t *y, int64_t *x, int compat_c) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     MultiGeom g;
     int rc = fill_geom(ctx, g, maxh, maxw, ratios, nratios);
     if (rc) return rc;
@@ -650,7 +650,7 @@ int64_t dfe_yx2x_multi(int maxh, int maxw, const int *ratios, int nratios, doubl
 int dfe_flow_tail(dfe_ctx *ctx, const float *vol, int rows, int Wo, int hWin, int wWin, double threshold, int row_off,
                   int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t,
                   int pad_l, int scores_padded) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, vol && rows >= 0 && Wo > 0 && hWin > 0 && wWin > 0, DFE_E_ARG, "dfe_flow_tail: bad argument");
     if (rows == 0) return DFE_OK;
     TailOut o;
@@ -675,7 +675,7 @@ int dfe_flow_tail(dfe_ctx *ctx, const float *vol, int rows, int Wo, int hWin, in
 
 int dfe_flow_to_depth_cartesian(dfe_ctx *ctx, const float *flow, int H, int W, float cx, float cy, int fix_dot, float *depth,
                                 float *conf) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, H >= 0 && W >= 0, DFE_E_SHAPE, "dfe_flow_to_depth_cartesian: H=%d W=%d", H, W);
     if ((long long)H * W == 0) return DFE_OK;
     DFE_REQUIRE(ctx, flow && depth && conf, DFE_E_ARG, "dfe_flow_to_depth_cartesian: NULL tensor");

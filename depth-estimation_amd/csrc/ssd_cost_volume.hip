@@ -1510,7 +1510,7 @@ extern "C" {
 
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw,
                             int hWin, int wWin, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1 && out, DFE_E_ARG, "dfe_ssd_cost_volume_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && kh > 0 && kw > 0 && hWin > 0 && wWin > 0, DFE_E_ARG,
                 "dfe_ssd_cost_volume_f32: C=%d k=%dx%d win=%dx%d must be positive", C, kh, kw, hWin, wWin);
@@ -1589,7 +1589,7 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
 int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin,
                      int wWin, double extract_threshold, int64_t *idx, float *best, float *flow_y, float *flow_x,
                      float *scores, int64_t *imaxs) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1, DFE_E_ARG, "dfe_ssd_flow_f32: NULL frame");
     DFE_REQUIRE(ctx, C > 0 && kh > 0 && kw > 0 && hWin > 0 && wWin > 0, DFE_E_ARG,
                 "dfe_ssd_flow_f32: C=%d k=%dx%d win=%dx%d must be positive", C, kh, kw, hWin, wWin);
@@ -1604,7 +1604,7 @@ int dfe_ssd_flow_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int 
 int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin,
                             float foe_x, float foe_y, double extract_threshold, float *flow, float *scores, float *depth,
                             float *depth_conf) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1 && flow, DFE_E_ARG, "dfe_flow_depth_pair_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && k > 0 && hWin > 0 && wWin > 0, DFE_E_ARG, "dfe_flow_depth_pair_f32: C=%d k=%d win=%dx%d", C, k,
                 hWin, wWin);
@@ -1629,7 +1629,7 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
 
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh,
                              int maxw, float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in1 && in2 && out, DFE_E_ARG, "dfe_spatial_matching_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE,
                 "dfe_spatial_matching_f32: K=%d H1=%d W1=%d maxh=%d maxw=%d must be positive", K, H1, W1, maxh, maxw);
@@ -1649,7 +1649,7 @@ int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, i
 
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W, int hWin,
                             float *out) {
-    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "ctx is NULL");
+    DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in1 && in2 && out, DFE_E_ARG, "dfe_radial_matching_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W > 0 && hWin > 0, DFE_E_SHAPE,
                 "dfe_radial_matching_f32: K=%d H1=%d W=%d hWin=%d must be positive", K, H1, W, hWin);
