@@ -14,6 +14,7 @@ no CPU fallback -- a missing library or device raises.
     unfold, compute_cartesian_groundtruth_cross_correlation  (radial/radial_opticalflow_groundtruth.lua)
     nn.CascadingAddTable, getModelMultiscale            (CascadingAddTable.lua, opticalflow_model_multiscale.lua)
     getC2PMask, getP2CMask, cartesian2polar, flow2depth (radial/cartesian2polar.lua, radial_opticalflow_display.lua)
+    torch7_io.load / save, load_calibration             (Torch7 binary files: *.cal, saveModel / saveNetwork weights)
 """
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
@@ -38,6 +39,8 @@ from .network import getFilter, getFilterRadial, getModel, tables_random  # noqa
 from .radial import (getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth, getKOutput, getP2CMaskOF,  # noqa: F401
                      computeDepthMapFromFlow)
 from .glue import SmartReshape, FunctionWrapper, Mul2, Log2, OutputExtractor, postProcessImage, enlargeMask  # noqa: F401
+from . import torch7_io  # noqa: F401
+from .torch7_io import load_calibration  # noqa: F401
 from .groundtruth import (  # noqa: F401
     unfold,
     cross_correlation_pad_output,

@@ -131,3 +131,22 @@ def synth_pair(H, W, C=3, seed=0, max_flow=12, integer=True, noise_sigma=2.0):
     if not integer:
         f0, f1 = f0 / np.float32(255), f1 / np.float32(255)
     return f0, f1, flow, (cx, cy)
+
+
+def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios):
+    """getModelMultiscale(...):forward + processOutput ('max', no threshold) for the identity patch filter, on the oracle:
+    per ratio pyramid_scale_volume (A2) -> softmin over the window (A3) -> cascade + ring extraction (A4 + A5) -> arg-max
+    with the centre tie-break (A6) -> x2yxMulti decode (A10).  opticalflow_model_multiscale.lua:134-333,
+    opticalflow_model.lua:153-161,201-252.  Returns dict(joined, idx, y, x, middle)."""
+    from tests import oracle as orc
+
+    H, W = f0.shape[1:]
+    vols = [orc.pyramid_scale_volume(f0, f1, r, k, k, maxh, maxw) for r in ratios]
+    probs = [orc.softmin(v.reshape(-1, maxh * maxw)).reshape(v.shape) for v in vols]
+    rc, joined = orc.cascade_ring(probs, ratios, H, W, maxh, maxw)
+    assert rc == 0
+    middle = orc.yx2x_multi(maxh, maxw, ratios, 0, 0)
+    idx, best = orc.argbest_center(joined, middle, True)
+    rc, y, x = orc.x2yx_multi(maxh, maxw, ratios, idx)
+    assert rc == 0
+    return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle)

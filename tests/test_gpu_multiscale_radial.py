@@ -463,3 +463,91 @@ def test_filter_stack_and_single_scale_model(dfe, cuda):
     rf = dfe.getFilterRadial(dict(layers=[(3, 1, 9, 6), "tanh", (6, 9, 1, 6)]), generator=gen)
     z = rf.forward(T(x, cuda))
     assert tuple(z.shape) == (6, 30 - 8, 37 - 8)
+
+
+def _one_call(dfe, cuda, f0, f1, k, mh, mw, ratios):
+    from depth_estimation_amd._lib import ratios_array
+
+    Cc, H, W = f0.shape
+    ctx = dfe.get_ctx(0)
+    rr, n = ratios_array(ratios)
+    flow = torch.empty((2, H, W), device=cuda)
+    idx = torch.empty((H, W), dtype=torch.int64, device=cuda)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx.check(dfe.lib().dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, mh, mw, rr, n, flow.data_ptr(), idx.data_ptr()))
+    return idx.cpu().numpy(), flow.cpu().numpy()
+
+
+def _assert_matches_oracle(gi, gflow, ref, mh, mw, ratios, max_tie_frac=0.02):
+    """Indices equal the oracle's except where the oracle's two best classes lie within 1e-5 of each other (the fast volume
+    kernel sums in a different order and the device's expf differs from glibc's in the last bit: SOFT_ATOL per scale); the
+    decode of whatever index was taken must be the codec's, exactly."""
+    top2 = np.sort(ref["joined"], -1)[..., -2:]
+    tie = top2[..., 1] - top2[..., 0] <= 1e-5
+    same = gi == ref["idx"]
+    assert (same | tie).all(), "%d pixels differ from the oracle outside ties" % int((~(same | tie)).sum())
+    assert (~same).mean() <= max_tie_frac
+    rc, ey, ex = orc.x2yx_multi(mh, mw, ratios, gi)
+    assert rc == 0 and np.array_equal(gflow[0], ey.astype(np.float32)) and np.array_equal(gflow[1], ex.astype(np.float32))
+
+
+@pytest.mark.parametrize("soft", ["0", "1"])
+@pytest.mark.parametrize("ratios,mh,H,W", [
+    ([1, 2, 4], 8, 96, 128),
+    ([1, 2, 4, 8], 8, 96, 136),          # W/8 = 17 tiles of 8: the ragged last tile / generic tail branch of the 32-px blocks
+    ([1, 2, 4, 8], 4, 64, 88),           # BASELINE configs[3] with maxhHR = 32
+    ([1, 2, 4, 8], 16, 64, 96),
+    ([1, 2, 4, 8, 16], 8, 96, 144),      # BASELINE configs[4] geometry (5 levels)
+    ([1, 2, 4, 8, 16], 4, 80, 112),
+])
+def test_one_call_multiscale_equals_oracle_chain(dfe, cuda, monkeypatch, soft, ratios, mh, H, W):
+    """dfe_multiscale_flow_pair_f32 -- what bench.py's pyramid workloads time -- against the ORACLE composition
+    pyramid_scale_volume -> softmin -> cascade_ring -> argbest_center -> x2yx_multi, directly (not via the staged HIP
+    path), for 3, 4 and 5 ratios, with the soft-min epilogue of the merged volume launch forced off and on."""
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + len(ratios) + mh, max_flow=min(10, 2 * ratios[-1]), noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    ref = rp.multiscale_flow_oracle(f0, f1, 7, mh, mh, ratios)
+    monkeypatch.setenv("DFE_SOFT_EPILOGUE", soft)
+    gi, gflow = _one_call(dfe, cuda, f0, f1, 7, mh, mh, ratios)
+    _assert_matches_oracle(gi, gflow, ref, mh, mh, ratios)
+
+
+def test_one_call_multiscale_auto_epilogue_720p_equals_oracle_and_staged(dfe, cuda):
+    """1280x720, ratios {1,2,4,8}, 8x8 windows: the `720p-pyramid` bench workload.  Scale 1 has 1600 blocks, i.e. the launcher
+    turns the soft-min epilogue on by itself (>= 1000).  Checked against the oracle chain (tie-aware), against the staged
+    HIP path (bitwise), and for the planted flow (size-independent property: recovered within the scale's step)."""
+    H, W, ratios = 720, 1280, [1, 2, 4, 8]
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=5, max_flow=12, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    gi, gflow = _one_call(dfe, cuda, f0, f1, 7, 8, 8, ratios)
+    ref = rp.multiscale_flow_oracle(f0, f1, 7, 8, 8, ratios)
+    _assert_matches_oracle(gi, gflow, ref, 8, 8, ratios)
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    staged = dfe.getModelMultiscale(geo).forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False)
+    assert np.array_equal(staged["index"].cpu().numpy(), gi)
+    inner = (slice(40, H - 40), slice(40, W - 40))
+    mag = np.maximum(np.abs(flow[0]), np.abs(flow[1]))
+    tol = np.where(mag <= 3, 1, np.where(mag <= 6, 2, np.where(mag <= 12, 4, 8)))
+    ok = (np.abs(gflow[0] - flow[0]) < tol + 1) & (np.abs(gflow[1] - flow[1]) < tol + 1)
+    assert ok[inner].mean() > 0.9
+
+
+@pytest.mark.parametrize("H,W,ratios", [(480, 640, [1, 2, 4]), (1080, 1920, [1, 2, 4, 8])])
+def test_full_size_pyramid_properties(dfe, cuda, H, W, ratios):
+    """Full-size pyramid (BASELINE configs[1] and configs[3] geometry): staged == one-call bit for bit, and the planted flow is
+    recovered within the step of the scale that reaches it (tests/test_multiscale.lua:61-71 tolerance rule)."""
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=2, max_flow=12, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    Hp, Wp = -(-H // ratios[-1]) * ratios[-1], -(-W // ratios[-1]) * ratios[-1]
+    p0, p1 = np.zeros((3, Hp, Wp), np.float32), np.zeros((3, Hp, Wp), np.float32)
+    p0[:, :H, :W], p1[:, :H, :W] = f0, f1
+    gi, gflow = _one_call(dfe, cuda, p0, p1, 7, 8, 8, ratios)
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=Hp, wImg=Wp, output_extraction_method="max")
+    staged = dfe.getModelMultiscale(geo).forwardFlow([T(p0, cuda), T(p1, cuda)], False, one_call=False)
+    assert np.array_equal(staged["index"].cpu().numpy(), gi)
+    assert np.array_equal(staged["y"].cpu().numpy(), gflow[0].astype(np.int64)) and np.array_equal(staged["x"].cpu().numpy(), gflow[1].astype(np.int64))
+    inner = (slice(40, H - 40), slice(40, W - 40))
+    mag = np.maximum(np.abs(flow[0]), np.abs(flow[1]))
+    tol = np.where(mag <= 3, 1, np.where(mag <= 6, 2, np.where(mag <= 12, 4, 8)))
+    ok = (np.abs(gflow[0][:H, :W] - flow[0]) < tol + 1) & (np.abs(gflow[1][:H, :W] - flow[1]) < tol + 1)
+    assert ok[inner].mean() > 0.9

@@ -608,3 +608,72 @@ def test_full_vga_cost_volume_properties(dfe, cuda):
     same = op.forward([t1, t1])
     centre = same.reshape(442, 602, -1)[:, :, mid - 1]
     assert float(centre.abs().max()) == 0.0 and float(same.min()) == 0.0
+
+
+# ------------------------------------------------------------------ real image pair (BASELINE configs[0])
+@pytest.mark.parametrize("size,win", [((320, 240), 17), ((640, 480), 33)])
+def test_celiu_car_pair_hip_equals_oracle(dfe, cuda, size, win):
+    """car1 -> car2 (tests/golden/celiu, the reference's own demo pair): 320x240 with the +-8 window of configs[0] and
+    640x480 with the headline +-16 window, through dfe_ssd_flow_f32 (fused build, finalize) and through
+    dfe_flow_depth_pair_f32, against the oracle -- uint8-valued frames, so everything is bit-exact."""
+    from tests.test_real_image_cpu import load_pair
+
+    f0, f1 = load_pair(size)
+    W, H = size
+    k = 7
+    Ho, Wo = H - k + 1 - win + 1, W - k + 1 - win + 1
+    # oracle: cost volume in row chunks (bounded memory), then arg-min with the centre tie-break, decode, extractOutput
+    mid = rp.middle_index(win, win)
+    eidx = np.empty((Ho, Wo), np.int64)
+    ebest = np.empty((Ho, Wo), np.float32)
+    esc, eim = np.zeros((Ho, Wo), np.float32), np.zeros((Ho, Wo), np.int64)
+    for r0 in range(0, Ho, 64):
+        r1 = min(r0 + 64, Ho)
+        vol = orc.ssd_cost_volume(f0[:, r0 : r1 + k - 1 + win - 1], f1[:, r0 : r1 + k - 1 + win - 1], k, k, win, win).reshape(r1 - r0, Wo, win * win)
+        eidx[r0:r1], ebest[r0:r1] = orc.argbest_center(vol, mid, False)
+        orc.extract_output(vol, 0.21, eim[r0:r1], esc[r0:r1])
+    ey, ex = orc.x2yx(eidx, win, win)
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best, fy, fx, sc = (torch.empty((Ho, Wo), device=cuda) for _ in range(4))
+    im = torch.zeros((Ho, Wo), dtype=torch.int64, device=cuda)
+    sc.zero_()
+    ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, 0.21, idx.data_ptr(), best.data_ptr(),
+                                        fy.data_ptr(), fx.data_ptr(), sc.data_ptr(), im.data_ptr()))
+    assert np.array_equal(idx.cpu().numpy(), eidx) and np.array_equal(best.cpu().numpy(), ebest)
+    assert np.array_equal(fy.cpu().numpy(), ey.astype(np.float32)) and np.array_equal(fx.cpu().numpy(), ex.astype(np.float32))
+    assert np.array_equal(sc.cpu().numpy(), esc) and np.array_equal(im.cpu().numpy(), eim)
+    # the pair call: centre-pasted flow, scores, depth
+    flow = torch.empty((2, H, W), device=cuda)
+    scores, depth, dconf = (torch.empty((H, W), device=cuda) for _ in range(3))
+    cx, cy = W / 2 + 17, H / 2 - 9
+    ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, win, win, cx, cy, 0.21,
+                                               flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), dconf.data_ptr()))
+    pt, pl = (H - Ho) // 2, (W - Wo) // 2
+    eflow = np.zeros((2, H, W), np.float32)
+    eflow[0, pt : pt + Ho, pl : pl + Wo], eflow[1, pt : pt + Ho, pl : pl + Wo] = ey, ex
+    assert np.array_equal(flow.cpu().numpy(), eflow)
+    ed, ec = orc.flow_to_depth_cartesian(eflow, cx, cy)
+    assert np.allclose(depth.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(dconf.cpu().numpy(), ec)
+
+
+def test_patch_mode_spatial_matching_equals_oracle(dfe, cuda):
+    """tests/test_patches.lua:46-60 on the device: a K x 1 x 1 patch against K x 16 x 16 candidates through
+    nn.SpatialMatching(16, 16) -- bit-exact against the oracle (reference summation order), arg-max of -output = the planted class."""
+    import math
+
+    rng = np.random.default_rng(3)
+    k, maxh = 16, 16
+    I0 = rng.random((3, 80, 90), dtype=np.float32)
+    c = math.ceil(maxh / 2) - 1
+    for fy, fx in ((0, 0), (3, -5), (-7, 8)):
+        I1 = np.roll(I0, (fy, fx), axis=(1, 2))
+        y, x = 30, 35
+        in1 = orc.unfold(I0[:, y : y + k, x : x + k], k, k)
+        in2 = orc.unfold(I1[:, y - c : y - c + maxh + k - 1, x - c : x - c + maxh + k - 1], k, k)
+        out = dfe.nn.SpatialMatching(maxh, maxh).forward([T(in1, cuda), T(in2, cuda)])
+        assert tuple(out.shape) == (1, 1, maxh, maxh)
+        assert np.array_equal(out.cpu().numpy(), orc.spatial_matching(in1, in2, maxh, maxh))
+        m = int((-out).reshape(-1).argmax().item()) + 1
+        assert m == (fy + math.ceil(maxh / 2) - 1) * maxh + fx + math.ceil(maxh / 2)

@@ -375,3 +375,84 @@ def test_matcher_gradients_are_the_jacobian_of_the_forward():
     p[1, 3, 2] += 1.0
     m[1, 3, 2] -= 1.0
     assert (rloss(r1, p) - rloss(r1, m)) / 2.0 == float(h2[1, 3, 2])
+
+
+# --- the reference's remaining data-free checks, restated on the oracle ---------------------------
+@pytest.mark.parametrize("maxh", [8, 7])
+def test_pyramid_windows_are_centred_on_the_pixel(maxh):
+    """tests/test_multiscale.lua:111-133: at every pyramid scale the window is centred on the pixel ("centered on ceil-1
+    AFTER the matching"): matching a frame against itself costs exactly 0 at cell (ceil(maxh/2), ceil(maxw/2)) (1-based)
+    and nowhere else; and content that moved by (2r, -r) pixels is found two cells below / one cell left of the centre at
+    the scale of ratio r."""
+    rng = np.random.default_rng(maxh)
+    H, W, k = 64, 80, 7
+    I0 = rng.random((3, H, W), dtype=np.float32)
+    c = math.ceil(maxh / 2) - 1
+    for r in (1, 2, 4):
+        v = orc.pyramid_scale_volume(I0, I0, r, k, k, maxh, maxh)
+        assert v.shape == (H // r, W // r, maxh, maxh)
+        assert (v[:, :, c, c] == 0).all()
+        inner = v[8 // r + 2 : -(8 // r) - 2, 8 // r + 2 : -(8 // r) - 2].reshape(-1, maxh * maxh)
+        others = np.delete(inner, c * maxh + c, axis=1)
+        assert (others > 0).all()
+        I1 = np.zeros_like(I0)
+        I1[:, 2 * r :, : W - r] = I0[:, : H - 2 * r, r:]          # I1(p + (2r, -r)) = I0(p)
+        v = orc.pyramid_scale_volume(I0, I1, r, k, k, maxh, maxh)
+        m = 16 // r + 2
+        am = v[m:-m, m:-m].reshape(v.shape[0] - 2 * m, v.shape[1] - 2 * m, -1).argmin(-1)
+        assert (am == (c + 2) * maxh + (c - 1)).all()
+        assert (v[m:-m, m:-m, c + 2, c - 1] == 0).all()
+
+
+@pytest.mark.parametrize("maxh,ratios", [(8, [1, 2, 4]), (8, [1, 2]), (16, [1, 2, 4, 8]), (4, [1, 2, 4, 8])])
+def test_ring_extraction_block_layout(maxh, ratios):
+    """tests/test_multiscale.lua:195-214 ("check complex reshaping"), restated: scale 1 leaves all its cells; for scale
+    i >= 2 the extracted vector, cut into the four blocks top (dh x maxw), left (lih x dw), right (lih x dw), bottom
+    (dh x maxw) and put back in place, is the cascade output of that scale with its middle lih x liw cells zeroed."""
+    rng = np.random.default_rng(maxh + len(ratios))
+    maxw, H, W = maxh, ratios[-1], 2 * ratios[-1]
+    probs = [rng.random((H // r, W // r, maxh, maxw), dtype=np.float32) for r in ratios]
+    rc, out = orc.cascade_ring(probs, ratios, H, W, maxh, maxw)
+    assert rc == 0
+    up = [np.repeat(np.repeat(p, r, 0), r, 1).reshape(-1, maxh, maxw) for p, r in zip(probs, ratios)]
+    rc, casc = orc.cascading_add(up, ratios, maxh, maxw)
+    assert rc == 0
+    out = out.reshape(H * W, -1)
+    assert np.array_equal(out[:, : maxh * maxw], casc[0].reshape(H * W, -1))           # reshaper.modules[1].output == cascad_out[1]
+    off = maxh * maxw
+    for i in range(1, len(ratios)):
+        liw = round(maxw * ratios[i - 1] / ratios[i]); dw = round((maxw - liw) / 2)
+        lih = round(maxh * ratios[i - 1] / ratios[i]); dh = round((maxh - lih) / 2)
+        blockt = casc[i].copy()
+        blockt[:, dh : dh + lih, dw : dw + liw] = 0
+        n = 2 * dh * maxw + 2 * lih * dw
+        reshaped = out[:, off : off + n]
+        block = np.zeros_like(blockt)
+        block[:, :dh] = reshaped[:, : dh * maxw].reshape(-1, dh, maxw)
+        block[:, dh : dh + lih, :dw] = reshaped[:, dh * maxw : dh * maxw + lih * dw].reshape(-1, lih, dw)
+        block[:, dh : dh + lih, dw + lih : dw + lih + dw] = reshaped[:, dh * maxw + lih * dw : dh * maxw + 2 * lih * dw].reshape(-1, lih, dw)
+        block[:, dh + lih : dh + lih + dh] = reshaped[:, dh * maxw + 2 * lih * dw : n].reshape(-1, dh, maxw)
+        assert np.array_equal(block, blockt)
+        off += n
+    assert off == out.shape[1]
+
+
+def test_patch_mode_matching_argmax_is_block_matching_ground_truth():
+    """tests/test_patches.lua:46-60: one 16x16 patch of frame 1 (K = 3*16*16 features at a 1x1 map) against the 16x16
+    candidate patches of a (16+16-1)^2 region of frame 2, through unfold + nn.SpatialMatching(16, 16): the arg-max of
+    -output is the class of the true displacement (here: planted; the reference takes it from its ground-truth files)."""
+    rng = np.random.default_rng(3)
+    k, maxh = 16, 16
+    I0 = rng.random((3, 80, 90), dtype=np.float32)
+    c = math.ceil(maxh / 2) - 1                                    # 0-based centre cell: displacement 0
+    for fy, fx in ((0, 0), (3, -5), (-7, 8), (8, -7), (-2, 2)):
+        I1 = np.roll(I0, (fy, fx), axis=(1, 2))                    # I1(p + f) = I0(p)
+        y, x = 30, 35
+        in1 = orc.unfold(I0[:, y : y + k, x : x + k], k, k)        # K x 1 x 1
+        reg = I1[:, y - c : y - c + maxh + k - 1, x - c : x - c + maxh + k - 1]
+        in2 = orc.unfold(reg, k, k)                                # K x 16 x 16
+        assert in1.shape == (3 * k * k, 1, 1) and in2.shape == (3 * k * k, maxh, maxh)
+        out = orc.spatial_matching(in1, in2, maxh, maxh)           # 1 x 1 x 16 x 16
+        m = int((-out).reshape(-1).argmax()) + 1                   # 1-based class, as torch's max
+        target = (fy + math.ceil(maxh / 2) - 1) * maxh + fx + math.ceil(maxh / 2)   # yx2x(centered2onebased(fy, fx)), opticalflow_model.lua:12-34
+        assert m == target and out.reshape(-1)[m - 1] == 0
