@@ -40,6 +40,14 @@ PYRAMIDS = {
     "720p-pyramid": (720, 1280, 3, 7, 8, 8, (1, 2, 4, 8)),
     "1080p-pyramid": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
 }
+# BASELINE.json configs[2]: 1280x720 radial (polar-warped) flow: C2P warp of both frames around the epipole, the default
+# separable filter stack {{3,1,17,5},{5,17,1,10}}, SpatialRadialMatching(15), arg-min, P2C warp, flow2depth, through
+# dfe_radial_flow_depth_pair_f32; polar image = frame size ("bench at 720x1280 polar").
+RADIALS = {
+    # name: (hImg, wImg, C, hInput, wInput, hWin, layers)
+    "720p-radial": (720, 1280, 3, 720, 1280, 15, [[3, 1, 17, 5], [5, 17, 1, 10]]),
+    "vga-radial": (480, 640, 3, 480, 640, 15, [[3, 1, 17, 5], [5, 17, 1, 10]]),
+}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -233,12 +241,68 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
         dist.destroy_process_group()
 
 
+def main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp):
+    """Radial workload: step = dfe_radial_flow_depth_pair_f32 on one pair per GPU.  `roofline` is the matcher + arg-min kernel
+    (A1r) against its algorithmic bytes (both feature maps read once + the hWin-cell volume written once), timed
+    with HIP events inside the timed region; the step also runs the polar warps, the two filter launches per frame and the
+    P2C / depth pass."""
+    hImg, wImg, Cc, hIn, wIn, hWin, layers = RADIALS[args.workload]
+    networkp = dict(hImg=hImg, wImg=wImg, hInput=hIn, wInput=wIn, hWin=hWin, layers=layers)
+    (pair_id,) = shard_pairs(world, world, rank)
+    f0, f1, _, (cx, cy) = rp.synth_pair(hImg, wImg, C=Cc, seed=pair_id, max_flow=12)
+    t0, t1 = torch.from_numpy(f0 / 255.0).to(dev, torch.float32), torch.from_numpy(f1 / 255.0).to(dev, torch.float32)
+    net = d.getTesterNetwork(networkp, device=dev, generator=torch.Generator().manual_seed(0))   # random-init weights of the architecture
+    ctx = d.get_ctx(local_rank)
+    lib = d.lib()
+    from depth_estimation_amd._lib import RadialParams
+    from depth_estimation_amd.radial import _separable_weights
+
+    w1, b1, w2, b2, th = _separable_weights(net, networkp)
+    prm = RadialParams(Cc, hImg, wImg, hIn, wIn, hWin, w1.shape[0], w1.shape[3], w2.shape[0], w2.shape[2], int(th), 1.0, 0.65)
+    hm, hOut, wOut = d.radial_out_shape(networkp)
+    vol = torch.empty((hm, wIn, hWin), device=dev)
+    pf = torch.empty((hm, wIn), device=dev)
+    cart, depth, conf = (torch.empty((hOut, wOut), device=dev) for _ in range(3))
+
+    def step():
+        ctx.check(lib.dfe_radial_flow_depth_pair_f32(ctx.handle, C.byref(prm), t0.data_ptr(), t1.data_ptr(), cx, cy, w1.data_ptr(), b1.data_ptr(),
+                                                     w2.data_ptr(), b2.data_ptr(), vol.data_ptr(), pf.data_ptr(), cart.data_ptr(), depth.data_ptr(),
+                                                     conf.data_ptr()))
+
+    elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize,
+                           before_timed=lambda: ctx.check(lib.dfe_profile_enable(ctx.handle, 1)))
+    ms, n = C.c_double(), C.c_int()
+    ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(ms), C.byref(n)))
+    ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+    if rank == 0:
+        K = w2.shape[0]
+        hf2 = hIn - (w2.shape[2] - 1)
+        balg = K * hm * wIn * 4 + K * hf2 * wIn * 4 + hm * wIn * hWin * 4        # in1 (the rows the matcher reads) + in2 + volume
+        kern_s = ms.value / 1e3 / max(n.value, 1)
+        step_s = elapsed / args.steps
+        print(json.dumps({
+            "metric": "Mpixels/s dense radial flow+depth, %dx%d pair, polar %dx%d, 17x17 separable filter, radial window %d" % (wImg, hImg, wIn, hIn, hWin),
+            "value": round(world * args.steps * hImg * wImg / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d C=%d radial path: C2P warp of both frames (polar %dx%d + 16 wrap columns), filter %s (random-init), "
+                                   "SpatialRadialMatching(%d) + arg-min, P2C warp, flow2depth; one pair per GPU per step" % (wImg, hImg, Cc, wIn, hIn, layers, hWin),
+                       "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "radial_match_kernel", "achieved": round(balg / kern_s / 1e9, 2) if kern_s > 0 else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(balg / kern_s / 1e9 / HBM_PEAK_GBS, 4) if kern_s > 0 else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": balg, "kernel_ms": round(kern_s * 1e3, 5), "launches_timed": n.value},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS))
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed) gather of the results to rank 0")
     args = ap.parse_args()
@@ -268,6 +332,8 @@ def main():
 
     if args.workload in PYRAMIDS:
         return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
+    if args.workload in RADIALS:
+        return main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp)
     H, W, Cc, k, hWin, wWin = WORKLOADS[args.workload]
     (pair_id,) = shard_pairs(world, world, rank)                              # a batch of `world` pairs, pair p on rank p
     f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=pair_id, max_flow=12)  # one seeded pair per rank

@@ -25,6 +25,8 @@ PROTOTYPES = {
     "dfe_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfe_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dfe_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),
@@ -83,7 +85,17 @@ PROTOTYPES = {
     "dfe_postprocess_image_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "dfe_enlarge_mask_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "dfe_output_extractor_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_radial_match_argmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int]),
+    "dfe_radial_out_shape": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p]),
+    "dfe_radial_flow_depth_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 9),
 }
+
+
+class RadialParams(C.Structure):
+    """dfe_radial_params (include/dfe.h)"""
+    _fields_ = [("C", C.c_int), ("hImg", C.c_int), ("wImg", C.c_int), ("hInput", C.c_int), ("wInput", C.c_int), ("hWin", C.c_int),
+                ("n1", C.c_int), ("kW1", C.c_int), ("n2", C.c_int), ("kH2", C.c_int), ("tanh_between", C.c_int),
+                ("alpha_polar", C.c_float), ("kinfty", C.c_double)]
 
 _lib = None
 

@@ -121,6 +121,24 @@ int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return DFE_OK;
 }
 
+int dfe_host_register(dfe_ctx *ctx, void *ptr, size_t bytes) {
+    DFE_REQUIRE(ctx, ctx && ptr && bytes > 0, DFE_E_ARG, "dfe_host_register: NULL / empty range");
+    DfeDeviceGuard guard(ctx);
+    hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return DFE_OK; }
+    if (e != hipSuccess) return dfe_fail(ctx, DFE_E_HIP, "hipHostRegister(%p, %zu): %s", ptr, bytes, hipGetErrorString(e));
+    return DFE_OK;
+}
+
+int dfe_host_unregister(dfe_ctx *ctx, void *ptr) {
+    DFE_REQUIRE(ctx, ctx && ptr, DFE_E_ARG, "dfe_host_unregister: NULL argument");
+    DfeDeviceGuard guard(ctx);
+    hipError_t e = hipHostUnregister(ptr);
+    if (e == hipErrorHostMemoryNotRegistered) { (void)hipGetLastError(); return DFE_OK; }
+    if (e != hipSuccess) return dfe_fail(ctx, DFE_E_HIP, "hipHostUnregister(%p): %s", ptr, hipGetErrorString(e));
+    return DFE_OK;
+}
+
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, mode >= 0 && mode <= 3, DFE_E_ARG, "cost-volume kernel mode %d not in 0..3", mode);

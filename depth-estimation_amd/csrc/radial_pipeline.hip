@@ -1,0 +1,357 @@
+// radial_pipeline.hip -- the radial (polar) flow -> depth path as one call (BASELINE configs[2]).
+//   replaces, composed: radial/test_radial_opticalflow.lua:186-225 and radial/train_radial_opticalflow.lua:161-182
+//     polar_prev, polar_img = cartesian2polar(frame, getC2PMask(wImg, hImg, wInput, hInput, e2, floor((wKernel-1)/2),
+//                                                              ceil((wKernel-1)/2), rmax, alpha))        data.lua:242-248
+//     output = getTesterNetwork(networkp):forward{polar_prev, polar_img}                 radial_opticalflow_network.lua:56-74
+//              = SpatialRadialMatching(hWin){ filter(crop(polar_prev, hWin-1 rows at the bottom)), filter(polar_img) }
+//              with filter = conv(C -> n1, 1 x kW) [tanh] conv(n1 -> n2, kH x 1) -- the default separable stack
+//              {{3,1,17,5},{5,17,1,10}} (train_radial:27), shared weights                radial_opticalflow_network.lua:6-30
+//     idx = output:min(3) - 1                                                           test_radial:205-207
+//     cartidx = cartesian2polar(idx, getP2CMaskOF(networkp, e2, alpha))                 test_radial:217-218, polar.lua:18-30
+//     depth, confs = flow2depth(networkp, cartidx, e2 * getKOutput(networkp), 0.65)     test_radial:224-225, display.lua:6-58
+// Kernels (every arithmetic expression is the one of the stand-alone ops in polar.hip / filters.hip /
+// ssd_cost_volume.hip, so the one-call result is bit-identical to the staged host path):
+//   polar_warp_pair_kernel   C2P grid evaluated in place (never stored) + bilinear gather of BOTH frames, wrap columns included
+//   conv_rows_kernel         1 x kW correlation, all nOut planes per thread from an LDS row tile (accumulation order of
+//                            nn.SpatialConvolution: bias, then input plane, then tap; separately rounded multiply and add)
+//   conv_cols_kernel         kH x 1 correlation, RY output rows per thread: a column of RY + kH - 1 inputs is read once per plane
+//   radial_match_kernel      A1r + arg-min: lanes over x (coalesced planes), RY rows per thread share their hWin + RY - 1
+//                            frame-1 rows, features summed in order k = 0..K-1; the volume leaves through an LDS transpose
+//                            as whole rows of W * hWin contiguous floats; first-minimum index - 1 = the radial flow
+//   p2c_flow_depth_kernel    P2C grid in place + bilinear sample of the polar flow + flow2depth
+#include "dfe_internal.h"
+#include <cmath>
+
+namespace {
+
+int grid1d(long long n, int bs = 256) {
+    long long b = (n + bs - 1) / bs;
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ float bilinear_at(const float *__restrict__ p, int H, int W, float fy, float fx) {
+#pragma clang fp contract(off)
+    fy = fy < 0 ? 0 : (fy > (float)(H - 1) ? (float)(H - 1) : fy);
+    fx = fx < 0 ? 0 : (fx > (float)(W - 1) ? (float)(W - 1) : fx);
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float top = (1 - wx) * p[(long long)y0 * W + x0] + wx * p[(long long)y0 * W + x1];
+    const float bot = (1 - wx) * p[(long long)y1 * W + x0] + wx * p[(long long)y1 * W + x1];
+    return (1 - wy) * top + wy * bot;
+}
+
+// polar image [C][hdst][Wp], Wp = lpad + wdst + rpad; padded column jp shows grid column (jp - lpad) mod wdst
+// (cartesian2polar.lua:42-47: the left pad repeats the last lpad columns, the right pad the first rpad)
+__global__ __launch_bounds__(256) void polar_warp_pair_kernel(const float *__restrict__ f0, const float *__restrict__ f1, int C, int H, int W,
+                                                             int wdst, int hdst, int Wp, int lpad, float xc, float yc, float kr, float ktheta,
+                                                             float alpha, float *__restrict__ o0, float *__restrict__ o1) {
+    const long long total = (long long)hdst * Wp, HW = (long long)H * W;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Wp), jp = (int)(e - (long long)i * Wp);
+        int j = jp - lpad;
+        j = j < 0 ? j + wdst : (j >= wdst ? j - wdst : j);
+        const float r = (float)((double)kr * pow((double)(float)i, (double)alpha));      // cartesian2polar.lua:34
+        const float th = ktheta * (float)j;                                             // :35
+        const float fy = (float)((double)r * sin((double)th) + (double)yc);             // :36
+        const float fx = (float)((double)r * cos((double)th) + (double)xc);             // :37
+        for (int c = 0; c < C; ++c) {
+            o0[c * total + e] = bilinear_at(f0 + c * HW, H, W, fy, fx);
+            o1[c * total + e] = bilinear_at(f1 + c * HW, H, W, fy, fx);
+        }
+    }
+}
+
+// out[o][y][x] = bias[o] + sum_i sum_v w[o][i][v] * in[i][y][x+v]   (kH = 1)
+template <int NOUT, bool TANH>
+__global__ __launch_bounds__(256) void conv_rows_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                       int nIn, int H, int W, int kW, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    extern __shared__ float tile[];                      // [nIn][256 + kW - 1]
+    const int Wo = W - kW + 1, TW = 256 + kW - 1;
+    const int y = blockIdx.y, x0 = blockIdx.x * 256, tx = threadIdx.x;
+    for (int i = 0; i < nIn; ++i)
+        for (int s = tx; s < TW; s += 256) {
+            const int x = x0 + s;
+            tile[i * TW + s] = x < W ? in[((long long)i * H + y) * W + x] : 0.f;
+        }
+    __syncthreads();
+    const int x = x0 + tx;
+    if (x >= Wo) return;
+    float acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    for (int i = 0; i < nIn; ++i)
+        for (int v = 0; v < kW; ++v) {
+            const float a = tile[i * TW + tx + v];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) acc[o] = acc[o] + w[((long long)o * nIn + i) * kW + v] * a;   // (wave-uniform weights: scalar loads)
+        }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) out[((long long)o * H + y) * Wo + x] = TANH ? tanhf(acc[o]) : acc[o];
+}
+
+// out[o][y][x] = bias[o] + sum_i sum_u w[o][i][u] * in[i][y+u][x]   (kW = 1); RY output rows per thread
+template <int NOUT, int RY, int KH>
+__global__ __launch_bounds__(256) void conv_cols_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                       int nIn, int H, int W, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int Ho = H - KH + 1;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * RY;
+    if (x >= W) return;
+    float acc[RY][NOUT];
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) acc[r][o] = bias ? bias[o] : 0.f;
+    for (int i = 0; i < nIn; ++i) {
+        float col[RY + KH - 1];
+#pragma unroll
+        for (int s = 0; s < RY + KH - 1; ++s) col[s] = in[((long long)i * H + min(y0 + s, H - 1)) * W + x];
+#pragma unroll
+        for (int u = 0; u < KH; ++u)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const float wv = w[((long long)o * nIn + i) * KH + u];
+#pragma unroll
+                for (int r = 0; r < RY; ++r) acc[r][o] = acc[r][o] + wv * col[r + u];
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+        if (y0 + r < Ho)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) out[((long long)o * Ho + y0 + r) * W + x] = acc[r][o];
+}
+
+// A1r + arg-min.  in1 [K][H1p >= H1][W] (only the first H1 rows of a plane are used: the cropped previous frame), in2 [K][H1+HW-1][W]; vol [H1][W][HW] (may be NULL), flow [H1][W] = first-min index (0-based)
+// as float, the last row zeroed when zero_last (train_radial:180).  Block = 64 columns x RY rows per thread x 4 row groups.
+template <int HWIN, int RY>
+__global__ __launch_bounds__(256) void radial_match_kernel(const float *__restrict__ in1, int H1p, const float *__restrict__ in2, int K, int H1, int W,
+                                                          float *__restrict__ vol, float *__restrict__ flow, int zero_last) {
+#pragma clang fp contract(off)
+    __shared__ float stage[4][64 * HWIN + 1];            // one output row of the block's 64 columns per row group
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y0 = (blockIdx.y * 4 + grp) * RY;
+    const int H2 = H1 + HWIN - 1;
+    const bool inx = x < W;
+    const int xs = inx ? x : W - 1;
+    float acc[RY][HWIN];
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+#pragma unroll
+        for (int d = 0; d < HWIN; ++d) acc[r][d] = 0.f;
+    if (y0 < H1) {
+        for (int k = 0; k < K; ++k) {
+            float b[RY + HWIN - 1], a[RY];
+#pragma unroll
+            for (int s = 0; s < RY + HWIN - 1; ++s) b[s] = in2[((long long)k * H2 + min(y0 + s, H2 - 1)) * W + xs];
+#pragma unroll
+            for (int r = 0; r < RY; ++r) a[r] = in1[((long long)k * H1p + min(y0 + r, H1 - 1)) * W + xs];
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+#pragma unroll
+                for (int d = 0; d < HWIN; ++d) {
+                    const float t = a[r] - b[r + d];
+                    acc[r][d] = acc[r][d] + t * t;
+                }
+        }
+    }
+    const int wcols = min(64, W - (int)blockIdx.x * 64);   // columns of this block inside the frame
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int y = y0 + r;                              // (wave-uniform)
+        if (y < H1) {
+            if (inx) {
+                float best = acc[r][0];
+                int bi = 0;
+#pragma unroll
+                for (int d = 1; d < HWIN; ++d)
+                    if (acc[r][d] < best) { best = acc[r][d]; bi = d; }   // strict: TH min keeps the first minimum
+                flow[(long long)y * W + x] = (zero_last && y == H1 - 1) ? 0.f : (float)bi;
+            }
+            if (vol) {
+#pragma unroll
+                for (int d = 0; d < HWIN; ++d) stage[grp][lane * HWIN + d] = acc[r][d];
+                __builtin_amdgcn_wave_barrier();
+                float *dst = vol + ((long long)y * W + (long long)blockIdx.x * 64) * HWIN;
+                for (int s = lane; s < wcols * HWIN; s += 64) dst[s] = stage[grp][s];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// cart[i][j] = bilinear(polar flow, P2C grid(i, j)); depth / conf = flow2depth(cart)
+__global__ __launch_bounds__(256) void p2c_flow_depth_kernel(const float *__restrict__ pflow, int hPolar, int wPolar, int wdst, int hdst, float xc,
+                                                            float yc, float kx, float ky, float pi2, float invalpha, float cx2, float cy2,
+                                                            float infty, float *__restrict__ cart, float *__restrict__ depth,
+                                                            float *__restrict__ conf) {
+    const long long total = (long long)hdst * wdst;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / wdst), j = (int)(e - (long long)i * wdst);
+        const float x = (float)j - xc, y = (float)i - yc;                                                       // cartesian2polar.lua:80-81
+        const float my = (float)(pow((double)(x * x + y * y), (double)invalpha) * (double)ky);                  // :82
+        const float mx = (float)(fmod(atan2((double)y, (double)x) + (double)pi2, (double)pi2) * (double)kx);    // :83
+        const float f = bilinear_at(pflow, hPolar, wPolar, my, mx);
+        if (cart) cart[e] = f;
+        const float a = (float)j - cx2, b = (float)i - cy2;
+        const float d = (float)sqrt((double)(a * a + b * b));     // radial_opticalflow_display.lua:39
+        float o = 0.f, c = 1.f;
+        if (d > 10.0f) o = (f < 0.1f) ? infty : d / f;            // :42-46
+        else c = 0.f;                                             // :48
+        if (depth) depth[e] = o / infty;                          // :57
+        if (conf) conf[e] = c;
+    }
+}
+
+double lua_rmax(double h, double w, double ex, double ey) {   // getRMax radial/radial_opticalflow_polar.lua:4-10
+    const double a = ex * ex + ey * ey, b = (w - ex) * (w - ex) + ey * ey, c = ex * ex + (h - ey) * (h - ey), d = (w - ex) * (w - ex) + (h - ey) * (h - ey);
+    return floor(sqrt(fmax(fmax(a, b), fmax(c, d))));
+}
+
+template <int NOUT>
+int launch_conv_rows(dfe_ctx *ctx, const float *in, const float *w, const float *b, int nIn, int H, int W, int kW, bool tanh_after, float *out) {
+    const int Wo = W - kW + 1;
+    const size_t lds = (size_t)nIn * (256 + kW - 1) * sizeof(float);
+    dim3 grid(dfe_cdiv(Wo, 256), H);
+    if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+    else hipLaunchKernelGGL((conv_rows_kernel<NOUT, false>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+}  // namespace
+
+// separable stack: fast kernels for the shapes with an instantiation, the generic direct convolution otherwise (same sums)
+static int radial_filter(dfe_ctx *ctx, const dfe_radial_params *p, const float *polar, int H, int Wp, const float *w1, const float *b1,
+                         const float *w2, const float *b2, float *tmp, float *feat) {
+    const int W = Wp - p->kW1 + 1, Ho = H - p->kH2 + 1;
+    int rc = DFE_OK;
+    bool done = false;
+    if ((size_t)p->C * (256 + p->kW1 - 1) * sizeof(float) <= 48 * 1024) {
+        switch (p->n1) {
+            case 4: rc = launch_conv_rows<4>(ctx, polar, w1, b1, p->C, H, Wp, p->kW1, p->tanh_between != 0, tmp); done = true; break;
+            case 5: rc = launch_conv_rows<5>(ctx, polar, w1, b1, p->C, H, Wp, p->kW1, p->tanh_between != 0, tmp); done = true; break;
+            case 8: rc = launch_conv_rows<8>(ctx, polar, w1, b1, p->C, H, Wp, p->kW1, p->tanh_between != 0, tmp); done = true; break;
+            default: break;
+        }
+    }
+    if (!done) {
+        rc = dfe_spatial_convolution_f32(ctx, polar, w1, b1, p->C, p->n1, H, Wp, 1, p->kW1, tmp);
+        if (!rc && p->tanh_between) rc = dfe_tanh_f32(ctx, tmp, (int64_t)p->n1 * H * W, tmp);
+    }
+    if (rc) return rc;
+    if (p->kH2 == 17 && (p->n2 == 10 || p->n2 == 8)) {
+        dim3 grid(dfe_cdiv(W, 256), dfe_cdiv(Ho, 4));
+        if (p->n2 == 10) hipLaunchKernelGGL((conv_cols_kernel<10, 4, 17>), grid, dim3(256), 0, ctx->stream, tmp, w2, b2, p->n1, H, W, feat);
+        else hipLaunchKernelGGL((conv_cols_kernel<8, 4, 17>), grid, dim3(256), 0, ctx->stream, tmp, w2, b2, p->n1, H, W, feat);
+        DFE_LAUNCH_CHECK(ctx);
+        return DFE_OK;
+    }
+    return dfe_spatial_convolution_f32(ctx, tmp, w2, b2, p->n1, p->n2, H, W, p->kH2, 1, feat);
+}
+
+extern "C" {
+
+int dfe_radial_out_shape(const dfe_radial_params *p, int *hMatch, int *hOut, int *wOut) {
+    if (!p || p->hInput <= 0 || p->wInput <= 0 || p->kH2 <= 0 || p->hWin <= 0) return DFE_E_ARG;
+    const int hm = p->hInput - (p->kH2 - 1) - (p->hWin - 1);
+    if (hm < 1) return DFE_E_SHAPE;
+    const double kOut = (double)hm / (double)p->hInput;   // getP2CMaskOF: hPolar = hInput - hKernel - hWin + 2
+    if (hMatch) *hMatch = hm;
+    if (hOut) *hOut = (int)((double)p->hImg * kOut);       // (Torch truncates the fractional tensor sizes)
+    if (wOut) *wOut = (int)((double)p->wImg * kOut);
+    return DFE_OK;
+}
+
+int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_rows, const float *in2, int K, int H1, int W, int hWin,
+                                float *volume, float *flow, int zero_last_row) {
+    DFE_ENTER(ctx);
+    if (in1_plane_rows <= 0) in1_plane_rows = H1;
+    DFE_REQUIRE(ctx, in1_plane_rows >= H1, DFE_E_SHAPE, "dfe_radial_match_argmin_f32: in1 planes of %d rows for %d output rows", in1_plane_rows, H1);
+    DFE_REQUIRE(ctx, in1 && in2 && flow, DFE_E_ARG, "dfe_radial_match_argmin_f32: NULL tensor");
+    DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W > 0 && hWin > 0, DFE_E_SHAPE, "dfe_radial_match_argmin_f32: K=%d H1=%d W=%d hWin=%d", K, H1, W, hWin);
+    DFE_REQUIRE(ctx, hWin == 15 || hWin == 12 || hWin == 8 || hWin == 16, DFE_E_UNSUPPORTED,
+                "dfe_radial_match_argmin_f32: hWin %d has no instantiation (8, 12, 15, 16); use dfe_radial_matching_f32 + dfe_argbest_center", hWin);
+    dim3 grid(dfe_cdiv(W, 64), dfe_cdiv(H1, 4 * 4));
+    {
+        DfeProfScope prof(ctx);
+        switch (hWin) {
+            case 15: hipLaunchKernelGGL((radial_match_kernel<15, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            case 12: hipLaunchKernelGGL((radial_match_kernel<12, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            case 16: hipLaunchKernelGGL((radial_match_kernel<16, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            default: hipLaunchKernelGGL((radial_match_kernel<8, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+        }
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = "radial_match_kernel";
+    return DFE_OK;
+}
+
+int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, const float *prev, const float *cur, double e2x, double e2y,
+                                   const float *w1, const float *b1, const float *w2, const float *b2, float *volume, float *polar_flow,
+                                   float *cart_flow, float *depth, float *conf) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, p && prev && cur && w1 && w2, DFE_E_ARG, "dfe_radial_flow_depth_pair_f32: NULL argument");
+    DFE_REQUIRE(ctx, p->C > 0 && p->hImg > 0 && p->wImg > 0 && p->hInput > 0 && p->wInput > 0 && p->n1 > 0 && p->n2 > 0 && p->kW1 > 0 && p->kH2 > 0 &&
+                         p->hWin > 0 && p->alpha_polar > 0 && p->kinfty > 0,
+                DFE_E_ARG, "dfe_radial_flow_depth_pair_f32: bad parameter block");
+    int hm, hOut, wOut;
+    DFE_REQUIRE(ctx, dfe_radial_out_shape(p, &hm, &hOut, &wOut) == DFE_OK && hOut > 0 && wOut > 0, DFE_E_SHAPE,
+                "dfe_radial_flow_depth_pair_f32: polar height %d too small for kernel %d + window %d", p->hInput, p->kH2, p->hWin);
+    const int lpad = (p->kW1 - 1) / 2, rpad = (p->kW1 - 1) - lpad;        // floor / ceil((wKernel-1)/2): test_radial:190-191
+    DFE_REQUIRE(ctx, lpad <= p->wInput && rpad <= p->wInput, DFE_E_SHAPE, "dfe_radial_flow_depth_pair_f32: wInput %d below the kernel width", p->wInput);
+    const int Wp = p->wInput + lpad + rpad, H = p->hInput, W = p->wInput;
+    const int Hf2 = H - (p->kH2 - 1);                                        // feature rows of a full polar frame
+    // scratch: two polar frames, one row-filter buffer, two feature maps, the polar flow
+    const size_t polar_b = ((size_t)p->C * H * Wp * 4 + 255) / 256 * 256, tmp_b = ((size_t)p->n1 * H * W * 4 + 255) / 256 * 256;
+    const size_t f2_b = ((size_t)p->n2 * Hf2 * W * 4 + 255) / 256 * 256, f1_b = f2_b;
+    const size_t pf_b = ((size_t)hm * W * 4 + 255) / 256 * 256;
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, 2 * polar_b + tmp_b + f1_b + f2_b + pf_b, &scr);
+    if (rc) return rc;
+    float *pol0 = (float *)scr, *pol1 = (float *)((char *)scr + polar_b), *tmp = (float *)((char *)scr + 2 * polar_b);
+    float *feat1 = (float *)((char *)tmp + tmp_b), *feat2 = (float *)((char *)feat1 + f1_b), *pflow = (float *)((char *)feat2 + f2_b);
+    if (polar_flow) pflow = polar_flow;
+
+    const double rmax = lua_rmax(p->hImg, p->wImg, e2x, e2y);
+    {   // 1. both frames to polar (getC2PMask's constants: cartesian2polar.lua:13-14)
+        const float kr = (float)(rmax / pow((double)H, (double)p->alpha_polar));
+        const float ktheta = (float)(2 * M_PI / W);
+        hipLaunchKernelGGL(polar_warp_pair_kernel, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, prev, cur, p->C, p->hImg, p->wImg, W, H,
+                           Wp, lpad, (float)e2x, (float)e2y, kr, ktheta, p->alpha_polar, pol0, pol1);
+        DFE_LAUNCH_CHECK(ctx);
+    }
+    // 2. shared filter on both polar frames.  The reference crops the previous frame's last hWin-1 rows BEFORE its filter
+    //    (SpatialPadding(0,0,0,-hWin+1), network.lua:59); a valid correlation's surviving rows do not see the cropped ones, so
+    //    the full frame is filtered and the matcher reads the first hm rows of each feature plane (plane pitch Hf2 rows).
+    rc = radial_filter(ctx, p, pol0, H, Wp, w1, b1, w2, b2, tmp, feat1);
+    if (rc) return rc;
+    rc = radial_filter(ctx, p, pol1, H, Wp, w1, b1, w2, b2, tmp, feat2);
+    if (rc) return rc;
+    // 3. matcher + arg-min (+ the volume when asked for); last flow row zeroed (train_radial:178-180)
+    rc = dfe_radial_match_argmin_f32(ctx, feat1, Hf2, feat2, p->n2, hm, W, p->hWin, volume, pflow, 1);
+    if (rc) return rc;
+    {   // 4. polar flow -> cartesian -> depth (getP2CMaskOF + flow2depth with center2 = e2 * getKOutput)
+        const double kOut = (double)hm / (double)H;
+        const double nrmax = rmax * kOut;
+        const float pi2 = (float)(2 * M_PI);
+        const float kx = (float)((double)W / (2 * M_PI));
+        const float ky = (float)((double)hm / pow(nrmax, 1.0 / (double)p->alpha_polar));
+        const float invalpha = (float)(1.0 / (double)p->alpha_polar) * 0.5f;
+        const double kOut2 = (double)(H - (p->kH2 - 1) / 2 - p->hWin + 1) / (double)H;           // getKOutput polar.lua:12-16 (sic: not kOut)
+        const double c2x = e2x * kOut2, c2y = e2y * kOut2;
+        const float infty = (float)(lua_rmax(p->hImg, p->wImg, c2x, c2y) * p->kinfty);
+        hipLaunchKernelGGL(p2c_flow_depth_kernel, dim3(grid1d((long long)hOut * wOut)), dim3(256), 0, ctx->stream, pflow, hm, W, wOut, hOut,
+                           (float)(e2x * kOut), (float)(e2y * kOut), kx, ky, pi2, invalpha, (float)c2x, (float)c2y, infty,
+                           cart_flow, depth, conf);
+        DFE_LAUNCH_CHECK(ctx);
+    }
+    ctx->last_kernel = "radial_match_kernel";
+    return DFE_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@ function CascadingAddTable:__init(ratios, trainable, single_beta)
       self.gradInput[i] = torch.FloatTensor()
    end
    self.cratios = ffi.new('int[?]', #ratios, ratios)
+   self.dbuf = {}
 end
 
 local function check_inputs(self, input)
@@ -36,27 +37,22 @@ local function check_inputs(self, input)
    end
 end
 
--- runs one of the two C entry points over a table of tensors: stage, call, fetch, free
+-- runs one of the two C entry points over a table of tensors: stage into the module's persistent device buffers, call, fetch
 local function run(self, fn, src, dst)
    local n = #src
    local P, maxh, maxw = src[1]:size(1), src[1]:size(2), src[1]:size(3)
    local din, dout = ffi.new('const float*[?]', n), ffi.new('float*[?]', n)
-   local held = {}
    for i = 1, n do
-      local p = dfe.upload(src[i])
-      din[i - 1] = ffi.cast('const float*', p)
-      local q = ffi.new('void*[1]')
-      dfe.check(dfe.lib.dfe_malloc(dfe.ctx, src[i]:nElement() * 4, q))
-      dout[i - 1] = ffi.cast('float*', q[0])
-      held[#held + 1] = p
-      held[#held + 1] = q[0]
+      dfe.checktype(src[i], 'torch.FloatTensor', 'nn.CascadingAddTable: input[' .. i .. ']')
+      self.dbuf[i] = self.dbuf[i] or {dfe.newBuffer(), dfe.newBuffer()}
+      din[i - 1] = ffi.cast('const float*', (dfe.upload(src[i], self.dbuf[i][1])))
+      dout[i - 1] = ffi.cast('float*', self.dbuf[i][2]:reserve(src[i]:nElement() * 4))
    end
    dfe.check(fn(dfe.ctx, din, self.cratios, n, P, maxh, maxw, dout))
    for i = 1, n do
       dst[i]:resizeAs(src[i])
       dfe.download(dst[i], dout[i - 1])
    end
-   for _, p in ipairs(held) do dfe.free(p) end
 end
 
 function CascadingAddTable:updateOutput(input)

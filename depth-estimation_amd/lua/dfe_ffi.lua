@@ -16,6 +16,8 @@ int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr);
 int dfe_free(dfe_ctx *ctx, void *dptr);
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dfe_host_register(dfe_ctx *ctx, void *ptr, size_t bytes);
+int dfe_host_unregister(dfe_ctx *ctx, void *ptr);
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 const char *dfe_last_kernel(const dfe_ctx *ctx);
@@ -25,6 +27,9 @@ int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float *out);
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W, int hWin, float *out);
+int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_rows, const float *in2, int K, int H1, int W, int hWin, float *volume, float *flow, int zero_last_row);
+int dfe_radial_out_shape(const dfe_radial_params *p, int *hMatch, int *hOut, int *wOut);
+int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, const float *prev, const float *cur, double e2x, double e2y, const float *w1, const float *b1, const float *w2, const float *b2, float *volume, float *polar_flow, float *cart_flow, float *depth, float *conf);
 int dfe_spatial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W1, int maxh, int maxw, float *gradIn1, float *gradIn2);
 int dfe_radial_matching_backward_f32(dfe_ctx *ctx, const float *in1, const float *in2, const float *gradOut, int K, int H1, int W, int hWin, float *gradIn1, float *gradIn2);
 int dfe_argbest_center(dfe_ctx *ctx, const float *vol, int64_t P, int N, int middle, int take_max, int64_t *idx, float *best);
@@ -74,21 +79,63 @@ function M.check(rc)
    if rc ~= 0 then error('libdfe: ' .. ffi.string(M.lib.dfe_last_error(M.ctx))) end
 end
 
--- stage a (contiguous) host tensor on the device; returns a device pointer owned by the caller
-function M.upload(t)
+-- Device buffers are PERSISTENT: one per (module instance, role), grown when the tensor it mirrors grows, never freed per
+-- call (a VGA SpatialMatching would otherwise spend far longer in hipMalloc / hipFree than in its kernel).  Host tensors
+-- that are handed over again and again (a module's output, the frames of a video loop) are pinned in place on first
+-- sight (dfe_host_register), so the copies are direct DMA; a tensor whose storage moved is re-pinned.
+local Buffer = {}
+Buffer.__index = Buffer
+function M.newBuffer() return setmetatable({ptr = nil, bytes = 0}, Buffer) end
+function Buffer:reserve(bytes)
+   if bytes > self.bytes then
+      if self.ptr ~= nil then M.check(M.lib.dfe_free(M.ctx, self.ptr)) end
+      local p = ffi.new('void*[1]')
+      M.check(M.lib.dfe_malloc(M.ctx, bytes, p))
+      self.ptr, self.bytes = p[0], bytes
+   end
+   return self.ptr
+end
+function Buffer:free()
+   if self.ptr ~= nil then M.check(M.lib.dfe_free(M.ctx, self.ptr)) end
+   self.ptr, self.bytes = nil, 0
+end
+
+local pinned = {}   -- storage address (number) -> bytes
+local function pin(t)
+   local p, bytes = t:data(), t:nElement() * t:elementSize()
+   local key = tonumber(ffi.cast('intptr_t', p))
+   if pinned[key] == nil or pinned[key] < bytes then
+      if pinned[key] ~= nil then M.check(M.lib.dfe_host_unregister(M.ctx, p)) end
+      M.check(M.lib.dfe_host_register(M.ctx, p, bytes))
+      pinned[key] = bytes
+   end
+end
+function M.unpin(t)
+   local key = tonumber(ffi.cast('intptr_t', t:data()))
+   if pinned[key] ~= nil then M.check(M.lib.dfe_host_unregister(M.ctx, t:data())); pinned[key] = nil end
+end
+
+-- the C ABI is typed: a DoubleTensor uploaded byte for byte would be read as floats
+function M.checktype(t, typename, what)
+   if torch.typename(t) ~= typename then
+      error(string.format('%s must be a %s, got %s', what, typename, torch.typename(t) or type(t)))
+   end
+end
+
+-- host tensor -> persistent device buffer `buf`; returns the device pointer
+function M.upload(t, buf)
    t = t:contiguous()
    local bytes = t:nElement() * t:elementSize()
-   local p = ffi.new('void*[1]')
-   M.check(M.lib.dfe_malloc(M.ctx, bytes, p))
-   M.check(M.lib.dfe_memcpy_h2d(M.ctx, p[0], t:data(), bytes))
-   return p[0], bytes
+   local d = buf:reserve(bytes)
+   pin(t)
+   M.check(M.lib.dfe_memcpy_h2d(M.ctx, d, t:data(), bytes))
+   return d, bytes
 end
 
 function M.download(t, dptr)
    assert(t:isContiguous())
+   pin(t)
    M.check(M.lib.dfe_memcpy_d2h(M.ctx, t:data(), dptr, t:nElement() * t:elementSize()))
 end
-
-function M.free(dptr) M.check(M.lib.dfe_free(M.ctx, dptr)) end
 
 return M

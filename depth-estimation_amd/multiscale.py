@@ -8,7 +8,7 @@ import torch
 
 from ._lib import lib, ratios_array
 from .context import get_ctx, ptr
-from .nn import Module
+from .nn import Module, _f32c
 from .opticalflow_model import _g
 
 
@@ -89,7 +89,7 @@ class MultiscaleModel(Module):
     def updateOutput(self, input):
         g = self.geometry
         i0, i1 = input
-        i0, i1 = i0.contiguous(), i1.contiguous()
+        i0, i1 = _f32c(i0, "MultiscaleModel: input[1]"), _f32c(i1, "MultiscaleModel: input[2]")   # the C ABI is typed: float32 frames
         Cc, H, W = i0.shape
         maxh, maxw, kh, kw = _g(g, "maxh"), _g(g, "maxw"), _g(g, "hKernel"), _g(g, "wKernel")
         rmax = self.ratios[-1]
@@ -127,7 +127,7 @@ class MultiscaleModel(Module):
         (dfe_cascade_flow_f32).  Returns the same table: index, confidences (all 1), y, x [, full, full_confidences]."""
         g = self.geometry
         i0, i1 = input
-        i0, i1 = i0.contiguous(), i1.contiguous()
+        i0, i1 = _f32c(i0, "MultiscaleModel: input[1]"), _f32c(i1, "MultiscaleModel: input[2]")   # the C ABI is typed: float32 frames
         Cc, H, W = i0.shape
         maxh, maxw, kh, kw = _g(g, "maxh"), _g(g, "maxw"), _g(g, "hKernel"), _g(g, "wKernel")
         rmax = self.ratios[-1]

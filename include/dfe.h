@@ -54,6 +54,11 @@ int dfe_malloc(dfe_ctx *ctx, size_t bytes, void **dptr);
 int dfe_free(dfe_ctx *ctx, void *dptr);
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* synchronous */
+/* Pins a host range the caller keeps passing to dfe_memcpy_h2d / _d2h (the storage of a Torch tensor that is reused from
+ * frame to frame): copies from / to it then run as direct DMA instead of through the runtime's pageable staging.
+ * Registering a range twice, or unregistering an unknown one, is not an error.  Unregister before the memory is freed. */
+int dfe_host_register(dfe_ctx *ctx, void *ptr, size_t bytes);
+int dfe_host_unregister(dfe_ctx *ctx, void *ptr);
 /* cost-volume kernel selection (tuning / tests; also the DFE_CV_MODE environment variable at context creation):
  * 0 = auto (default: the row-image kernel where it applies -- C=3, 7x7 patch, 769..1096 window cells, e.g. 33x33 --
  * else the tiled kernel, else the reference-order kernel), 1 = force the reference-order kernel (bit-identical float
@@ -98,6 +103,43 @@ int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, i
  * in1 [K][H1][W], in2 [K][H1+hWin-1][W] -> out [H1][W][hWin]. */
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1,
                             int W, int hWin, float *out);
+
+/* ---- A1r + arg-min, and the radial path in one call (BASELINE configs[2]) ------------------ */
+/* replaces: SpatialRadialMatching(hWin):forward followed by `_, idx = output:min(3); idx:add(-1)`
+ *   (radial/train_radial_opticalflow.lua:161-168, radial/test_radial_opticalflow.lua:204-207).  in1 [K][in1_plane_rows][W]
+ *   (only the first H1 rows of a plane are read: the previous frame cropped by hWin-1 rows, network.lua:59;
+ *   0 = H1), in2 [K][H1+hWin-1][W]; volume [H1][W][hWin] or NULL; flow [H1][W] = first-minimum index - 1 as float
+ *   (TH min keeps the first minimum), its last row zeroed when zero_last_row (train_radial:178-180).
+ *   hWin in {8, 12, 15, 16}. */
+int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_rows, const float *in2, int K, int H1, int W,
+                                int hWin, float *volume, float *flow, int zero_last_row);
+
+/* networkp of the radial scripts (radial/train_radial_opticalflow.lua:83-97) for the default separable filter stack
+ * {{C,1,kW1,n1},{n1,kH2,1,n2}} (train_radial:27), optionally with 'tanh' between the two convolutions. */
+typedef struct dfe_radial_params {
+    int C, hImg, wImg;     /* cartesian frames [C][hImg][wImg] */
+    int hInput, wInput;    /* polar image size before the wKernel-1 wrap-around columns */
+    int hWin;              /* radial search window */
+    int n1, kW1;           /* layer 1: C -> n1 planes, 1 x kW1 (wKernel = kW1) */
+    int n2, kH2;           /* layer 2: n1 -> n2 planes, kH2 x 1 (hKernel = kH2) */
+    int tanh_between;      /* non-zero: nn.Tanh between the layers */
+    float alpha_polar;     /* radial exponent of the polar grid (1 = linear) */
+    double kinfty;         /* flow2depth's infinity factor (0.65 in test_radial:225; a Lua number, i.e. a double) */
+} dfe_radial_params;
+/* rows of the matcher output (hInput - hKernel - hWin + 2) and size of the cartesian flow / depth images
+ * (floor(hImg * kOutput) x floor(wImg * kOutput), getP2CMaskOF radial/radial_opticalflow_polar.lua:18-30). */
+int dfe_radial_out_shape(const dfe_radial_params *p, int *hMatch, int *hOut, int *wOut);
+/* replaces, composed: radial/test_radial_opticalflow.lua:186-225 (= train_radial:161-182 + flow2depth):
+ *   getC2PMask + cartesian2polar of both frames -> getTesterNetwork(networkp):forward -> min(3) - 1 -> getP2CMaskOF +
+ *   cartesian2polar of the flow -> flow2depth(networkp, flow, e2 * getKOutput(networkp), kinfty).
+ *   prev (ego-motion-corrected by the caller) / cur [C][hImg][wImg]; (e2x, e2y) the epipole = focus of expansion in
+ *   frame pixels (doubles, like the Lua numbers they replace: they are scaled before the reference rounds them to float); w1 [n1][C][1][kW1], b1 [n1], w2 [n2][n1][kH2][1], b2 [n2] (biases may be NULL).
+ *   Outputs (each may be NULL): volume [hMatch][wInput][hWin], polar_flow [hMatch][wInput], cart_flow / depth / conf
+ *   [hOut][wOut].  Bit-identical to the staged calls (dfe_polar_grid_c2p_f32, dfe_warp_bilinear_f32,
+ *   dfe_spatial_convolution_f32, dfe_radial_matching_f32, ...). */
+int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, const float *prev, const float *cur, double e2x,
+                                   double e2y, const float *w1, const float *b1, const float *w2, const float *b2,
+                                   float *volume, float *polar_flow, float *cart_flow, float *depth, float *conf);
 
 /* ---- N2: gradients of the two matchers (training drivers call model:backward through them) ------- */
 /* replaces: nn.SpatialMatching:updateGradInput / nn.SpatialRadialMatching:updateGradInput (un-vendored nnx), reached

@@ -150,3 +150,46 @@ def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios):
     rc, y, x = orc.x2yx_multi(maxh, maxw, ratios, idx)
     assert rc == 0
     return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle)
+
+
+def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between=False, kinfty=0.65, alpha=1.0):
+    """radial/test_radial_opticalflow.lua:186-225 on the oracle, for the separable filter stack conv(1 x kW) [tanh] conv(kH x 1):
+    getC2PMask(+ wrap columns) -> cartesian2polar of both frames -> getTesterNetwork (crop hWin-1 rows of the previous frame,
+    shared filter, SpatialRadialMatching) -> min(3) - 1 (last row zeroed, train_radial:178-180) -> getP2CMaskOF ->
+    cartesian2polar of the flow -> flow2depth(center = e2 * getKOutput).  Returns dict(polar_prev, polar_img, feat1, feat2,
+    output, polar_flow, flow, depth, confs)."""
+    import math
+
+    import numpy as np
+
+    from tests import oracle as orc
+
+    Cc, hImg, wImg = img.shape
+    hIn, wIn, hWin = networkp["hInput"], networkp["wInput"], networkp["hWin"]
+    kW, kH = w1.shape[3], w2.shape[2]
+    ex, ey = float(e2[0]), float(e2[1])
+    rmax = math.floor(math.sqrt(max(max(ex * ex + ey * ey, (wImg - ex) ** 2 + ey * ey), max(ex * ex + (hImg - ey) ** 2, (wImg - ex) ** 2 + (hImg - ey) ** 2))))
+    mask = orc.polar_grid_c2p(wImg, hImg, wIn, hIn, ex, ey, (kW - 1) // 2, -(-(kW - 1) // 2), rmax, alpha)
+    pp, pi = orc.warp_bilinear(prev_img, mask), orc.warp_bilinear(img, mask)
+
+    def filt(x):
+        t = orc.spatial_convolution(x, w1, b1)
+        if tanh_between:
+            t = orc.tanh(t)
+        return orc.spatial_convolution(t, w2, b2)
+
+    f1, f2 = filt(np.ascontiguousarray(pp[:, : hIn - hWin + 1])), filt(pi)      # SpatialPadding(0,0,0,-hWin+1) on the previous frame
+    out = orc.radial_matching(f1, f2, hWin)
+    pf = out.argmin(2).astype(np.float32)                                       # numpy argmin: first minimum
+    pf[-1] = 0
+    hPolar = hIn - kH - hWin + 2
+    assert hPolar == out.shape[0]
+    kOut = hPolar / hIn
+    hOut, wOut = int(hImg * kOut), int(wImg * kOut)
+    p2c = orc.polar_grid_p2c(wIn, hPolar, wOut, hOut, ex * kOut, ey * kOut, rmax * kOut, alpha)
+    cart = orc.warp_bilinear(pf[None], p2c)[0]
+    kOut2 = (hIn - (kH - 1) // 2 - hWin + 1) / hIn
+    cx, cy = ex * kOut2, ey * kOut2
+    infty = math.floor(math.sqrt(max(max(cx * cx + cy * cy, (wImg - cx) ** 2 + cy * cy), max(cx * cx + (hImg - cy) ** 2, (wImg - cx) ** 2 + (hImg - cy) ** 2)))) * kinfty
+    depth, conf = orc.flow_to_depth_radial(cart, cx, cy, infty)
+    return dict(polar_prev=pp, polar_img=pi, feat1=f1, feat2=f2, output=out, polar_flow=pf, flow=cart, depth=depth, confs=conf)

@@ -551,3 +551,71 @@ def test_full_size_pyramid_properties(dfe, cuda, H, W, ratios):
     tol = np.where(mag <= 3, 1, np.where(mag <= 6, 2, np.where(mag <= 12, 4, 8)))
     ok = (np.abs(gflow[0][:H, :W] - flow[0]) < tol + 1) & (np.abs(gflow[1][:H, :W] - flow[1]) < tol + 1)
     assert ok[inner].mean() > 0.9
+
+
+# ------------------------------------------------------------------ the radial path as a path (BASELINE configs[2])
+def _radial_setup(dfe, cuda, hImg, wImg, hIn, wIn, layers, hWin=15, seed=0):
+    networkp = dict(hImg=hImg, wImg=wImg, hInput=hIn, wInput=wIn, hWin=hWin, layers=layers)
+    g = torch.Generator().manual_seed(seed)
+    net = dfe.getTesterNetwork(networkp, device=cuda, generator=g)
+    f0, f1, _, (cx, cy) = rp.synth_pair(hImg, wImg, C=3, seed=seed, max_flow=6, noise_sigma=0)
+    return networkp, net, f0 / np.float32(255), f1 / np.float32(255), (cx, cy)
+
+
+@pytest.mark.parametrize("layers,hIn,wIn", [
+    ([[3, 1, 17, 5], [5, 17, 1, 10]], 200, 200),             # the reference's defaults (train_radial:27-33)
+    ([[3, 1, 17, 5], "tanh", [5, 17, 1, 10]], 120, 136),
+    ([[3, 1, 9, 4], [4, 11, 1, 6]], 96, 100),                # a stack without a fast instantiation: generic convolutions inside the one call
+])
+def test_radial_path_one_call_equals_staged_and_oracle(dfe, cuda, layers, hIn, wIn):
+    """dfe_radial_flow_depth_pair_f32 (test_radial:186-225 in one call) == the staged module path bit for bit, and both agree
+    with the oracle composition: polar frames / features within the polar-grid tolerance (device libm vs glibc: 2e-5 abs on
+    the sampling coordinates), the integer polar flow equal wherever the oracle's two best costs are not within 1e-4
+    relative of each other, depth equal where the flow is."""
+    networkp, net, f0, f1, e2 = _radial_setup(dfe, cuda, 180, 320, hIn, wIn, layers)
+    one = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=True, want_volume=True)
+    stg = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=False, want_volume=True)
+    hm, hOut, wOut = dfe.radial_out_shape(networkp)
+    assert tuple(one["output"].shape) == (hm, wIn, 15) and tuple(one["flow"].shape) == (hOut, wOut)
+    for k in ("output", "polar_flow", "flow", "depth", "confs"):
+        assert torch.equal(one[k], stg[k]), k
+    convs = [m for m in net.modules[0].modules[1].modules if hasattr(m, "weight")]
+    w1, b1, w2, b2 = (convs[0].weight.cpu().numpy(), convs[0].bias.cpu().numpy(), convs[1].weight.cpu().numpy(), convs[1].bias.cpu().numpy())
+    ref = rp.radial_path_oracle(f0, f1, e2, networkp, w1, b1, w2, b2, tanh_between="tanh" in layers)
+    out = one["output"].cpu().numpy()
+    assert np.abs(out - ref["output"]).max() <= 2e-3 * np.abs(ref["output"]).max()        # sampling-coordinate jitter through two convolutions
+    pf, rf = one["polar_flow"].cpu().numpy(), ref["polar_flow"]
+    srt = np.sort(ref["output"], -1)
+    tie = (srt[..., 1] - srt[..., 0]) <= 1e-4 * srt[..., 1] + 1e-7
+    tie[-1] = True                                                                       # (zeroed row)
+    assert ((pf == rf) | tie).all() and (pf != rf).mean() < 0.02
+    same = np.abs(one["flow"].cpu().numpy() - ref["flow"]) <= 1e-4
+    assert same.mean() > 0.97
+    assert np.array_equal(one["confs"].cpu().numpy(), ref["confs"])
+    d, rd = one["depth"].cpu().numpy(), ref["depth"]
+    assert (np.abs(d - rd)[same] <= 1e-3 * np.abs(rd)[same] + 1e-6).all()
+    # radial expansion from the epipole: the matcher finds outward (>= 0) flow, non-trivially
+    assert pf.min() >= 0 and pf.max() <= 14 and (pf[: hm // 2] > 0).mean() > 0.2
+
+
+def test_radial_match_argmin_equals_matching_then_min(dfe, cuda):
+    """dfe_radial_match_argmin_f32 == dfe_radial_matching_f32 -> first minimum - 1, bit for bit (volume and flow), for every
+    instantiated window, ragged widths and the cropped-plane form of in1; == the oracle."""
+    rng = np.random.default_rng(0)
+    ctx = dfe.get_ctx(0)
+    for hWin, K, H1, W, extra in ((15, 10, 37, 100, 5), (12, 7, 20, 64, 0), (8, 3, 9, 130, 2), (16, 12, 33, 65, 0)):
+        in1 = rng.standard_normal((K, H1 + extra, W)).astype(np.float32)      # planes taller than H1: only the first H1 rows are read
+        in2 = rng.standard_normal((K, H1 + hWin - 1, W)).astype(np.float32)
+        in2[:, 3:8, 5] = in1[:, 0:5, 5]                                       # exact zeros -> exact ties at some cells
+        ref = orc.radial_matching(np.ascontiguousarray(in1[:, :H1]), in2, hWin)
+        vol = torch.empty((H1, W, hWin), device=cuda)
+        flow = torch.empty((H1, W), device=cuda)
+        t1, t2 = T(in1, cuda), T(in2, cuda)
+        ctx.check(dfe.lib().dfe_radial_match_argmin_f32(ctx.handle, t1.data_ptr(), H1 + extra, t2.data_ptr(), K, H1, W, hWin,
+                                                       vol.data_ptr(), flow.data_ptr(), 0))
+        assert np.array_equal(vol.cpu().numpy(), ref)
+        assert np.array_equal(flow.cpu().numpy(), ref.argmin(2).astype(np.float32))
+        staged = dfe.nn.SpatialRadialMatching(hWin).forward([T(np.ascontiguousarray(in1[:, :H1]), cuda), T(in2, cuda)])
+        assert torch.equal(staged, vol)
+    with pytest.raises(dfe.DfeError):
+        ctx.check(dfe.lib().dfe_radial_match_argmin_f32(ctx.handle, vol.data_ptr(), 0, vol.data_ptr(), 1, 4, 4, 5, None, flow.data_ptr(), 0))
