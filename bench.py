@@ -32,6 +32,13 @@ WORKLOADS = {
     "1080p": (1080, 1920, 3, 7, 33, 33),
     "vga-luma": (480, 640, 1, 7, 33, 33),   # luminance frames (C = 1)
 }
+# fp16 cost volume (BASELINE configs[4]; SURVEY 8(d): 3840x2160 / 33x33 fp16 = 17 770.8 MB per pair): the same step through
+# dfe_flow_depth_pair_f16 -- volume stored as half(cost * 2^-8), arg-min before the down-convert
+F16_WORKLOADS = {
+    "4k-f16": (2160, 3840, 3, 7, 33, 33),
+    "vga-f16": (480, 640, 3, 7, 33, 33),
+    "1080p-f16": (1080, 1920, 3, 7, 33, 33),
+}
 # BASELINE.json configs[1] literally: 640x480, 3-level pyramid {1,2,4}, 7x7 patch, 8x8 window per scale (= +-16 at the
 # coarsest scale), through dfe_multiscale_flow_pair_f32.  Not the default: the north-star roofline target is stated for
 # the single-scale cost-volume build, which is what `vga` measures.
@@ -51,9 +58,9 @@ RADIALS = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(H, W, Cc, k, hWin, wWin):
+def algorithmic_bytes(H, W, Cc, k, hWin, wWin, elem=4):
     Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
-    return 2 * Cc * H * W * 4 + Ho * Wo * hWin * wWin * 4
+    return 2 * Cc * H * W * 4 + Ho * Wo * hWin * wWin * elem
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -302,7 +309,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS))
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS) + sorted(F16_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed) gather of the results to rank 0")
     args = ap.parse_args()
@@ -334,7 +341,8 @@ def main():
         return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
     if args.workload in RADIALS:
         return main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp)
-    H, W, Cc, k, hWin, wWin = WORKLOADS[args.workload]
+    f16 = args.workload in F16_WORKLOADS
+    H, W, Cc, k, hWin, wWin = (F16_WORKLOADS if f16 else WORKLOADS)[args.workload]
     (pair_id,) = shard_pairs(world, world, rank)                              # a batch of `world` pairs, pair p on rank p
     f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=pair_id, max_flow=12)  # one seeded pair per rank
     t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
@@ -346,6 +354,10 @@ def main():
     lib = d.lib()
 
     def step():
+        if f16:
+            ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, hWin, wWin, cx, cy, 2.0 ** -8, None, None,
+                                                  flow.data_ptr(), depth.data_ptr(), dconf.data_ptr()))
+            return
         ctx.check(
             lib.dfe_flow_depth_pair_f32(
                 ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, hWin, wWin, cx, cy, 0.21,
@@ -371,23 +383,30 @@ def main():
     if rank == 0:
         Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
         try:
-            vol = torch.empty((Ho, Wo, hWin, wWin), device=dev)
+            vol = torch.empty((Ho, Wo, hWin, wWin), device=dev, dtype=torch.float16 if f16 else torch.float32)
+
+            def build():
+                if f16:
+                    ctx.check(lib.dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, 2.0 ** -8, vol.data_ptr()))
+                else:
+                    ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+
             for _ in range(5):
-                ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+                build()
             torch.cuda.synchronize()
             ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
             for _ in range(20):
-                ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+                build()
             b_ms, b_n = C.c_double(), C.c_int()
             ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(b_ms), C.byref(b_n)))
             ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
-            build_ms, build_kernel = b_ms.value / max(b_n.value, 1), ctx.last_kernel()
+            build_ms, build_kernel = b_ms.value / 20, ctx.last_kernel()   # (per build = per pair, whatever the number of band launches)
             del vol
         except torch.OutOfMemoryError:
             pass
 
     gather = None
-    if world > 1 and not args.no_gather:
+    if world > 1 and not args.no_gather and not f16:
         # results of the batch to rank 0 (flow as int16 x 2 -- displacements are integers in +-16 --, scores and depth fp32)
         res, g_s, g_bytes = gather_results([flow.to(torch.int16), scores, depth], world, rank, dist, torch.cuda.synchronize)
         if rank == 0:
@@ -395,8 +414,10 @@ def main():
             gather = {"ms": round(g_s * 1e3, 3), "bytes_to_rank0": g_bytes, "note": "untimed: after the K steps, one gather of every pair's {flow int16 x2, scores, depth}"}
 
     if rank == 0:
-        balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin)
-        kern_s = cv_ms.value / 1e3 / max(cv_n.value, 1)
+        balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin, 2 if f16 else 4)
+        # (a frame whose volume exceeds the scratch limit is built in several bands = several launches per step: the
+        #  algorithmic bytes are the pair's, so the time is the sum of the step's cost-volume launches)
+        kern_s = cv_ms.value / 1e3 / max(args.steps, 1)
         achieved = balg / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic = build_traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -418,11 +439,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 sums, f16 volume" if f16 else "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d C=%d single-scale dense SSD cost volume (7x7 patch, %dx%d window = +-16) "
-                "+ arg-min/extractOutput/decode + flow->depth, one pair per GPU per step" % (W, H, Cc, hWin, wWin),
+                "workload": "%dx%d C=%d single-scale dense SSD cost volume (7x7 patch, %dx%d window = +-16)%s "
+                "+ arg-min/%sdecode + flow->depth, one pair per GPU per step" % (W, H, Cc, hWin, wWin, " stored as fp16 (cost * 2^-8)" if f16 else "",
+                                                                               "" if f16 else "extractOutput/"),
                 "pairs_per_step": world,
                 "sharding": "pair-per-gpu" if world > 1 else "single",
             },
@@ -440,6 +462,7 @@ def main():
                 if kern_s > 0 else None,
                 "kernel_ms": round(kern_s * 1e3, 5),
                 "launches_timed": cv_n.value,
+                "launches_per_step": cv_n.value // max(args.steps, 1),
             },
         }
         if build_ms:
@@ -451,7 +474,7 @@ def main():
             }
         if gather:
             out["gather"] = gather
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(f0, f1, k, hWin, wWin, cx, cy)
         print(json.dumps(out), flush=True)
     if world > 1:

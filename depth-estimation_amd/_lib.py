@@ -31,6 +31,8 @@ PROTOTYPES = {
     "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),
     "dfe_ssd_cost_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
+    "dfe_ssd_cost_volume_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, C.c_void_p]),
+    "dfe_flow_depth_pair_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 5),
     "dfe_spatial_matching_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "dfe_radial_matching_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "dfe_argbest_center": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -186,6 +186,7 @@ struct CvTiledArgs {
     int stage_len;     // row-image kernel: floats per image
     int sw_ovh;        // column sweep: cost of starting a piece, in row steps (warm-up rows + ring staging)
     int sw_min;        // column sweep: a piece is never shorter than this many output rows
+    float scale;       // fp16 volume: stored value = cost * scale (2^-8 keeps 147 * 255^2 inside the half range)
 };
 
 // Persistent column sweep: the (column, output row) grid is walked column-major as one linear sequence of ncols*Ho row
@@ -776,10 +777,16 @@ template <int C, int K, int TX> struct RowimgGeom {
     static constexpr int sweep_tile0_off = (R * pitch33 * px_bytes + 127) / 128 * 128;
     static constexpr int sweep_stage_off = sweep_tile0_off + (R0 * kT0W * px_bytes + VUnroll<K>::value * 64 * 4 + 127) / 128 * 128;
     static constexpr int stage_len33 = (TX * 1089 + 32 + 31) / 32 * 32;
+    static constexpr int stage_len33h = (TX * 1089 + 64 + 31) / 32 * 32;   // fp16 volume: image congruent to the global index mod 64 (a line of halfs)
 };
 // DC: the window's cell count as a compile-time constant (0 = run time).  With D known, the 8 deposit addresses per task row
 // (st + x*D + d), the scan's and the copy-out's become immediate offsets -- instructions of the lock-stepped phases.
-template <int C, int K, int TX, bool SM, bool FUSE, bool SWEEP, int DC = 0>
+// F16: the volume leaves as fp16 (cost * p.scale, round to nearest even).  The row image stays fp32 -- the fused arg-min scan
+// reads it, so indices and minima are those of the fp32 build ("arg-min before the down-convert") -- and is kept congruent to
+// the global HALF index mod 64; the copy-out converts 8 cells per lane into one dwordx4.  Static tiles only (a 128-B line
+// holds 64 cells: completing the run's last line would take up to 63 cells of the next pixel, more than the mini task's
+// idle lanes, so partial lines stay and rely on the XCD-aware block order).
+template <int C, int K, int TX, bool SM, bool FUSE, bool SWEEP, int DC = 0, bool F16 = false>
 __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__restrict__ I0, const float *__restrict__ I1,
                                                              float *__restrict__ out, CvTiledArgs p, CvFuseArgs fa) {
     using px_t = typename Px<C>::type;
@@ -801,7 +808,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const int g_lrows = (CG && SWEEP) ? RowimgGeom<C, K, TX>::R : p.lrows;
     const int g_tile0_off = (CG && SWEEP) ? RowimgGeom<C, K, TX>::sweep_tile0_off : p.tile0_off;
     const int g_stage_off = (CG && SWEEP) ? RowimgGeom<C, K, TX>::sweep_stage_off : p.stage_off;
-    const int g_stage_len = CG ? RowimgGeom<C, K, TX>::stage_len33 : p.stage_len;
+    const int g_stage_len = CG ? (F16 ? RowimgGeom<C, K, TX>::stage_len33h : RowimgGeom<C, K, TX>::stage_len33) : p.stage_len;
+    static_assert(!(F16 && SWEEP), "fp16 volumes: static tiles only");
+    constexpr int LM = F16 ? 63 : 31;                    // cells per 128-B line of the volume, minus one
     px_t *lds = reinterpret_cast<px_t *>(dfe_smem);                             // frame-1 tile [lrows][pitch]
     const px_t *t0 = reinterpret_cast<const px_t *>(dfe_smem + g_tile0_off);    // frame-0 tile [ROWS][32]
     float *stage = reinterpret_cast<float *>(dfe_smem + g_stage_off);          // [2][stage_len], 128-B aligned
@@ -814,7 +823,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // XCD layout.  Instead the block also computes the <= 31 leading cells of pixel x0+8 that complete its last line (31
     // idle lanes of the mini task: one output per lane, no extra instructions) and writes that line whole; its right
     // neighbour skips its head.  Left: two partial lines per IMAGE row (first and last column) instead of two per tile row.
-    constexpr bool TOWN = DC == 1089;
+    constexpr bool TOWN = DC == 1089 && !F16;
     // Static tiles: one piece per block, XCD-aware block order (hardware deals linear block ids round-robin to the 8 XCDs; give
     // every XCD a contiguous range of tiles, x fastest, so neighbours in x share an L2), TY output rows per block, the last
     // tile row shifted inwards.  Column sweep: the block walks down its range of the column-major (column, row) sequence
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             G0_run += (long long)p.Wo * D;
             const long long pg_run = pg_next;
             if constexpr (FUSE) pg_next += p.Wo;
-            const int a0 = (int)(G0 & 31);
+            const int a0 = (int)(G0 & LM);
             float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
@@ -1164,18 +1173,48 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
                 if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
-                    const int head = (32 - (a0 + ov)) & 31;                  // floats before the first whole line
-                    const int ntl = has_next ? (-(a0 + RUN)) & 31 : 0;       // cells of the next pixel that complete the last line
-                    const int nbody4 = ((RUN - ov - head + ntl) >> 5) << 3;  // float4 pieces in whole 128-B lines
-                    const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
-                    const float *gb = out + G0 + ov + head;
                     int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
-                    // at most 3 pieces per thread (TX*D/4 <= 2192 float4 over >= 960 threads): all LDS reads first, then the
+                    constexpr int STR = NCW * 64;
+                    int head, nbody4;
+                    if constexpr (F16) {
+                        // 8 cells per piece: two b128 reads of the fp32 image -> v_cvt_pkrtz would truncate, so four
+                        // v_cvt_f16_f32 pairs (round to nearest even) packed into one dwordx4 store
+                        head = (64 - (a0 + ov)) & 63;                        // cells before the first whole line
+                        const int nbody8 = ((RUN - ov - head) >> 6) << 3;    // 8-cell pieces in whole 128-B lines
+                        nbody4 = nbody8 << 1;                                // (in 4-cell units, for the tail below)
+                        const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
+                        const _Float16 *gb = reinterpret_cast<const _Float16 *>(out) + G0 + ov + head;
+                        constexpr int NPC = ((TX * 1096 + 64) / 8 + STR - 1) / STR;
+                        const float sc = p.scale;
+                        f4_t lo[NPC], hi[NPC];
+#pragma unroll
+                        for (int i = 0; i < NPC; ++i) {
+                            const int j = min(tj + i * STR, nbody8 - 1);
+                            lo[i] = sb[2 * j];
+                            hi[i] = sb[2 * j + 1];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NPC; ++i)
+                            if (tj + i * STR < nbody8) {
+                                typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                                union { h2_t h[4]; f4_t v; } u;
+                                u.h[0] = h2_t{(_Float16)(lo[i][0] * sc), (_Float16)(lo[i][1] * sc)};
+                                u.h[1] = h2_t{(_Float16)(lo[i][2] * sc), (_Float16)(lo[i][3] * sc)};
+                                u.h[2] = h2_t{(_Float16)(hi[i][0] * sc), (_Float16)(hi[i][1] * sc)};
+                                u.h[3] = h2_t{(_Float16)(hi[i][2] * sc), (_Float16)(hi[i][3] * sc)};
+                                asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(u.v), "s"(gb) : "memory");
+                            }
+                    } else {
+                    head = (32 - (a0 + ov)) & 31;                            // floats before the first whole line
+                    const int ntl = has_next ? (-(a0 + RUN)) & 31 : 0;       // cells of the next pixel that complete the last line
+                    nbody4 = ((RUN - ov - head + ntl) >> 5) << 3;            // float4 pieces in whole 128-B lines
+                    const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
+                    const float *gb = out + G0 + ov + head;
+                    // at most 3 (4 with 10 copier waves) pieces per thread: all LDS reads first, then the
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
-                    constexpr int STR = NCW * 64;
                     constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
                     f4_t val[NPC];
 #pragma unroll
@@ -1184,10 +1223,17 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     for (int i = 0; i < NPC; ++i)
                         if (tj + i * STR < nbody4)
                             asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                    }
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
-                        if (wave == CW0 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
-                        if (wave == CW0 + 1 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
+                        if constexpr (F16) {
+                            _Float16 *oh = reinterpret_cast<_Float16 *>(out);
+                            if (wave == CW0 && lane < head) oh[G0 + ov + lane] = (_Float16)(st[ov + lane] * p.scale);
+                            if (wave == CW0 + 1 && lane < ntail) oh[G0 + tail0 + lane] = (_Float16)(st[tail0 + lane] * p.scale);
+                        } else {
+                            if (wave == CW0 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
+                            if (wave == CW0 + 1 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
+                        }
                     }
                 }
             }
@@ -1203,7 +1249,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 
 // LDS bytes of a static-tile block of `ty` output rows (0 = does not apply) and the kernel arguments that go with it
 template <int C, int K, int TX>
-static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int wWin, CvTiledArgs *out_args) {
+static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int wWin, CvTiledArgs *out_args, bool f16 = false) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
@@ -1223,8 +1269,10 @@ static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int w
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
     a.stage_off = a.tile0_off + (int)(((size_t)rows * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
-    a.stage_len = (TX * D + 32 + 31) / 32 * 32;
+    a.stage_len = (TX * D + (f16 ? 64 : 32) + 31) / 32 * 32;
     a.chunk0 = 0;
+    a.sw_ovh = a.sw_min = 0;
+    a.scale = 1.f;
     size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
     if (lds_bytes > 160 * 1024) return 0;
     if (out_args) *out_args = a;
@@ -1232,18 +1280,20 @@ static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int w
 }
 
 // static tiles of `ty` output rows
-template <int C, int K, int TX, bool FUSE>
+template <int C, int K, int TX, bool FUSE, bool F16 = false>
 static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin,
-                                int ty, float *out, const CvFuseArgs *fa, bool *handled) {
+                                int ty, float *out, const CvFuseArgs *fa, bool *handled, float scale = 1.f) {
     *handled = false;
     CvTiledArgs a;
-    const size_t lds_bytes = rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, &a);
+    const size_t lds_bytes = rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, &a, F16);
     if (!lds_bytes) return DFE_OK;
+    a.scale = scale;
     // the +-16 search (33 x 33 = 1089 cells) gets the instantiation with D as a constant
-    if (hWin == 33 && wWin == 33 && (a.pitch != RowimgGeom<C, K, TX>::pitch33 || a.stage_len != RowimgGeom<C, K, TX>::stage_len33))
+    if (hWin == 33 && wWin == 33 && (a.pitch != RowimgGeom<C, K, TX>::pitch33 ||
+                                     a.stage_len != (F16 ? RowimgGeom<C, K, TX>::stage_len33h : RowimgGeom<C, K, TX>::stage_len33)))
         return dfe_fail(ctx, DFE_E_UNSUPPORTED, "row-image kernel: LDS geometry differs from the kernel's constants");
-    auto kern = (hWin == 33 && wWin == 33) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 1089>
-                                      : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false>;
+    auto kern = (hWin == 33 && wWin == 33) ? ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 1089, F16>
+                                      : ssd_cv_rowimg_kernel<C, K, TX, DFE_RI_SMEM, FUSE, false, 0, F16>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(a.Wo, TX), dfe_cdiv(a.Ho, ty));
     {
@@ -1251,7 +1301,8 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
         hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = FUSE ? "ssd_cv_rowimg_kernel+fused_tail" : "ssd_cv_rowimg_kernel";
+    ctx->last_kernel = F16 ? (FUSE ? "ssd_cv_rowimg_kernel_f16+fused_tail" : "ssd_cv_rowimg_kernel_f16")
+                           : (FUSE ? "ssd_cv_rowimg_kernel+fused_tail" : "ssd_cv_rowimg_kernel");
     *handled = true;
     return DFE_OK;
 }
@@ -1300,6 +1351,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     while ((a.pitch - wWin) % M != 0) ++a.pitch;
     const int ncols = dfe_cdiv(Wo, TX);
     a.seg_rows = 0;
+    a.scale = 1.f;
     a.sw_ovh = kSweepOvh; a.sw_min = kSweepMin;
     int nblk = sweep_blocks(ctx, ncols, Ho);
     if (const int k = FUSE ? 0 : sweep_aligned_k(ctx, ncols, Ho)) { nblk = k * ncols; a.sw_ovh = 0; }
@@ -1341,14 +1393,14 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
 // the co-bottleneck, and a short tile's warm-up rows overlapped the drain of the previous tile's stores.)
 // ty + K-1 is a multiple of the row unroll U; LDS (the frame-1 tile grows with ty) allows up to 48 rows at 33 x 33.
 template <int C, int K, int TX>
-static int rowimg_pick_ty(const dfe_ctx *ctx, int H, int W, long long plane, int hWin, int wWin, double *cost_out) {
+static int rowimg_pick_ty(const dfe_ctx *ctx, int H, int W, long long plane, int hWin, int wWin, double *cost_out, bool f16 = false) {
     constexpr int U = VUnroll<K>::value;
     const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
     const int ncols = dfe_cdiv(Wo, TX);
     int best = 0;
     double best_cost = 1e30;
     for (int ty = U - (K - 1) % U; ty <= Ho && ty <= 20 * U; ty += U) {
-        if (ty < 1 || !rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, nullptr)) continue;
+        if (ty < 1 || !rowimg_plan<C, K, TX>(ty, H, W, plane, hWin, wWin, nullptr, f16)) continue;
         const double cost = (double)dfe_cdiv((long long)ncols * dfe_cdiv(Ho, ty), ctx->ncu) * (ty + K - 1);
         if (cost < best_cost) { best_cost = cost; best = ty; }   // ties: the shorter tile (less LDS, finer last round)
     }
@@ -1388,6 +1440,35 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
         }
     }
     return launch_cv_rowimg_one<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, ty, out, fa, handled);
+}
+
+// fp16 volume (cost * scale): static tiles of the row-image kernel, the height rowimg_pick_ty chooses for the (slightly larger) image
+template <int C, int K, int TX, bool FUSE>
+static int launch_cv_rowimg_f16(dfe_ctx *ctx, const float *I0, const float *I1, int H, int W, long long plane, int hWin, int wWin, float scale,
+                                void *out, const CvFuseArgs *fa, bool *handled) {
+    *handled = false;
+    int ty;
+    const int code = ctx->cv_tyq;
+    if (code >= 100) ty = code - 100;
+    else ty = rowimg_pick_ty<C, K, TX>(ctx, H, W, plane, hWin, wWin, nullptr, true);
+    if (ty < 1) return DFE_OK;
+    return launch_cv_rowimg_one<C, K, TX, FUSE, true>(ctx, I0, I1, H, W, plane, hWin, wWin, ty, (float *)out, fa, handled, scale);
+}
+
+// fp16 build of raw frames (C in {1, 3}, k = 7, 769..1096 window cells); *handled = false: no fast kernel for the shape
+int cv_frames_dispatch_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin, int wWin,
+                           float scale, void *out, const CvFuseArgs *fa, bool *handled) {
+    *handled = false;
+    if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || k != 7 || (C != 3 && C != 1)) return DFE_OK;
+    if (fa) return C == 3 ? launch_cv_rowimg_f16<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, fa, handled)
+                          : launch_cv_rowimg_f16<1, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, fa, handled);
+    return C == 3 ? launch_cv_rowimg_f16<3, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, nullptr, handled)
+                  : launch_cv_rowimg_f16<1, 7, 8, false>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, nullptr, handled);
+}
+
+// fp32 -> fp16 with the volume's scale (shapes without a fast fp16 kernel: built in fp32 bands, converted)
+__global__ __launch_bounds__(256) void cv_to_half_kernel(const float *__restrict__ in, long long n, float scale, _Float16 *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) out[e] = (_Float16)(in[e] * scale);
 }
 
 // the volumes of n independent frame pairs with windows of at most one chunk (C = 3, k = 7) in one launch; *handled = false
@@ -1522,8 +1603,8 @@ int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
 
 // rows of the output volume that fit one scratch band (ctx->scratch_limit, 16 GiB by default:
 // one launch per pair up to 1080p/33x33; 288 GB of HBM make the whole volume the natural unit)
-static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D) {
-    long long row_bytes = (long long)Wo * D * sizeof(float);
+static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D, int elem = (int)sizeof(float)) {
+    long long row_bytes = (long long)Wo * D * elem;
     long long band = (long long)ctx->scratch_limit / row_bytes;
     if (band < 1) band = 1;
     if (band > Ho) band = Ho;
@@ -1537,12 +1618,16 @@ static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D) {
 // Fallback (shapes without a fused instantiation): build, then the full pass dfe_flow_tail.
 static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin,
                          double thr, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int pitch,
-                         int pad_t, int pad_l, int scores_padded, const DfePairDepth *pd = nullptr, bool *pd_done = nullptr) {
+                         int pad_t, int pad_l, int scores_padded, const DfePairDepth *pd = nullptr, bool *pd_done = nullptr, float f16_scale = 0.f) {
+    // f16_scale != 0: the volume is materialised as fp16 (cost * f16_scale); arg-min, centre and lead cells still come from
+    // the fp32 sums in the kernel, so indices and minima are those of the fp32 path.  No extractOutput scores then (its
+    // rare fall-back reads the volume).
     const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
     const int D = hWin * wWin, nch = (D + 63) / 64;
     const long long P = (long long)Ho * Wo;
-    const int band = band_rows(ctx, Ho, Wo, D);
-    const size_t vol_bytes = ((size_t)band * Wo * D * sizeof(float) + 255) / 256 * 256;
+    const int elem = f16_scale != 0.f ? 2 : 4;
+    const int band = band_rows(ctx, Ho, Wo, D, elem);
+    const size_t vol_bytes = ((size_t)band * Wo * D * elem + 255) / 256 * 256;
     const size_t part_bytes = ((size_t)nch * P * sizeof(float2) + 255) / 256 * 256;
     const size_t cen_bytes = ((size_t)P * sizeof(float) + 255) / 256 * 256;
     const size_t lead_bytes = ((size_t)P * DFE_LEAD * sizeof(float) + 255) / 256 * 256;
@@ -1565,7 +1650,13 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
         bool fused = false;
         int nparts = nch;
-        if (kh == kw) {
+        if (kh == kw && f16_scale != 0.f) {
+            fa.row_off = r0;
+            rc = cv_frames_dispatch_f16(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, f16_scale, vol, &fa, &fused);
+            if (rc) return rc;
+            nparts = 2;
+            if (!fused) return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no fused fp16 cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);
+        } else if (kh == kw) {
             fa.row_off = r0;
             rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused, &nparts);
             if (rc) return rc;
@@ -1625,6 +1716,61 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
     if (rc || pd_done) return rc;
     // several bands, or no fused build for this shape: one pass afterwards zeroes the border and makes depth
     return dfe_pair_border_depth(ctx, flow, scores, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
+}
+
+int dfe_ssd_cost_volume_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin,
+                            float scale, void *out) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, I0 && I1 && out, DFE_E_ARG, "dfe_ssd_cost_volume_f16: NULL tensor");
+    DFE_REQUIRE(ctx, C > 0 && kh > 0 && kw > 0 && hWin > 0 && wWin > 0 && scale > 0, DFE_E_ARG,
+                "dfe_ssd_cost_volume_f16: C=%d k=%dx%d win=%dx%d scale=%g must be positive", C, kh, kw, hWin, wWin, (double)scale);
+    const int Ho = H - kh + 1 - hWin + 1, Wo = W - kw + 1 - wWin + 1;
+    DFE_REQUIRE(ctx, Ho > 0 && Wo > 0, DFE_E_SHAPE, "dfe_ssd_cost_volume_f16: frame %dx%d too small for kernel %dx%d + window %dx%d", H, W, kh, kw,
+                hWin, wWin);
+    if (kh == kw) {
+        bool handled = false;
+        int rc = cv_frames_dispatch_f16(ctx, I0, I1, C, H, W, (long long)H * W, kh, hWin, wWin, scale, out, nullptr, &handled);
+        if (rc != DFE_OK || handled) return rc;
+    }
+    // any other shape: fp32 bands in the scratch arena, converted
+    const int D = hWin * wWin;
+    const int band = band_rows(ctx, Ho, Wo, D);
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
+    if (rc) return rc;
+    for (int r0 = 0; r0 < Ho; r0 += band) {
+        const int nr = (r0 + band <= Ho) ? band : Ho - r0;
+        rc = cv_frames_dispatch(ctx, I0 + (long long)r0 * W, I1 + (long long)r0 * W, C, nr + kh - 1 + hWin - 1, W, (long long)H * W, kh, kw, hWin, wWin,
+                                (float *)scr);
+        if (rc) return rc;
+        const long long n = (long long)nr * Wo * D;
+        long long blocks = (n + 255) / 256;
+        if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL(cv_to_half_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float *)scr, n, scale,
+                           (_Float16 *)out + (long long)r0 * Wo * D);
+        DFE_LAUNCH_CHECK(ctx);
+    }
+    return DFE_OK;
+}
+
+int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x,
+                            float foe_y, float scale, int64_t *idx, float *best, float *flow, float *depth, float *depth_conf) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, I0 && I1 && flow, DFE_E_ARG, "dfe_flow_depth_pair_f16: NULL tensor");
+    DFE_REQUIRE(ctx, C > 0 && k > 0 && hWin > 0 && wWin > 0 && scale > 0, DFE_E_ARG, "dfe_flow_depth_pair_f16: C=%d k=%d win=%dx%d scale=%g", C, k, hWin,
+                wWin, (double)scale);
+    DFE_REQUIRE(ctx, (depth == nullptr) == (depth_conf == nullptr), DFE_E_ARG, "dfe_flow_depth_pair_f16: depth and depth_conf go together");
+    const int Ho = H - k + 1 - hWin + 1, Wo = W - k + 1 - wWin + 1;
+    DFE_REQUIRE(ctx, Ho > 0 && Wo > 0, DFE_E_SHAPE, "dfe_flow_depth_pair_f16: frame %dx%d too small for kernel %d + window %dx%d", H, W, k, hWin, wWin);
+    const long long HW = (long long)H * W;
+    const int pad_t = (H - Ho) / 2, pad_l = (W - Wo) / 2;
+    const DfePairDepth pd{H, W, foe_x, foe_y, depth, depth_conf};
+    bool pd_done = false;
+    // (idx / best are [Ho][Wo], like dfe_ssd_flow_f32's; flow is the centre-pasted [2][H][W])
+    int rc = flow_pipeline(ctx, I0, I1, C, H, W, k, k, hWin, wWin, 0.0, idx, best, flow, flow + HW, nullptr, nullptr, W, pad_t, pad_l, 1, &pd, &pd_done,
+                           scale);
+    if (rc || pd_done) return rc;
+    return dfe_pair_border_depth(ctx, flow, nullptr, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
 }
 
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh,

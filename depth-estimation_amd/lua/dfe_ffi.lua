@@ -25,6 +25,8 @@ int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float *out);
+int dfe_ssd_cost_volume_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float scale, void *out);
+int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, float scale, int64_t *idx, float *best, float *flow, float *depth, float *depth_conf);
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W, int hWin, float *out);
 int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_rows, const float *in2, int K, int H1, int W, int hWin, float *volume, float *flow, int zero_last_row);

@@ -91,6 +91,21 @@ int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W,
                             int kh, int kw, int hWin, int wWin, float *out);
 
+/* ---- A0+A1 with an fp16 volume (BASELINE configs[4]; SURVEY 7 "fp16 cost volume", 8(c) numeric contract) ------ */
+/* Same sums as dfe_ssd_cost_volume_f32 (fp32 accumulation); the volume is stored as IEEE half, out[..] =
+ * half(cost * scale), round to nearest even.  Raw SSD overflows half (147 * 255^2 = 9.56e6 > 65504), hence the scale:
+ * 2^-8 for uint8-valued frames (max 37 344), 1 for frames in [0, 1].  out [Ho][Wo][hWin][wWin] of uint16 (half bits).
+ * Stored values are within rel 2^-11 of the fp32 volume (bit-exact against half(oracle * scale) on integer-valued frames). */
+int dfe_ssd_cost_volume_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin,
+                            int wWin, float scale, void *out);
+/* dfe_flow_depth_pair_f32 with the volume materialised as fp16: arg-min (+ centre tie-break) is taken on the fp32 sums
+ * BEFORE the down-convert, so idx / best / flow / depth are identical to the fp32 path's.  idx, best [Ho][Wo] (may be NULL),
+ * flow [2][H][W] centre-pasted, depth / depth_conf [H][W] (both or neither).  No extractOutput scores (their rare
+ * fall-back reads the volume).  Shapes: C in {1,3}, 7x7 patch, 769..1096 window cells (else DFE_E_UNSUPPORTED). */
+int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin,
+                            float foe_x, float foe_y, float scale, int64_t *idx, float *best, float *flow, float *depth,
+                            float *depth_conf);
+
 /* ---- A1: nn.SpatialMatching(maxh,maxw,false):updateOutput on feature maps -- */
 /* replaces: nnx SpatialMatching call sites opticalflow_model_multiscale.lua:216,
  *   opticalflow_model.lua:93, version2/network.lua:30, tests/time_matching.lua:18.

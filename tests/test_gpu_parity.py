@@ -677,3 +677,81 @@ def test_patch_mode_spatial_matching_equals_oracle(dfe, cuda):
         assert np.array_equal(out.cpu().numpy(), orc.spatial_matching(in1, in2, maxh, maxh))
         m = int((-out).reshape(-1).argmax().item()) + 1
         assert m == (fy + math.ceil(maxh / 2) - 1) * maxh + fx + math.ceil(maxh / 2)
+
+
+# ------------------------------------------------------------------ fp16 cost volume (BASELINE configs[4], SURVEY 8(c) numeric contract)
+def _half_oracle(cost, scale):
+    return (cost * np.float32(scale)).astype(np.float16)
+
+
+@pytest.mark.parametrize("H,W,C,win,tile", [(96, 130, 3, 33, 0), (131, 90, 3, 33, 118), (75, 47, 1, 33, 0), (70, 90, 3, 31, 0), (60, 64, 3, 9, 0), (50, 60, 2, 5, 0)])
+def test_cost_volume_f16_bit_exact_on_integer_frames(dfe, cuda, H, W, C, win, tile):
+    """dfe_ssd_cost_volume_f16: half(cost * 2^-8), round to nearest even -- bit-exact against the oracle's fp32 volume converted
+    by numpy, for the row-image kernel's fp16 instantiations (33x33 with D constant, 31x31 generic, C = 1 and 3, ragged
+    sizes so that partial lines and shifted last tiles occur) and for shapes that take the fp32-bands + convert route."""
+    k = 7 if C != 2 else 5
+    f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=H + win, max_flow=4)
+    cpu = orc.ssd_cost_volume(f0, f1, k, k, win, win)
+    ctx = dfe.get_ctx(0)
+    ctx.set_cost_volume_tile(tile)
+    try:
+        out = torch.full(cpu.shape, -1.0, dtype=torch.float16, device=cuda)
+        t0, t1 = T(f0, cuda), T(f1, cuda)
+        ctx.check(dfe.lib().dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, k, win, win, 2.0 ** -8, out.data_ptr()))
+        fast = C in (1, 3) and k == 7 and 768 < win * win <= 1096
+        assert ctx.last_kernel() == ("ssd_cv_rowimg_kernel_f16" if fast else ctx.last_kernel())
+        if fast:
+            assert ctx.last_kernel() == "ssd_cv_rowimg_kernel_f16"
+    finally:
+        ctx.set_cost_volume_tile(0)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), _half_oracle(cpu, 2.0 ** -8).view(np.uint16))
+
+
+def test_cost_volume_f16_float_frames_within_half_precision(dfe, cuda):
+    """Frames in [0, 1] (scale 1): stored values within rel 2^-10 of the fp32 volume, deterministic."""
+    f0, f1, _, _ = rp.synth_pair(90, 100, C=3, seed=7, integer=False, max_flow=6)
+    cpu = orc.ssd_cost_volume(f0, f1, 7, 7, 33, 33)
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(cpu.shape, dtype=torch.float16, device=cuda)
+        ctx.check(dfe.lib().dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, 90, 100, 7, 7, 33, 33, 1.0, out.data_ptr()))
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    g = outs[0].cpu().numpy().astype(np.float32)
+    assert (np.abs(g - cpu) <= 2.0 ** -10 * np.abs(cpu) + 2.0 ** -24).all()
+
+
+@pytest.mark.parametrize("H,W,C", [(96, 130, 3), (480, 640, 3), (75, 47, 1)])
+def test_flow_depth_pair_f16_indices_identical_to_f32_path(dfe, cuda, H, W, C):
+    """dfe_flow_depth_pair_f16: arg-min before the down-convert -> idx, best, flow, depth identical to the fp32 pipeline's
+    (and to the oracle on a small frame); and the volume the step materialises is the fp16 one."""
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=C, seed=H, max_flow=10)
+    k, win = 7, 33
+    Ho, Wo = H - k - win + 2, W - k - win + 2
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    idx32 = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best32, fy, fx = (torch.empty((Ho, Wo), device=cuda) for _ in range(3))
+    ctx.check(lib.dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, k, win, win, 0.21, idx32.data_ptr(), best32.data_ptr(),
+                                   fy.data_ptr(), fx.data_ptr(), None, None))
+    flow32 = torch.empty((2, H, W), device=cuda)
+    sc, d32, c32 = (torch.empty((H, W), device=cuda) for _ in range(3))
+    ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 0.21, flow32.data_ptr(), sc.data_ptr(),
+                                          d32.data_ptr(), c32.data_ptr()))
+    idx16 = torch.empty_like(idx32)
+    best16 = torch.empty_like(best32)
+    flow16 = torch.empty_like(flow32)
+    d16, c16 = torch.empty_like(d32), torch.empty_like(c32)
+    ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 2.0 ** -8, idx16.data_ptr(),
+                                          best16.data_ptr(), flow16.data_ptr(), d16.data_ptr(), c16.data_ptr()))
+    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel_f16+fused_tail"
+    assert torch.equal(idx16, idx32) and torch.equal(best16, best32)
+    assert torch.equal(flow16, flow32) and torch.equal(d16, d32) and torch.equal(c16, c32)
+    if H < 200:
+        ref = rp.dense_flow_oracle(f0, f1, win, win, k, k)
+        assert np.array_equal(idx16.cpu().numpy(), ref["idx"]) and np.array_equal(best16.cpu().numpy(), ref["best"])
+    with pytest.raises(dfe.DfeError):   # no fused fp16 kernel for a 9x9 window: the caller takes the fp32 path
+        ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, 9, 9, cx, cy, 2.0 ** -8, None, None, flow16.data_ptr(), None, None))
