@@ -19,6 +19,7 @@ no CPU fallback -- a missing library or device raises.
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
 from . import nn  # noqa: F401
+from . import network, radial, glue  # noqa: F401
 from . import extractoutput  # noqa: F401
 from .opticalflow_model import (  # noqa: F401
     x2yx,
@@ -37,7 +38,7 @@ from .opticalflow_model import (  # noqa: F401
 from .multiscale import CascadingAddTable, MultiscaleModel, getModelMultiscale  # noqa: F401
 from .network import getFilter, getFilterRadial, getModel, tables_random  # noqa: F401
 from .radial import (getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth, getKOutput, getP2CMaskOF,  # noqa: F401
-                     computeDepthMapFromFlow, getTesterNetwork, getMatcher, radialFlowDepth, radial_out_shape)
+                     computeDepthMapFromFlow, getTesterNetwork, getTrainerNetwork, getMatcher, radialFlowDepth, radial_out_shape)
 from .glue import SmartReshape, FunctionWrapper, Mul2, Log2, OutputExtractor, postProcessImage, enlargeMask  # noqa: F401
 from . import torch7_io  # noqa: F401
 from .torch7_io import load_calibration  # noqa: F401

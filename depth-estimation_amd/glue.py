@@ -38,6 +38,10 @@ class SmartReshape(Module):
         self.output = input.view(size)
         return self.output
 
+    def updateGradInput(self, input, gradOutput):
+        self.gradInput = gradOutput.contiguous().view(input.shape)   # SmartReshape.lua:64-68
+        return self.gradInput
+
 
 class FunctionWrapper(Module):
     """nn.FunctionWrapper(init, updateOutput, updateGradInput): FunctionWrapper.lua:8-22"""
@@ -73,10 +77,22 @@ class Log2(Module):
         self.null_epsilon = null_epsilon
 
     def updateOutput(self, input):
-        if self.null_epsilon is not None:
-            input.clamp_(min=self.null_epsilon)  # bad*eps + (1-bad)*input, written back into input (:17)
-        self.output = input.log()
-        return self.output
+        if input.dtype != torch.float32 or not input.is_contiguous():
+            raise TypeError("Log2: input must be a contiguous FloatTensor (it is clamped in place, Log.lua:17)")
+        out = torch.empty_like(input)
+        ctx = get_ctx(input)
+        # bad*eps + (1-bad)*input written back into input (:15-18), then log (:19-21)
+        ctx.check(lib().dfe_log2_forward_f32(ctx.handle, ptr(input), input.numel(), float(self.null_epsilon or 0.0), int(self.null_epsilon is not None), ptr(out)))
+        self.output = out
+        return out
+
+    def updateGradInput(self, input, gradOutput):
+        go = gradOutput.contiguous()
+        gi = torch.empty_like(go)
+        ctx = get_ctx(go)
+        ctx.check(lib().dfe_log2_backward_f32(ctx.handle, ptr(input), ptr(go), go.numel(), ptr(gi)))   # gradOutput / input (:24-28)
+        self.gradInput = gi
+        return gi
 
 
 class OutputExtractor(Module):

@@ -21,6 +21,31 @@ class SpatialConvolution(Module):
         stdv = 1.0 / math.sqrt(self.kW * self.kH * self.nInputPlane)   # nn.SpatialConvolution:reset
         self.weight = (torch.rand((self.nOutputPlane, self.nInputPlane, self.kH, self.kW), generator=generator) * 2 - 1).mul_(stdv).to(device)
         self.bias = (torch.rand((self.nOutputPlane,), generator=generator) * 2 - 1).mul_(stdv).to(device)
+        self.gradWeight, self.gradBias = torch.zeros_like(self.weight), torch.zeros_like(self.bias)
+
+    def _params(self):
+        return [self.weight, self.bias]
+
+    def _grads(self):
+        return [self.gradWeight, self.gradBias]
+
+    def updateGradInput(self, input, gradOutput):
+        x, go = _f32c(input, "input"), _f32c(gradOutput, "gradOutput")
+        nIn, H, W = x.shape
+        if tuple(go.shape) != (self.nOutputPlane, H - self.kH + 1, W - self.kW + 1):
+            raise ValueError("SpatialConvolution: gradOutput must be %s, got %s" % ((self.nOutputPlane, H - self.kH + 1, W - self.kW + 1), tuple(go.shape)))
+        gi = torch.empty_like(x)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_grad_input_f32(ctx.handle, ptr(go), ptr(self.weight), nIn, self.nOutputPlane, H, W, self.kH, self.kW, ptr(gi)))
+        self.gradInput = gi
+        return gi
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        x, go = _f32c(input, "input"), _f32c(gradOutput, "gradOutput")
+        nIn, H, W = x.shape
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_acc_grad_f32(ctx.handle, ptr(x), ptr(go), nIn, self.nOutputPlane, H, W, self.kH, self.kW, float(scale),
+                                                             ptr(self.gradWeight), ptr(self.gradBias)))
 
     def updateOutput(self, input):
         x = _f32c(input, "input")
@@ -60,6 +85,32 @@ class SpatialConvolutionMap(Module):
         self.weight = (torch.rand((nconn, self.kH, self.kW), generator=generator) * 2 - 1).mul_(stdv).to(device)
         self.bias = (torch.rand((self.nOutputPlane,), generator=generator) * 2 - 1).mul_(stdv).to(device)
         self._conn_dev = self.connTable.to(device)
+        self.gradWeight, self.gradBias = torch.zeros_like(self.weight), torch.zeros_like(self.bias)
+
+    def _params(self):
+        return [self.weight, self.bias]
+
+    def _grads(self):
+        return [self.gradWeight, self.gradBias]
+
+    def updateGradInput(self, input, gradOutput):
+        x, go = _f32c(input, "input"), _f32c(gradOutput, "gradOutput")
+        nIn, H, W = x.shape
+        if tuple(go.shape) != (self.nOutputPlane, H - self.kH + 1, W - self.kW + 1):
+            raise ValueError("SpatialConvolutionMap: gradOutput must be %s, got %s" % ((self.nOutputPlane, H - self.kH + 1, W - self.kW + 1), tuple(go.shape)))
+        gi = torch.empty_like(x)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_map_grad_input_f32(ctx.handle, ptr(go), ptr(self.weight), ptr(self._conn_dev), self.connTable.shape[0], nIn,
+                                                                   self.nOutputPlane, H, W, self.kH, self.kW, ptr(gi)))
+        self.gradInput = gi
+        return gi
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        x, go = _f32c(input, "input"), _f32c(gradOutput, "gradOutput")
+        nIn, H, W = x.shape
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_spatial_convolution_map_acc_grad_f32(ctx.handle, ptr(x), ptr(go), ptr(self._conn_dev), self.connTable.shape[0], nIn,
+                                                                 self.nOutputPlane, H, W, self.kH, self.kW, float(scale), ptr(self.gradWeight), ptr(self.gradBias)))
 
     def updateOutput(self, input):
         x = _f32c(input, "input")
@@ -83,6 +134,14 @@ class Tanh(Module):
         self.output = out
         return out
 
+    def updateGradInput(self, input, gradOutput):
+        go = _f32c(gradOutput, "gradOutput")
+        gi = torch.empty_like(go)
+        ctx = get_ctx(go)
+        ctx.check(lib().dfe_tanh_backward_f32(ctx.handle, ptr(self.output), ptr(go), go.numel(), ptr(gi)))
+        self.gradInput = gi
+        return gi
+
 
 class Sequential(Module):
     def __init__(self):
@@ -94,10 +153,27 @@ class Sequential(Module):
         return self
 
     def updateOutput(self, input):
+        self._inputs = []
         for m in self.modules:
+            self._inputs.append(input)
             input = m.forward(input)
         self.output = input
         return input
+
+    def backward(self, input, gradOutput, scale=1.0):
+        """nn.Sequential:backward: modules in reverse order, each on the input it saw in the last forward."""
+        g = gradOutput
+        for m, x in zip(reversed(self.modules), reversed(self._inputs)):
+            g = m.backward(x, g, scale)
+        self.gradInput = g
+        return g
+
+    def updateGradInput(self, input, gradOutput):
+        g = gradOutput
+        for m, x in zip(reversed(self.modules), reversed(self._inputs)):
+            g = m.updateGradInput(x, g)
+        self.gradInput = g
+        return g
 
 
 class ParallelTable(Module):
@@ -113,11 +189,23 @@ class ParallelTable(Module):
         self.output = [m.forward(x) for m, x in zip(self.modules, input)]
         return self.output
 
+    def backward(self, input, gradOutput, scale=1.0):
+        self.gradInput = [m.backward(x, g, scale) for m, x, g in zip(self.modules, input, gradOutput)]
+        return self.gradInput
+
+    def updateGradInput(self, input, gradOutput):
+        self.gradInput = [m.updateGradInput(x, g) for m, x, g in zip(self.modules, input, gradOutput)]
+        return self.gradInput
+
 
 class Minus(Module):
     def updateOutput(self, input):
         self.output = -input
         return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        self.gradInput = -gradOutput
+        return self.gradInput
 
 
 class SoftMaxWindow(Module):
@@ -135,6 +223,16 @@ class SoftMaxWindow(Module):
         ctx.check(lib().dfe_softmin_f32(ctx.handle, ptr(cost), H * W, N, ptr(out)))
         self.output = out
         return out
+
+    def updateGradInput(self, input, gradOutput):
+        go = _f32c(gradOutput, "gradOutput")
+        out = self.output
+        gi = torch.empty_like(out)
+        ctx = get_ctx(out)
+        N = out.shape[-1]
+        ctx.check(lib().dfe_softmax_backward_f32(ctx.handle, ptr(out), ptr(go.reshape(out.shape)), out.numel() // N, N, ptr(gi)))
+        self.gradInput = gi.reshape(input.shape)
+        return self.gradInput
 
 
 def getFilter(geometry, device="cuda", generator=None):
@@ -173,26 +271,39 @@ def getFilterRadial(networkp, device="cuda", generator=None):
 
 
 class _SharedFilter(Module):
-    """filter:clone('weight','bias',...) -- the second branch shares the first one's parameters."""
+    """filter:clone('weight','bias','gradWeight','gradBias') -- the second branch shares the first one's parameters AND
+    gradient buffers (accGradParameters of both branches accumulates into the same tensors), but keeps its own outputs."""
 
     def __init__(self, filt):
         super().__init__()
         self.filt = filt
-
-    def updateOutput(self, input):
-        out = input
-        for m in self.filt.modules:     # run with the shared weights, keep an own output
-            if isinstance(m, SpatialConvolution):
-                mm = SpatialConvolution.__new__(SpatialConvolution)
-                mm.__dict__.update(m.__dict__)
-            elif isinstance(m, SpatialConvolutionMap):
-                mm = SpatialConvolutionMap.__new__(SpatialConvolutionMap)
-                mm.__dict__.update(m.__dict__)
+        self.modules = []
+        for m in filt.modules:
+            if isinstance(m, (SpatialConvolution, SpatialConvolutionMap)):
+                mm = type(m).__new__(type(m))
+                mm.__dict__.update(m.__dict__)     # same weight / bias / gradWeight / gradBias tensors
+                mm.output = mm.gradInput = None
             else:
                 mm = type(m)()
+            self.modules.append(mm)
+
+    def updateOutput(self, input):
+        self._inputs = []
+        out = input
+        for mm in self.modules:
+            self._inputs.append(out)
             out = mm.forward(out)
         self.output = out
         return out
+
+    def backward(self, input, gradOutput, scale=1.0):
+        g = gradOutput
+        for m, x in zip(reversed(self.modules), reversed(self._inputs)):
+            g = m.backward(x, g, scale)
+        self.gradInput = g
+        return g
+
+    updateGradInput = Sequential.updateGradInput
 
 
 def getModel(geometry, full_image=True, prefiltered=False, device="cuda", generator=None):

@@ -7,14 +7,55 @@ from .context import get_ctx, ptr
 
 
 class Module:
+    """Torch7's nn.Module protocol: forward = updateOutput; backward(input, gradOutput, scale) = updateGradInput +
+    accGradParameters; parameters() -> (weights, gradWeights); zeroGradParameters; updateParameters(lr)."""
+
     def __init__(self):
         self.output = None
+        self.gradInput = None
 
     def forward(self, input):
         return self.updateOutput(input)
 
     def __call__(self, input):
         return self.forward(input)
+
+    def updateGradInput(self, input, gradOutput):
+        raise NotImplementedError("%s: updateGradInput" % type(self).__name__)
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        pass
+
+    def backward(self, input, gradOutput, scale=1.0):
+        gi = self.updateGradInput(input, gradOutput)
+        self.accGradParameters(input, gradOutput, scale)
+        return gi
+
+    def parameters(self):
+        """([weights...], [gradWeights...]) of this module and its children (shared tensors listed once)."""
+        ws, gs, seen = [], [], set()
+        for m in self._all_modules():
+            for w, g in zip(getattr(m, "_params", lambda: [])(), getattr(m, "_grads", lambda: [])()):
+                if id(w) not in seen:
+                    seen.add(id(w))
+                    ws.append(w)
+                    gs.append(g)
+        return ws, gs
+
+    def _all_modules(self):
+        out = [self]
+        for m in getattr(self, "modules", []) or []:
+            out.extend(m._all_modules() if isinstance(m, Module) else [])
+        return out
+
+    def zeroGradParameters(self):
+        for g in self.parameters()[1]:
+            g.zero_()
+
+    def updateParameters(self, learningRate):
+        ws, gs = self.parameters()
+        for w, g in zip(ws, gs):
+            w.add_(g, alpha=-float(learningRate))
 
 
 def _f32c(t, what):

@@ -141,6 +141,65 @@ class SpatialPadding:
 
     updateOutput = forward
 
+    def backward(self, x, gradOutput, scale=1.0):
+        l, r, t, b = self.pads
+        if min(l, r, t, b) >= 0:
+            Cc, H, W = gradOutput.shape
+            self.gradInput = gradOutput[:, t : H - b, l : W - r].contiguous()
+        else:
+            gi = torch.zeros_like(x)
+            Cc, H, W = x.shape
+            gi[:, -t : H + b, -l : W + r] = gradOutput
+            self.gradInput = gi
+        return self.gradInput
+
+    updateGradInput = lambda self, x, g: self.backward(x, g)
+
+    def _all_modules(self):
+        return []
+
+
+class LogSoftMaxRows:
+    """nn.Reshape(1, hWin) -> nn.Minus -> nn.LogSoftMax -> nn.Reshape(hWin) of getTrainerNetwork
+    (radial/radial_opticalflow_network.lua:48-52) on a ... x hWin volume: log soft-MIN over the last dimension."""
+
+    def __init__(self):
+        self.output = self.gradInput = None
+
+    def forward(self, x):
+        x = x.contiguous()
+        N = x.shape[-1]
+        neg = (-x).contiguous()
+        out = torch.empty_like(x)
+        ctx = get_ctx(x)
+        ctx.check(lib().dfe_log_softmax_f32(ctx.handle, ptr(neg), x.numel() // N, N, ptr(out)))
+        self.output = out
+        return out
+
+    updateOutput = forward
+
+    def backward(self, x, gradOutput, scale=1.0):
+        go = gradOutput.contiguous()
+        N = go.shape[-1]
+        gi = torch.empty_like(go)
+        ctx = get_ctx(go)
+        ctx.check(lib().dfe_log_softmax_backward_f32(ctx.handle, ptr(self.output), ptr(go), go.numel() // N, N, ptr(gi)))
+        self.gradInput = -gi            # through the Minus
+        return self.gradInput
+
+    updateGradInput = lambda self, x, g: self.backward(x, g)
+
+    def _all_modules(self):
+        return []
+
+
+def getTrainerNetwork(networkp, device="cuda", generator=None):
+    """radial/radial_opticalflow_network.lua:36-54: the tester network followed by Reshape(1, hWin), Minus, LogSoftMax,
+    Reshape(hWin) -- log-probabilities over the hWin radial displacements (ClassNLLCriterion on top, train_radial:233-236)."""
+    network = getTesterNetwork(networkp, device=device, generator=generator)
+    network.add(LogSoftMaxRows())
+    return network
+
 
 def getTesterNetwork(networkp, device="cuda", generator=None):
     """radial/radial_opticalflow_network.lua:56-74: ParallelTable{ Sequential{SpatialPadding(0,0,0,-hWin+1), filter},
@@ -155,9 +214,7 @@ def getTesterNetwork(networkp, device="cuda", generator=None):
     filt = getFilterRadial(networkp, device=device, generator=generator)
     seq_prev.add(filt)
     filters.add(seq_prev)
-    shared = _SharedFilter(filt)
-    shared.modules = filt.modules
-    filters.add(shared)
+    filters.add(_SharedFilter(filt))
     network.add(filters)
     network.add(getMatcher(networkp))
     return network

@@ -363,6 +363,38 @@ int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *
                                     float *out);
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
 
+/* ---- next-row N2: gradients of the filter stack and of the soft-max / log layers, so that network:backward(input, df_do)
+ *      reaches the convolution weights through the drop-in (radial/train_radial_opticalflow.lua:228-252,
+ *      opticalflow.lua:296-338).  The modules are un-vendored nn; pinned by the finite-difference Jacobian of the
+ *      forward (the method of tests/test_cascad.lua:21-25). ------------------------------------------------------ */
+/* nn.SpatialConvolution:updateGradInput: gradIn[i][y][x] = sum_o sum_u sum_v w[o][i][u][v] gradOut[o][y-u][x-v];
+ * gradOut [nOut][H-kH+1][W-kW+1], gradIn [nIn][H][W]. */
+int dfe_spatial_convolution_grad_input_f32(dfe_ctx *ctx, const float *gradOut, const float *weight, int nIn, int nOut, int H,
+                                           int W, int kH, int kW, float *gradIn);
+/* nn.SpatialConvolution:accGradParameters(input, gradOutput, scale): gradWeight[o][i][u][v] += scale * sum_{y,x}
+ * gradOut[o][y][x] in[i][y+u][x+v]; gradBias[o] += scale * sum gradOut[o] (gradBias may be NULL).  ACCUMULATES (zero the
+ * buffers first, as zeroGradParameters does); shared between the two filter branches like the reference's clone(). */
+int dfe_spatial_convolution_acc_grad_f32(dfe_ctx *ctx, const float *in, const float *gradOut, int nIn, int nOut, int H, int W,
+                                         int kH, int kW, float scale, float *gradWeight, float *gradBias);
+/* the same for nn.SpatialConvolutionMap (weight / gradWeight [nConn][kH][kW], conn [nConn][2] (from, to) 1-based, device int32) */
+int dfe_spatial_convolution_map_grad_input_f32(dfe_ctx *ctx, const float *gradOut, const float *weight, const int32_t *conn,
+                                               int nConn, int nIn, int nOut, int H, int W, int kH, int kW, float *gradIn);
+int dfe_spatial_convolution_map_acc_grad_f32(dfe_ctx *ctx, const float *in, const float *gradOut, const int32_t *conn, int nConn,
+                                             int nIn, int nOut, int H, int W, int kH, int kW, float scale, float *gradWeight,
+                                             float *gradBias);
+/* nn.Tanh:updateGradInput from the module's OUTPUT: gradIn = gradOut * (1 - out^2) */
+int dfe_tanh_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOut, int64_t n, float *gradIn);
+/* nn.Log2 (Log.lua:13-28): forward clamps the INPUT in place to >= null_epsilon when clamp != 0 (:15-18), out = log(input);
+ * backward gradIn = gradOut / input (the clamped one). */
+int dfe_log2_forward_f32(dfe_ctx *ctx, float *input, int64_t n, float null_epsilon, int clamp, float *out);
+int dfe_log2_backward_f32(dfe_ctx *ctx, const float *input, const float *gradOut, int64_t n, float *gradIn);
+/* nn.LogSoftMax over rows [P][N] (radial/radial_opticalflow_network.lua:50) and its gradient gradIn = gradOut -
+ * exp(out) * sum(gradOut); nn.SoftMax's gradient gradIn = out * (gradOut - sum(gradOut * out)) for the window soft-max
+ * of getModel (opticalflow_model.lua:96-109; forward = dfe_softmin_f32 on the un-negated costs). */
+int dfe_log_softmax_f32(dfe_ctx *ctx, const float *in, int64_t P, int N, float *out);
+int dfe_log_softmax_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOut, int64_t P, int N, float *gradIn);
+int dfe_softmax_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOut, int64_t P, int N, float *gradIn);
+
 /* ---- A11 ('mean' extraction): marginal of the window over its columns --------------------------- */
 /* replaces: input:reshape(H,W,maxh,maxw):sum(4) in getOutputConfidences2, opticalflow_model.lua:192.
  *   in [P][A][B] -> out [P][A], double accumulator as in TH. */

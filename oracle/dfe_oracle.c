@@ -117,6 +117,94 @@ void orc_tanh(const float *in, int64_t n, float *out) { /* nn.Tanh: tanhf */
     for (int64_t i = 0; i < n; ++i) out[i] = tanhf(in[i]);
 }
 
+/* N2: gradients of the filter stack (un-vendored nn; pinned as the Jacobian of the forward above, the way
+ * tests/test_cascad.lua:21-25 pins the cascade).  conn == NULL: dense nn.SpatialConvolution, weight [nOut][nIn][kH][kW];
+ * else nn.SpatialConvolutionMap, weight [nConn][kH][kW], conn (from, to) 1-based.
+ *   gradIn[i][y][x]      = sum_o sum_u sum_v w[o][i][u][v] gO[o][y-u][x-v]        (terms in that order)
+ *   gradW[o][i][u][v]   += scale * sum_{y,x} gO[o][y][x] in[i][y+u][x+v]           (row-major float sum)
+ *   gradB[o]            += scale * sum_{y,x} gO[o][y][x] */
+void orc_spatial_convolution_grad_input(const float *go, const float *weight, const int *conn, int nConn, int nIn, int nOut,
+                                        int H, int W, int kH, int kW, float *gi) {
+    int Ho = H - kH + 1, Wo = W - kW + 1;
+    ORC_PAR_FOR
+    for (int i = 0; i < nIn; ++i)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float s = 0.f;
+                int nq = conn ? nConn : nOut;
+                for (int q = 0; q < nq; ++q) {
+                    int o = q;
+                    if (conn) {
+                        if (conn[2 * q] - 1 != i) continue;
+                        o = conn[2 * q + 1] - 1;
+                    }
+                    const float *wk = conn ? weight + (size_t)q * kH * kW : weight + ((size_t)o * nIn + i) * kH * kW;
+                    for (int u = 0; u < kH; ++u) {
+                        int yy = y - u;
+                        if (yy < 0 || yy >= Ho) continue;
+                        for (int v = 0; v < kW; ++v) {
+                            int xx = x - v;
+                            if (xx < 0 || xx >= Wo) continue;
+                            s += wk[u * kW + v] * go[((size_t)o * Ho + yy) * Wo + xx];
+                        }
+                    }
+                }
+                gi[((size_t)i * H + y) * W + x] = s;
+            }
+}
+void orc_spatial_convolution_acc_grad(const float *in, const float *go, const int *conn, int nConn, int nIn, int nOut, int H,
+                                      int W, int kH, int kW, float scale, float *gw, float *gb) {
+    int Ho = H - kH + 1, Wo = W - kW + 1;
+    int nq = conn ? nConn : nOut * nIn;
+    ORC_PAR_FOR
+    for (int q = 0; q < nq; ++q) {
+        int i = conn ? conn[2 * q] - 1 : q % nIn, o = conn ? conn[2 * q + 1] - 1 : q / nIn;
+        for (int u = 0; u < kH; ++u)
+            for (int v = 0; v < kW; ++v) {
+                float s = 0.f;
+                for (int y = 0; y < Ho; ++y)
+                    for (int x = 0; x < Wo; ++x) s += go[((size_t)o * Ho + y) * Wo + x] * in[((size_t)i * H + y + u) * W + x + v];
+                gw[((size_t)q * kH + u) * kW + v] += scale * s;
+            }
+    }
+    if (gb)
+        for (int o = 0; o < nOut; ++o) {
+            float s = 0.f;
+            for (int p = 0; p < Ho * Wo; ++p) s += go[(size_t)o * Ho * Wo + p];
+            gb[o] += scale * s;
+        }
+}
+void orc_tanh_backward(const float *out, const float *go, int64_t n, float *gi) {
+    for (int64_t i = 0; i < n; ++i) gi[i] = go[i] * (1.f - out[i] * out[i]);
+}
+/* nn.LogSoftMax over rows of N (radial/radial_opticalflow_network.lua:50) and its gradient; nn.SoftMax's gradient
+ * (the window soft-max of getModel, opticalflow_model.lua:96-109) */
+void orc_log_softmax(const float *in, int64_t P, int N, float *out) {
+    for (int64_t p = 0; p < P; ++p) {
+        const float *r = in + p * N;
+        float m = r[0];
+        for (int j = 1; j < N; ++j) m = r[j] > m ? r[j] : m;
+        double s = 0;
+        for (int j = 0; j < N; ++j) s += exp((double)r[j] - m);
+        float l = (float)(m + log(s));
+        for (int j = 0; j < N; ++j) out[p * N + j] = r[j] - l;
+    }
+}
+void orc_log_softmax_backward(const float *out, const float *go, int64_t P, int N, float *gi) {
+    for (int64_t p = 0; p < P; ++p) {
+        double s = 0;
+        for (int j = 0; j < N; ++j) s += go[p * N + j];
+        for (int j = 0; j < N; ++j) gi[p * N + j] = (float)(go[p * N + j] - exp((double)out[p * N + j]) * s);
+    }
+}
+void orc_softmax_backward(const float *out, const float *go, int64_t P, int N, float *gi) {
+    for (int64_t p = 0; p < P; ++p) {
+        double s = 0;
+        for (int j = 0; j < N; ++j) s += (double)go[p * N + j] * out[p * N + j];
+        for (int j = 0; j < N; ++j) gi[p * N + j] = (float)(out[p * N + j] * (go[p * N + j] - s));
+    }
+}
+
 /* N2: gradients of A1 / A1r w.r.t. both feature maps (un-vendored nnx; nothing in the reference tests them -- pinned as
  * the Jacobian of orc_spatial_matching / orc_radial_matching, the way tests/test_cascad.lua:22 pins the cascade).
  * g1[k][y][x]  = sum_{dy,dx}  2 (in1[k][y][x] - in2[k][y+dy][x+dx]) go[y][x][dy][dx]

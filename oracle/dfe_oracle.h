@@ -53,6 +53,14 @@ void orc_spatial_convolution(const float *in, const float *weight, const float *
 void orc_spatial_convolution_map(const float *in, const float *weight, const float *bias, const int *conn, int nConn,
                                  int nIn, int nOut, int H, int W, int kH, int kW, float *out);
 void orc_tanh(const float *in, int64_t n, float *out);
+void orc_spatial_convolution_grad_input(const float *go, const float *weight, const int *conn, int nConn, int nIn, int nOut,
+                                        int H, int W, int kH, int kW, float *gi);
+void orc_spatial_convolution_acc_grad(const float *in, const float *go, const int *conn, int nConn, int nIn, int nOut, int H,
+                                      int W, int kH, int kW, float scale, float *gw, float *gb);
+void orc_tanh_backward(const float *out, const float *go, int64_t n, float *gi);
+void orc_log_softmax(const float *in, int64_t P, int N, float *out);
+void orc_log_softmax_backward(const float *out, const float *go, int64_t P, int N, float *gi);
+void orc_softmax_backward(const float *out, const float *go, int64_t P, int N, float *gi);
 
 /* N2: gradients of A1 and A1r w.r.t. in1 and in2 (go = gradOutput, layout of the forward output). Pinned as the Jacobian
  * of the forward restatements (no reference test exists; method of tests/test_cascad.lua:22). */

@@ -52,6 +52,12 @@ def lib():
             "orc_spatial_convolution": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_spatial_convolution_map": (None, [f32p, f32p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_tanh": (None, [f32p, C.c_int64, f32p]),
+            "orc_spatial_convolution_grad_input": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [f32p]),
+            "orc_spatial_convolution_acc_grad": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, f32p, C.c_void_p]),
+            "orc_tanh_backward": (None, [f32p, f32p, C.c_int64, f32p]),
+            "orc_log_softmax": (None, [f32p, C.c_int64, C.c_int, f32p]),
+            "orc_log_softmax_backward": (None, [f32p, f32p, C.c_int64, C.c_int, f32p]),
+            "orc_softmax_backward": (None, [f32p, f32p, C.c_int64, C.c_int, f32p]),
             "orc_spatial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
             "orc_radial_matching_backward": (None, [f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p, f32p]),
             "orc_cascading_add_backward": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -255,6 +261,54 @@ def tanh(inp):
     out = np.empty_like(inp)
     lib().orc_tanh(inp.reshape(-1), inp.size, out.reshape(-1))
     return out
+
+
+def spatial_convolution_backward(inp, weight, go, conn=None, nOut=None, scale=1.0, with_bias=True):
+    """(gradInput, gradWeight, gradBias) of nn.SpatialConvolution (conn None, weight nOut x nIn x kH x kW) or
+    nn.SpatialConvolutionMap (weight nConn x kH x kW, conn nConn x 2 (from, to) 1-based), gradients accumulated from zero."""
+    inp, weight, go = _f(inp), _f(weight), _f(go)
+    nIn, H, W = inp.shape
+    if conn is None:
+        nOut, _, kH, kW = weight.shape
+        cp, nConn = None, 0
+    else:
+        nConn, kH, kW = weight.shape
+        conn = np.ascontiguousarray(conn, np.int32)
+        cp = conn.ctypes.data
+    gi = np.empty_like(inp)
+    gw = np.zeros_like(weight)
+    gb = np.zeros(nOut, np.float32)
+    lib().orc_spatial_convolution_grad_input(go, weight, cp, nConn, nIn, nOut, H, W, kH, kW, gi)
+    lib().orc_spatial_convolution_acc_grad(inp, go, cp, nConn, nIn, nOut, H, W, kH, kW, scale, gw, gb.ctypes.data if with_bias else None)
+    return gi, gw, gb
+
+
+def tanh_backward(out, go):
+    out, go = _f(out), _f(go)
+    gi = np.empty_like(out)
+    lib().orc_tanh_backward(out.reshape(-1), go.reshape(-1), out.size, gi.reshape(-1))
+    return gi
+
+
+def log_softmax(x):
+    x = _f(x)
+    out = np.empty_like(x)
+    lib().orc_log_softmax(x.reshape(-1), x.size // x.shape[-1], x.shape[-1], out.reshape(-1))
+    return out
+
+
+def log_softmax_backward(out, go):
+    out, go = _f(out), _f(go)
+    gi = np.empty_like(out)
+    lib().orc_log_softmax_backward(out.reshape(-1), go.reshape(-1), out.size // out.shape[-1], out.shape[-1], gi.reshape(-1))
+    return gi
+
+
+def softmax_backward(out, go):
+    out, go = _f(out), _f(go)
+    gi = np.empty_like(out)
+    lib().orc_softmax_backward(out.reshape(-1), go.reshape(-1), out.size // out.shape[-1], out.shape[-1], gi.reshape(-1))
+    return gi
 
 
 def spatial_matching_backward(in1, in2, go, maxh, maxw):

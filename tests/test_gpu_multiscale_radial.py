@@ -619,3 +619,134 @@ def test_radial_match_argmin_equals_matching_then_min(dfe, cuda):
         assert torch.equal(staged, vol)
     with pytest.raises(dfe.DfeError):
         ctx.check(dfe.lib().dfe_radial_match_argmin_f32(ctx.handle, vol.data_ptr(), 0, vol.data_ptr(), 1, 4, 4, 5, None, flow.data_ptr(), 0))
+
+
+# ------------------------------------------------------------------ next-row N2: backward through the filter stack
+@pytest.mark.parametrize("kH,kW,use_map", [(3, 3, False), (1, 17, False), (17, 1, False), (3, 2, True)])
+def test_convolution_backward_equals_oracle(dfe, cuda, kH, kW, use_map):
+    """nn.SpatialConvolution(Map):updateGradInput bit-exact against the oracle (same term order), accGradParameters within
+    1e-5 relative (block reduction against the oracle's sequential sum), accumulating and scaled like Torch7's."""
+    rng = np.random.default_rng(kH + kW)
+    nIn, nOut, H, W = 3, 5, 24, 40
+    x = rng.standard_normal((nIn, H, W)).astype(np.float32)
+    if use_map:
+        conn = dfe.tables_random(nIn, nOut, 2, generator=torch.Generator().manual_seed(1))
+        m = dfe.network.SpatialConvolutionMap(conn, kW, kH, device=cuda, generator=torch.Generator().manual_seed(2))
+        cnp = conn.numpy()
+    else:
+        m = dfe.network.SpatialConvolution(nIn, nOut, kW, kH, device=cuda, generator=torch.Generator().manual_seed(2))
+        cnp = None
+    out = m.forward(T(x, cuda))
+    go = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    egi, egw, egb = orc.spatial_convolution_backward(x, m.weight.cpu().numpy(), go, conn=cnp, nOut=nOut)
+    m.zeroGradParameters()
+    gi = m.backward(T(x, cuda), T(go, cuda))
+    assert np.array_equal(gi.cpu().numpy(), egi)
+    assert np.allclose(m.gradWeight.cpu().numpy(), egw, rtol=1e-5, atol=1e-5 * np.abs(egw).max())
+    assert np.allclose(m.gradBias.cpu().numpy(), egb, rtol=1e-5, atol=1e-5 * np.abs(egb).max())
+    m.backward(T(x, cuda), T(go, cuda), 0.5)                     # accumulates scale * grad on top
+    assert np.allclose(m.gradWeight.cpu().numpy(), 1.5 * egw, rtol=2e-5, atol=2e-5 * np.abs(egw).max())
+    with pytest.raises(ValueError):
+        m.updateGradInput(T(x, cuda), T(go[:, :-1], cuda))
+
+
+def test_elementwise_backward_equals_oracle(dfe, cuda):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((6, 15)).astype(np.float32)
+    go = rng.standard_normal((6, 15)).astype(np.float32)
+    t = dfe.network.Tanh()
+    out = t.forward(T(x, cuda))
+    assert np.allclose(t.backward(T(x, cuda), T(go, cuda)).cpu().numpy(), orc.tanh_backward(out.cpu().numpy(), go), rtol=1e-6, atol=1e-7)
+    ls = dfe.radial.LogSoftMaxRows()
+    out = ls.forward(T(x, cuda))
+    ref = orc.log_softmax(-x)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert np.allclose(ls.backward(T(x, cuda), T(go, cuda)).cpu().numpy(), -orc.log_softmax_backward(ref, go), rtol=1e-5, atol=1e-6)
+    lg = dfe.Log2(1e-10)
+    p = np.abs(x) * (np.abs(x) > 0.3)                            # zeros: clamped in place to eps (Log.lua:15-18)
+    tp = T(p, cuda)
+    out = lg.forward(tp)
+    pc = np.maximum(p, np.float32(1e-10))
+    assert np.array_equal(tp.cpu().numpy(), pc) and np.allclose(out.cpu().numpy(), np.log(pc), rtol=1e-6, atol=1e-6)
+    assert np.allclose(lg.backward(tp, T(go, cuda)).cpu().numpy(), go / pc, rtol=1e-6)
+    sr = dfe.SmartReshape([-1, -2], -3)
+    v = torch.randn((2, 3, 4), device=cuda)
+    o = sr.forward(v)
+    assert tuple(o.shape) == (6, 4) and tuple(sr.backward(v, torch.ones_like(o)).shape) == (2, 3, 4)
+
+
+def test_radial_trainer_network_backward_reaches_the_weights(dfe, cuda):
+    """radial/train_radial_opticalflow.lua:228-252 on the drop-in: output = network:forward{patch_prev, patch};
+    err = ClassNLL(output, target + 1); network:backward(input, df_do) -> gradients in the SHARED filter weights of both
+    branches.  Checked against central differences of the loss on a handful of weights (fp32 forward: 3e-2 relative) and by
+    an SGD step lowering the loss."""
+    networkp = dict(hImg=180, wImg=320, hInput=40, wInput=24, hWin=15, layers=[[3, 1, 17, 5], "tanh", [5, 17, 1, 10]])
+    net = dfe.getTrainerNetwork(networkp, device=cuda, generator=torch.Generator().manual_seed(3))
+    rng = np.random.default_rng(0)
+    hK, wK = 17, 17
+    # a training patch: prev hKernel+hWin-1 rows? the trainer feeds patches whose matcher output is 1 x 1 x hWin
+    prev = rng.random((3, hK + 15 - 1, wK)).astype(np.float32)
+    cur = rng.random((3, hK + 15 - 1, wK)).astype(np.float32)
+    cur[:, 4:, :] = prev[:, :-4, :]                              # the content moved 4 rows outward
+    target = 4
+    tp, tc = T(prev, cuda), T(cur, cuda)
+
+    def loss():
+        out = net.forward([tp, tc])
+        assert tuple(out.shape) == (1, 1, 15)
+        return float(-out[0, 0, target])
+
+    l0 = loss()
+    df = torch.zeros((1, 1, 15), device=cuda)
+    df[0, 0, target] = -1.0                                      # ClassNLLCriterion:backward
+    net.zeroGradParameters()
+    net.backward([tp, tc], df)
+    ws, gs = net.parameters()
+    assert len(ws) == 4 and all(float(g.abs().sum()) > 0 for g in gs)      # 2 convolutions x (weight, bias), shared by both branches
+    for w, g in zip(ws, gs):
+        flat, gflat = w.view(-1), g.view(-1)
+        for k in rng.choice(flat.numel(), size=min(4, flat.numel()), replace=False):
+            k = int(k)
+            o = float(flat[k])
+            eps = 2e-2
+            flat[k] = o + eps
+            hi = loss()
+            flat[k] = o - eps
+            lo = loss()
+            flat[k] = o
+            fd = (hi - lo) / (2 * eps)
+            assert abs(fd - float(gflat[k])) <= 3e-2 * max(abs(fd), abs(float(gflat[k]))) + 2e-3, (k, fd, float(gflat[k]))
+    net.updateParameters(2e-2)
+    assert loss() < l0
+
+
+def test_single_scale_model_training_chain_backward(dfe, cuda):
+    """opticalflow.lua:296-338 through getModel in training mode: filters -> SpatialMatching -> Minus -> window soft-max ->
+    Log2(1e-10); model:backward(input, df_do) fills the filter gradients (checked by finite differences on two weights)."""
+    geo = dict(maxh=4, maxw=4, hKernel=3, wKernel=3, layers=[[3, 3, 3, 4]], training_mode=True, output_extraction_method="max")
+    model = dfe.getModel(geo, device=cuda, generator=torch.Generator().manual_seed(1))
+    rng = np.random.default_rng(2)
+    p1 = T(rng.random((3, 3, 3)).astype(np.float32), cuda)       # one patch -> 1 x 1 features
+    p2 = T(rng.random((3, 6, 6)).astype(np.float32), cuda)       # its 4 x 4 search region
+    target = 6
+
+    def loss():
+        out = model.forward([p1, p2])
+        return float(-out.reshape(-1)[target])
+
+    loss()
+    df = torch.zeros_like(model.output)
+    df.view(-1)[target] = -1.0
+    model.zeroGradParameters()
+    model.backward([p1, p2], df)
+    ws, gs = model.parameters()
+    w, g = ws[0].view(-1), gs[0].view(-1)
+    for k in (0, 17):
+        o = float(w[k])
+        w[k] = o + 1e-2
+        hi = loss()
+        w[k] = o - 1e-2
+        lo = loss()
+        w[k] = o
+        fd = (hi - lo) / 2e-2
+        assert abs(fd - float(g[k])) <= 3e-2 * max(abs(fd), abs(float(g[k]))) + 2e-3
