@@ -47,6 +47,10 @@ class SpatialConvolution(Module):
         ctx.check(lib().dfe_spatial_convolution_acc_grad_f32(ctx.handle, ptr(x), ptr(go), nIn, self.nOutputPlane, H, W, self.kH, self.kW, float(scale),
                                                              ptr(self.gradWeight), ptr(self.gradBias)))
 
+    # kernel = "exact": the direct kernel, bit-identical to the CPU loop (separately rounded multiply and add);
+    # kernel = "mfma": implicit GEMM on the matrix cores (fused multiply-adds in the same order: <= 1e-5 relative)
+    kernel = "exact"
+
     def updateOutput(self, input):
         x = _f32c(input, "input")
         nIn, H, W = x.shape
@@ -54,6 +58,11 @@ class SpatialConvolution(Module):
             raise ValueError("SpatialConvolution: expected %d input planes, got %d" % (self.nInputPlane, nIn))
         out = torch.empty((self.nOutputPlane, H - self.kH + 1, W - self.kW + 1), dtype=torch.float32, device=x.device)
         ctx = get_ctx(x)
+        if self.kernel == "mfma":
+            ctx.check(lib().dfe_spatial_convolution_mfma_f32(ctx.handle, ptr(x), ptr(self.weight), ptr(self.bias), nIn, self.nOutputPlane, H, W,
+                                                             self.kH, self.kW, 0, ptr(out)))
+            self.output = out
+            return out
         ctx.check(lib().dfe_spatial_convolution_f32(ctx.handle, ptr(x), ptr(self.weight), ptr(self.bias), nIn, self.nOutputPlane, H, W,
                                                     self.kH, self.kW, ptr(out)))
         self.output = out

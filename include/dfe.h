@@ -362,6 +362,12 @@ int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *
                                     const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW,
                                     float *out);
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
+/* nn.SpatialConvolution [+ nn.Tanh] as an implicit GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32
+ * accumulate, an fmaf chain in the reference's (input plane, ky, kx) order).  Same layouts as dfe_spatial_convolution_f32;
+ * results differ from it by the fusing of each multiply-add only (<= 1e-5 relative to sum |terms|).  kH x kW up to what
+ * fits one block's LDS (17 x 17 does); DFE_E_UNSUPPORTED beyond. */
+int dfe_spatial_convolution_mfma_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut,
+                                     int H, int W, int kH, int kW, int tanh_after, float *out);
 
 /* ---- next-row N2: gradients of the filter stack and of the soft-max / log layers, so that network:backward(input, df_do)
  *      reaches the convolution weights through the drop-in (radial/train_radial_opticalflow.lua:228-252,

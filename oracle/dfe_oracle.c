@@ -92,6 +92,23 @@ void orc_spatial_convolution(const float *in, const float *weight, const float *
                 out[((size_t)o * Ho + y) * Wo + x] = s;
             }
 }
+/* The same convolution with FUSED multiply-adds in the same (i, u, v) order -- what dfe_spatial_convolution_mfma_f32 computes
+ * (v_mfma_f32_16x16x4_f32 is an fmaf chain over k): test infrastructure for that kernel only. */
+void orc_spatial_convolution_fma(const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W,
+                                 int kH, int kW, float *out) {
+    int Ho = H - kH + 1, Wo = W - kW + 1;
+    ORC_PAR_FOR
+    for (int o = 0; o < nOut; ++o)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float s = bias ? bias[o] : 0.f;
+                for (int i = 0; i < nIn; ++i)
+                    for (int u = 0; u < kH; ++u)
+                        for (int v = 0; v < kW; ++v)
+                            s = fmaf(in[((size_t)i * H + y + u) * W + x + v], weight[(((size_t)o * nIn + i) * kH + u) * kW + v], s);
+                out[((size_t)o * Ho + y) * Wo + x] = s;
+            }
+}
 /* nn.SpatialConvolutionMap(connTable, kW, kH): connection c = (from, to) 1-based, one kH x kW kernel per connection,
  * accumulated into out[to] in table order. ref: opticalflow_model.lua:56-59 (nn.tables.random fan-in tables) */
 void orc_spatial_convolution_map(const float *in, const float *weight, const float *bias, const int *conn, int nConn,

@@ -51,6 +51,7 @@ def lib():
             "orc_cascading_add": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, i32p, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
             "orc_spatial_convolution": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_spatial_convolution_map": (None, [f32p, f32p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+            "orc_spatial_convolution_fma": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_tanh": (None, [f32p, C.c_int64, f32p]),
             "orc_spatial_convolution_grad_input": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [f32p]),
             "orc_spatial_convolution_acc_grad": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, f32p, C.c_void_p]),
@@ -242,6 +243,16 @@ def spatial_convolution(inp, weight, bias):
     out = np.empty((nOut, H - kH + 1, W - kW + 1), np.float32)
     b = _f(bias) if bias is not None else None
     lib().orc_spatial_convolution(inp, weight, b.ctypes.data if b is not None else None, nIn, nOut, H, W, kH, kW, out)
+    return out
+
+
+def spatial_convolution_fma(inp, weight, bias):
+    inp, weight = _f(inp), _f(weight)
+    nOut, nIn, kH, kW = weight.shape
+    _, H, W = inp.shape
+    out = np.empty((nOut, H - kH + 1, W - kW + 1), np.float32)
+    b = _f(bias) if bias is not None else None
+    lib().orc_spatial_convolution_fma(inp, weight, b.ctypes.data if b is not None else None, nIn, nOut, H, W, kH, kW, out)
     return out
 
 

@@ -750,3 +750,31 @@ def test_single_scale_model_training_chain_backward(dfe, cuda):
         w[k] = o
         fd = (hi - lo) / 2e-2
         assert abs(fd - float(g[k])) <= 3e-2 * max(abs(fd), abs(float(g[k]))) + 2e-3
+
+
+# ------------------------------------------------------------------ next-row N1: implicit-GEMM convolution on the matrix cores
+@pytest.mark.parametrize("nIn,nOut,kH,kW,H,W", [(3, 4, 5, 5, 60, 90), (4, 4, 5, 5, 37, 101), (4, 10, 5, 5, 64, 64), (3, 32, 17, 17, 48, 150),
+                                              (3, 5, 1, 17, 40, 100), (5, 10, 17, 1, 40, 70), (2, 17, 3, 2, 9, 20)])
+def test_convolution_mfma_equals_fma_oracle(dfe, cuda, nIn, nOut, kH, kW, H, W):
+    """dfe_spatial_convolution_mfma_f32 (v_mfma_f32_16x16x4_f32 implicit GEMM): bit-exact against the oracle's fmaf chain in
+    (input plane, ky, kx) order, and within 1e-5 * sum|terms| of nn.SpatialConvolution's separately rounded loop; the layer
+    shapes of tests/time_matching.lua:13, version2/network.lua (17 x 17 x 32) and the radial separable stack."""
+    rng = np.random.default_rng(nOut + kH)
+    x = rng.standard_normal((nIn, H, W)).astype(np.float32)
+    w = (rng.standard_normal((nOut, nIn, kH, kW)) / np.sqrt(nIn * kH * kW)).astype(np.float32)
+    b = rng.standard_normal(nOut).astype(np.float32)
+    out = torch.empty((nOut, H - kH + 1, W - kW + 1), device=cuda)
+    ctx = dfe.get_ctx(0)
+    tx, tw, tb = T(x, cuda), T(w, cuda), T(b, cuda)
+    ctx.check(dfe.lib().dfe_spatial_convolution_mfma_f32(ctx.handle, tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), nIn, nOut, H, W, kH, kW, 0, out.data_ptr()))
+    assert ctx.last_kernel() == "conv_mfma_kernel"
+    g = out.cpu().numpy()
+    assert np.array_equal(g, orc.spatial_convolution_fma(x, w, b))
+    ref = orc.spatial_convolution(x, w, b)
+    mag = orc.spatial_convolution(np.abs(x), np.abs(w), np.abs(b))
+    assert (np.abs(g - ref) <= 1e-5 * mag).all()
+    # through the module, without a bias
+    m = dfe.network.SpatialConvolution(nIn, nOut, kW, kH, device=cuda, generator=torch.Generator().manual_seed(0))
+    m.kernel = "mfma"
+    o2 = m.forward(tx)
+    assert np.array_equal(o2.cpu().numpy(), orc.spatial_convolution_fma(x, m.weight.cpu().numpy(), m.bias.cpu().numpy()))
