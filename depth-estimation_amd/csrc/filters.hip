@@ -95,3 +95,100 @@ int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// nn.SpatialContrastiveNormalization(nIn, 1-D kernel, threshold, thresval): version2/network.lua:12 puts it in front of both
+// filter branches (image.gaussian1D(normalization_k)).  = SpatialSubtractiveNormalization then SpatialDivisiveNormalization,
+// each built on one "estimator": zero pad, horizontal pass per plane, vertical pass that also sums the planes, divided by the
+// estimator of a tensor of ones (border correction).  Un-vendored nn, nothing in the reference tests it: restated from recall
+// (oracle/dfe_oracle.c: orc_contrastive_normalization) -- parity unpinned.  Same term order as the oracle: bit-identical.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int CN_MAXK = 33;
+struct CnKernel { float kn[CN_MAXK]; int k; };
+
+// mode 0: src = in; 1: src = (in - est/coef)^2 (the divisive stage's input, recomputed instead of stored)
+template <int MODE>
+__global__ void cn_rows_kernel(const float *__restrict__ in, const float *__restrict__ est, const float *__restrict__ coef, int C, int H, int W,
+                               CnKernel kk, int ones, float *__restrict__ tmp) {
+#pragma clang fp contract(off)
+    const long long n = (long long)C * H * W, P = (long long)H * W;
+    const int pl = kk.k / 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W);
+        const long long row = e - x;
+        const long long p0 = (e % P) - x;
+        float s = 0.f;
+        for (int v = 0; v < kk.k; ++v) {
+            const int xx = x + v - pl;
+            float a = 0.f;
+            if (xx >= 0 && xx < W) {
+                if (ones) a = 1.f;
+                else if (MODE == 0) a = in[row + xx];
+                else { const float y = in[row + xx] - est[p0 + xx] / coef[p0 + xx]; a = y * y; }
+            }
+            s = s + kk.kn[v] * a;
+        }
+        tmp[e] = s;
+    }
+}
+
+__global__ void cn_cols_kernel(const float *__restrict__ tmp, int C, int H, int W, CnKernel kk, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const long long P = (long long)H * W;
+    const int pl = kk.k / 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % W), y = (int)(e / W);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c)
+            for (int u = 0; u < kk.k; ++u) {
+                const int yy = y + u - pl;
+                const float a = (yy >= 0 && yy < H) ? tmp[c * P + (long long)yy * W + x] : 0.f;
+                s = s + kk.kn[u] * a;
+            }
+        out[e] = s;
+    }
+}
+
+__global__ void cn_finish_kernel(const float *__restrict__ in, const float *__restrict__ est, const float *__restrict__ est2,
+                                 const float *__restrict__ coef, int C, long long P, float threshold, float thresval, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < C * P; e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e % P;
+        const float y = in[e] - est[p] / coef[p];
+        float sd = sqrtf(est2[p]) / coef[p];
+        sd = sd > threshold ? sd : thresval;
+        out[e] = y / sd;
+    }
+}
+
+}  // namespace
+
+extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
+                                                 float thresval, float *out) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, in && kernel_host && out, DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
+    DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && k > 0 && k <= CN_MAXK, DFE_E_SHAPE, "dfe_contrastive_normalization_f32: C=%d %dx%d kernel %d (max %d)", C, H,
+                W, k, CN_MAXK);
+    CnKernel kk;
+    kk.k = k;
+    float ks = 0.f;
+    for (int i = 0; i < k; ++i) ks += kernel_host[i];
+    for (int i = 0; i < k; ++i) kk.kn[i] = kernel_host[i] / (ks * (float)C);       // self.kernel:div(self.kernel:sum() * self.nInputPlane)
+    const long long P = (long long)H * W;
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, ((size_t)C * P + 3 * P) * sizeof(float), &scr);
+    if (rc) return rc;
+    float *tmp = (float *)scr, *coef = tmp + C * P, *est = coef + P, *est2 = est + P;
+    const int g1 = grid_n(C * P), g2 = grid_n(P);
+    hipLaunchKernelGGL(cn_rows_kernel<0>, dim3(g1), dim3(256), 0, ctx->stream, in, (const float *)nullptr, (const float *)nullptr, C, H, W, kk, 1, tmp);
+    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, coef);
+    hipLaunchKernelGGL(cn_rows_kernel<0>, dim3(g1), dim3(256), 0, ctx->stream, in, (const float *)nullptr, (const float *)nullptr, C, H, W, kk, 0, tmp);
+    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, est);
+    hipLaunchKernelGGL(cn_rows_kernel<1>, dim3(g1), dim3(256), 0, ctx->stream, in, est, coef, C, H, W, kk, 0, tmp);
+    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, est2);
+    hipLaunchKernelGGL(cn_finish_kernel, dim3(g1), dim3(256), 0, ctx->stream, in, est, est2, coef, C, P, threshold, thresval, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}

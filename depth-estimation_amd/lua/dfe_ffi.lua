@@ -65,6 +65,7 @@ int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int ma
 int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
 int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
+int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold, float thresval, float *out);
 int dfe_spatial_convolution_mfma_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, int tanh_after, float *out);
 int dfe_spatial_convolution_grad_input_f32(dfe_ctx *ctx, const float *gradOut, const float *weight, int nIn, int nOut, int H, int W, int kH, int kW, float *gradIn);
 int dfe_spatial_convolution_acc_grad_f32(dfe_ctx *ctx, const float *in, const float *gradOut, int nIn, int nOut, int H, int W, int kH, int kW, float scale, float *gradWeight, float *gradBias);

@@ -152,6 +152,42 @@ class Tanh(Module):
         return gi
 
 
+def gaussian1D(size, sigma=0.25, amplitude=1.0, normalize=False):
+    """image.gaussian1D (un-vendored `image`; as recalled): amplitude * exp(-((i - center) / (sigma * size))^2 / 2), 1-based i,
+    center = size / 2 + 0.5."""
+    i = torch.arange(1, size + 1, dtype=torch.float64)
+    g = amplitude * torch.exp(-(((i - (size / 2 + 0.5)) / (sigma * size)) ** 2) / 2)
+    if normalize:
+        g = g / g.sum()
+    return g.to(torch.float32)
+
+
+class SpatialContrastiveNormalization(Module):
+    """nn.SpatialContrastiveNormalization(nInputPlane, kernel, threshold, thresval) with a 1-D kernel -- the front end of both
+    filter branches in version2/network.lua:12,22."""
+
+    def __init__(self, nInputPlane=1, kernel=None, threshold=1e-4, thresval=1e-4):
+        super().__init__()
+        self.nInputPlane = int(nInputPlane)
+        self.kernel = (torch.ones(9) if kernel is None else kernel).to(torch.float32).cpu().contiguous()
+        if self.kernel.dim() != 1:
+            raise NotImplementedError("SpatialContrastiveNormalization: the reference uses a 1-D kernel (image.gaussian1D)")
+        self.threshold, self.thresval = float(threshold), float(thresval)
+
+    def updateOutput(self, input):
+        x = _f32c(input, "input")
+        Cc, H, W = x.shape
+        if Cc != self.nInputPlane:
+            raise ValueError("SpatialContrastiveNormalization: expected %d planes, got %d" % (self.nInputPlane, Cc))
+        out = torch.empty_like(x)
+        ctx = get_ctx(x)
+        import ctypes
+        kp = self.kernel.numpy().ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        ctx.check(lib().dfe_contrastive_normalization_f32(ctx.handle, ptr(x), Cc, H, W, kp, self.kernel.numel(), self.threshold, self.thresval, ptr(out)))
+        self.output = out
+        return out
+
+
 class Sequential(Module):
     def __init__(self):
         super().__init__()

@@ -362,6 +362,12 @@ int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *
                                     const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW,
                                     float *out);
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
+/* nn.SpatialContrastiveNormalization(nIn, kernel1d, threshold, thresval) (version2/network.lua:12, in front of both filter
+ * branches): subtractive then divisive local normalisation with a separable 1-D kernel (k <= 33 taps, HOST pointer),
+ * border-corrected by the estimator of a ones tensor.  Un-vendored nn, restated from recall: parity unpinned.
+ * in / out [C][H][W]. */
+int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k,
+                                      float threshold, float thresval, float *out);
 /* nn.SpatialConvolution [+ nn.Tanh] as an implicit GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32
  * accumulate, an fmaf chain in the reference's (input plane, ky, kx) order).  Same layouts as dfe_spatial_convolution_f32;
  * results differ from it by the fusing of each multiply-add only (<= 1e-5 relative to sum |terms|).  kH x kW up to what

@@ -134,6 +134,70 @@ void orc_tanh(const float *in, int64_t n, float *out) { /* nn.Tanh: tanhf */
     for (int64_t i = 0; i < n; ++i) out[i] = tanhf(in[i]);
 }
 
+/* nn.SpatialContrastiveNormalization(nIn, kernel1d, threshold, thresval) = SpatialSubtractiveNormalization followed by
+ * SpatialDivisiveNormalization with a 1-D kernel (version2/network.lua:12: image.gaussian1D(normalization_k)).
+ * [3P-recall: nn is un-vendored and nothing in the reference tests this module -- parity unpinned.]  As recalled from Torch7:
+ *   kn = kernel / (sum(kernel) * nIn); estimator(x) = zero-pad by floor(k/2) (ceil-1 on the far side for even k), a horizontal
+ *   pass per plane (SpatialConvolutionMap one-to-one, taps in order), a vertical pass that also sums the planes
+ *   (SpatialConvolution nIn -> 1: planes, then taps); coef = estimator(ones): the border correction.
+ *   subtractive: y = x - estimator(x) / coef (the one-plane mean replicated over the planes)
+ *   divisive:    s = sqrt(estimator(y^2)) / coef; s = s > threshold ? s : thresval; out = y / s                        */
+static void cn_estimator(const float *in, int C, int H, int W, const float *kn, int k, float *tmp, float *out) {
+    int pl = k / 2, pr = k - 1 - pl; /* SpatialZeroPadding(floor(k/2), ceil(k/2)-1 ...) so that the output keeps H x W */
+    (void)pr;
+    ORC_PAR_FOR
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                float s = 0.f;
+                for (int v = 0; v < k; ++v) {
+                    int xx = x + v - pl;
+                    float a = (xx >= 0 && xx < W) ? in[((size_t)c * H + y) * W + xx] : 0.f;
+                    s += kn[v] * a;
+                }
+                tmp[((size_t)c * H + y) * W + x] = s;
+            }
+    ORC_PAR_FOR
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float s = 0.f;
+            for (int c = 0; c < C; ++c)
+                for (int u = 0; u < k; ++u) {
+                    int yy = y + u - pl;
+                    float a = (yy >= 0 && yy < H) ? tmp[((size_t)c * H + yy) * W + x] : 0.f;
+                    s += kn[u] * a;
+                }
+            out[(size_t)y * W + x] = s;
+        }
+}
+void orc_contrastive_normalization(const float *in, int C, int H, int W, const float *kernel, int k, float threshold,
+                                   float thresval, float *out) {
+    size_t P = (size_t)H * W;
+    float *kn = (float *)malloc(sizeof(float) * k), *tmp = (float *)malloc(sizeof(float) * C * P);
+    float *ones = (float *)malloc(sizeof(float) * C * P), *coef = (float *)malloc(sizeof(float) * P);
+    float *est = (float *)malloc(sizeof(float) * P), *y = (float *)malloc(sizeof(float) * C * P), *sq = (float *)malloc(sizeof(float) * C * P);
+    float ks = 0.f;
+    for (int i = 0; i < k; ++i) ks += kernel[i];
+    for (int i = 0; i < k; ++i) kn[i] = kernel[i] / (ks * (float)C);
+    for (size_t i = 0; i < (size_t)C * P; ++i) ones[i] = 1.f;
+    cn_estimator(ones, C, H, W, kn, k, tmp, coef);
+    cn_estimator(in, C, H, W, kn, k, tmp, est);
+    for (int c = 0; c < C; ++c)
+        for (size_t p = 0; p < P; ++p) {
+            float v = in[c * P + p] - est[p] / coef[p];
+            y[c * P + p] = v;
+            sq[c * P + p] = v * v;
+        }
+    cn_estimator(sq, C, H, W, kn, k, tmp, est);
+    for (size_t p = 0; p < P; ++p) {
+        float sd = sqrtf(est[p]) / coef[p];
+        est[p] = sd > threshold ? sd : thresval;
+    }
+    for (int c = 0; c < C; ++c)
+        for (size_t p = 0; p < P; ++p) out[c * P + p] = y[c * P + p] / est[p];
+    free(kn); free(tmp); free(ones); free(coef); free(est); free(y); free(sq);
+}
+
 /* N2: gradients of the filter stack (un-vendored nn; pinned as the Jacobian of the forward above, the way
  * tests/test_cascad.lua:21-25 pins the cascade).  conn == NULL: dense nn.SpatialConvolution, weight [nOut][nIn][kH][kW];
  * else nn.SpatialConvolutionMap, weight [nConn][kH][kW], conn (from, to) 1-based.

@@ -52,6 +52,7 @@ def lib():
             "orc_spatial_convolution": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_spatial_convolution_map": (None, [f32p, f32p, C.c_void_p, i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_spatial_convolution_fma": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
+            "orc_contrastive_normalization": (None, [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, f32p]),
             "orc_tanh": (None, [f32p, C.c_int64, f32p]),
             "orc_spatial_convolution_grad_input": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [f32p]),
             "orc_spatial_convolution_acc_grad": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, f32p, C.c_void_p]),
@@ -264,6 +265,23 @@ def spatial_convolution_map(inp, weight, bias, conn, nOut):
     out = np.empty((nOut, H - kH + 1, W - kW + 1), np.float32)
     b = _f(bias) if bias is not None else None
     lib().orc_spatial_convolution_map(inp, weight, b.ctypes.data if b is not None else None, conn.reshape(-1), nConn, nIn, nOut, H, W, kH, kW, out)
+    return out
+
+
+def gaussian1D(size, sigma=0.25, amplitude=1.0, normalize=False):
+    """image.gaussian1D [3P-recall]: g[i] = amplitude * exp(-((i - center) / (sigma * size))^2 / 2), i = 1..size, center = size / 2 + 0.5"""
+    i = np.arange(1, size + 1, dtype=np.float64)
+    g = amplitude * np.exp(-(((i - (size / 2 + 0.5)) / (sigma * size)) ** 2) / 2)
+    if normalize:
+        g = g / g.sum()
+    return g.astype(np.float32)
+
+
+def contrastive_normalization(inp, kernel, threshold=1e-4, thresval=1e-4):
+    inp, kernel = _f(inp), _f(kernel)
+    Cc, H, W = inp.shape
+    out = np.empty_like(inp)
+    lib().orc_contrastive_normalization(inp, Cc, H, W, kernel, kernel.size, threshold, thresval, out)
     return out
 
 

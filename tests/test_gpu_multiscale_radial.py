@@ -778,3 +778,20 @@ def test_convolution_mfma_equals_fma_oracle(dfe, cuda, nIn, nOut, kH, kW, H, W):
     m.kernel = "mfma"
     o2 = m.forward(tx)
     assert np.array_equal(o2.cpu().numpy(), orc.spatial_convolution_fma(x, m.weight.cpu().numpy(), m.bias.cpu().numpy()))
+
+
+def test_contrastive_normalization_equals_oracle(dfe, cuda):
+    """nn.SpatialContrastiveNormalization(3, image.gaussian1D(k)) (version2/network.lua:12): bit-identical to the oracle's
+    restatement (same term order), zero local mean / unit local deviation where the kernel fits, borders corrected."""
+    rng = np.random.default_rng(4)
+    for k, H, W in ((7, 40, 56), (9, 33, 31), (4, 20, 24)):
+        x = (rng.random((3, H, W)) * 3 + 1).astype(np.float32)
+        g = orc.gaussian1D(k)
+        assert np.array_equal(dfe.network.gaussian1D(k).numpy(), g)
+        m = dfe.network.SpatialContrastiveNormalization(3, torch.from_numpy(g))
+        out = m.forward(T(x, cuda)).cpu().numpy()
+        ref = orc.contrastive_normalization(x, g)
+        assert np.array_equal(out, ref)
+        assert abs(float(out.mean())) < 0.05 and 0.5 < float(out.std()) < 1.5
+    flat = np.full((3, 16, 16), 2.0, np.float32)                      # constant input: zero after the subtraction, divided by thresval
+    assert float(np.abs(dfe.network.SpatialContrastiveNormalization(3, torch.from_numpy(orc.gaussian1D(5))).forward(T(flat, cuda)).cpu().numpy()).max()) < 1e-2
