@@ -101,7 +101,7 @@ int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out) {
 // filter branches (image.gaussian1D(normalization_k)).  = SpatialSubtractiveNormalization then SpatialDivisiveNormalization,
 // each built on one "estimator": zero pad, horizontal pass per plane, vertical pass that also sums the planes, divided by the
 // estimator of a tensor of ones (border correction).  Un-vendored nn, nothing in the reference tests it: restated from recall
-// (oracle/dfe_oracle.c: orc_contrastive_normalization) -- parity unpinned.  Same term order as the oracle: bit-identical.
+// (the CPU restatement states the same recall) -- parity unpinned.  Same term order as that restatement: bit-identical.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 
