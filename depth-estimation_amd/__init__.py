@@ -19,7 +19,7 @@ no CPU fallback -- a missing library or device raises.
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
 from . import nn  # noqa: F401
-from . import network, radial, glue  # noqa: F401
+from . import network, radial, glue, sfm2  # noqa: F401
 from . import extractoutput  # noqa: F401
 from .opticalflow_model import (  # noqa: F401
     x2yx,

@@ -99,6 +99,10 @@ PROTOTYPES = {
     "dfe_postprocess_image_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "dfe_enlarge_mask_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 4),
     "dfe_output_extractor_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_epipole": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),
+    "dfe_remove_ego_motion_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_undistort_image_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "dfe_foe_from_flow_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dfe_radial_match_argmin_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int]),
     "dfe_radial_out_shape": (C.c_int, [C.c_void_p, c_i32p, c_i32p, c_i32p]),
     "dfe_radial_flow_depth_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 9),

@@ -78,6 +78,10 @@ int dfe_log_softmax_f32(dfe_ctx *ctx, const float *in, int64_t P, int N, float *
 int dfe_log_softmax_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOut, int64_t P, int N, float *gradIn);
 int dfe_softmax_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOut, int64_t P, int N, float *gradIn);
 int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out);
+int dfe_epipole(const double *K9, const double *T3, double scale, double *e2_xy);
+int dfe_remove_ego_motion_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *R9, int inverse, float *out, float *mask);
+int dfe_undistort_image_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *dist5, float *out);
+int dfe_foe_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W, float min_flow, int iterations, double *foe_xy, double *n_used);
 ]]
 
 local M = {}

@@ -412,6 +412,25 @@ int dfe_softmax_backward_f32(dfe_ctx *ctx, const float *out, const float *gradOu
  *   in [P][A][B] -> out [P][A], double accumulator as in TH. */
 int dfe_marginal_sum_f32(dfe_ctx *ctx, const float *in, int64_t P, int A, int B, float *out);
 
+/* ---- next-row N4: ego-motion rectification and the epipole / focus of expansion, the step in front of the polar warp
+ *      (radial/radial_opticalflow_data.lua:211-231, depth_estimation_api.lua:139-147).  The reference calls the
+ *      un-vendored, OpenCV-backed `sfm2`; restated from the calling convention -- parity unpinned. ---------------- */
+/* e2 = K T / (K T)_3 * scale (data.lua:218-220: scale = networkp.wImg / calibrationp.wImg).  K row-major 3 x 3, T 3, host. */
+int dfe_epipole(const double *K9, const double *T3, double scale, double *e2_xy);
+/* sfm2.removeEgoMotion(img, K, R, 'bilinear') -> warped, mask: out(p) = bilinear(img, K R K^-1 p) (inverse != 0: R^T),
+ * mask(p) = 1 where the source lies inside the frame, else 0 (and out = 0).  img / out [C][H][W], mask [H][W] or NULL;
+ * K, R row-major host doubles. */
+int dfe_remove_ego_motion_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *R9,
+                              int inverse, float *out, float *mask);
+/* sfm2.undistortImage(img, K, distP): inverse-map undistortion with the (k1, k2, p1, p2, k3) model of the .cal files. */
+int dfe_undistort_image_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *dist5,
+                            float *out);
+/* Focus of expansion of a dense flow field (flow_y, flow_x [H][W]; conf [H][W] or NULL: pixels with conf <= 0 or
+ * |flow| < min_flow are skipped): least-squares intersection of the flow lines, `iterations` Huber re-weightings (0..16).
+ * foe_xy = (x, y) in pixels (host); n_used (may be NULL) = sum of the weights.  DFE_E_ARG when the lines are parallel. */
+int dfe_foe_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W,
+                          float min_flow, int iterations, double *foe_xy, double *n_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,7 @@ exact in fp32); cascade adds are bit-exact given equal inputs; softmin within 1e
 oracle's exact-expf softmax (SOFT_ATOL); polar grids / warp / depth within 1 ulp-ish float tolerance
 (device libm vs glibc), stated per test."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -795,3 +796,90 @@ def test_contrastive_normalization_equals_oracle(dfe, cuda):
         assert abs(float(out.mean())) < 0.05 and 0.5 < float(out.std()) < 1.5
     flat = np.full((3, 16, 16), 2.0, np.float32)                      # constant input: zero after the subtraction, divided by thresval
     assert float(np.abs(dfe.network.SpatialContrastiveNormalization(3, torch.from_numpy(orc.gaussian1D(5))).forward(T(flat, cuda)).cpu().numpy()).max()) < 1e-2
+
+
+# ------------------------------------------------------------------ next-row N4: ego-motion rectification, epipole, FOE
+def _np_bilinear(img, sy, sx):
+    H, W = img.shape[1:]
+    sy, sx = np.clip(sy, 0, H - 1).astype(np.float32), np.clip(sx, 0, W - 1).astype(np.float32)
+    y0, x0 = np.floor(sy).astype(int), np.floor(sx).astype(int)
+    y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+    wy, wx = (sy - y0).astype(np.float32), (sx - x0).astype(np.float32)
+    top = (1 - wx) * img[:, y0, x0] + wx * img[:, y0, x1]
+    bot = (1 - wx) * img[:, y1, x0] + wx * img[:, y1, x1]
+    return (1 - wy) * top + wy * bot
+
+
+def test_remove_ego_motion_and_undistort(dfe, cuda):
+    """sfm2.removeEgoMotion / undistortImage restated: against a numpy evaluation of the same maps, and by the property that a
+    rotation homography followed by its inverse returns the frame wherever the mask says the pixel survived."""
+    rng = np.random.default_rng(0)
+    H, W = 90, 120
+    img = rng.random((3, H, W)).astype(np.float32)
+    cal = dfe.load_calibration(os.path.join(os.path.dirname(__file__), "golden", "cal", "radial_ardrone.cal"))
+    K = cal["K"].astype(np.float64).copy()
+    K[0] *= W / cal["wImg"]
+    K[1] *= H / cal["hImg"]                                                # Ksmall (test_radial_opticalflow.lua:73-75)
+    a, b = 0.02, -0.015                                                    # small rotation about y then x
+    Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    R = Rx @ Ry
+    warped, mask = dfe.sfm2.removeEgoMotion(T(img, cuda), K, R)
+    Hm = (K @ R @ np.linalg.inv(K)).astype(np.float32)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    X = Hm[0, 0] * xs + Hm[0, 1] * ys + Hm[0, 2]
+    Y = Hm[1, 0] * xs + Hm[1, 1] * ys + Hm[1, 2]
+    Z = Hm[2, 0] * xs + Hm[2, 1] * ys + Hm[2, 2]
+    sx, sy = X / Z, Y / Z
+    inside = (sx >= 0) & (sx <= W - 1) & (sy >= 0) & (sy <= H - 1)
+    ref = np.where(inside, _np_bilinear(img, sy, sx), 0)
+    assert np.array_equal(mask.cpu().numpy(), inside.astype(np.float32))
+    assert np.abs(warped.cpu().numpy() - ref).max() < 2e-4
+    smooth = np.stack([np.sin(xs / 9) + np.cos(ys / 7)] * 3).astype(np.float32)
+    w2, _ = dfe.sfm2.removeEgoMotion(T(smooth, cuda), K, R)
+    b2, m2 = dfe.sfm2.removeEgoMotion(w2, K, R, inverse=True)
+    ok = (m2.cpu().numpy() > 0)[6:-6, 6:-6]
+    assert np.abs(b2.cpu().numpy()[:, 6:-6, 6:-6] - smooth[:, 6:-6, 6:-6])[:, ok].max() < 2e-2   # two bilinear resamplings of a curved surface
+    # undistortion: zero coefficients = identity; the ardrone coefficients move border pixels inwards
+    ident = dfe.sfm2.undistortImage(T(smooth, cuda), K, np.zeros(5))
+    assert np.abs(ident.cpu().numpy() - smooth).max() < 1e-5
+    und = dfe.sfm2.undistortImage(T(smooth, cuda), K, cal["distortion"])
+    k1, k2, p1, p2, k3 = [float(v) for v in cal["distortion"]]
+    xn, yn = (xs - K[0, 2]) / K[0, 0], (ys - K[1, 2]) / K[1, 1]
+    r2 = xn * xn + yn * yn
+    rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+    sx = (xn * rad + 2 * p1 * xn * yn + p2 * (r2 + 2 * xn * xn)) * K[0, 0] + K[0, 2]
+    sy = (yn * rad + p1 * (r2 + 2 * yn * yn) + 2 * p2 * xn * yn) * K[1, 1] + K[1, 2]
+    inside = (sx >= 0) & (sx <= W - 1) & (sy >= 0) & (sy <= H - 1)
+    ref = np.where(inside, _np_bilinear(smooth, sy, sx), 0)
+    assert np.abs(und.cpu().numpy() - ref).max() < 2e-3
+
+
+def test_epipole_and_foe_from_dense_flow(dfe, cuda):
+    """e2 = K T / (K T)_3 (data.lua:218-220); and the dense-flow FOE: planted radial expansion (the bench's synthetic pairs)
+    through the matcher -> FOE within half a pixel of the planted one, with and without outliers."""
+    K = np.array([[600.0, 0, 640.0], [0, 600.0, 345.0], [0, 0, 1]])
+    ex, ey = dfe.sfm2.getEpipole(K, [0.1, -0.05, 1.0], scale=0.25)
+    assert abs(ex - (600 * 0.1 + 640) * 0.25) < 1e-12 and abs(ey - (600 * -0.05 + 345) * 0.25) < 1e-12
+    with pytest.raises(ValueError):
+        dfe.sfm2.getEpipole(K, [1.0, 0.0, 0.0])
+    H, W = 240, 320
+    f0, f1, flow, (cx, cy) = rp.synth_pair(H, W, C=3, seed=1, max_flow=10, noise_sigma=0)
+    (fx, fy), n = dfe.sfm2.getFOEFromFlow(T(flow.astype(np.float32), cuda), None, min_flow=1.0, iterations=0)
+    assert abs(fx - cx) < 0.6 and abs(fy - cy) < 0.6 and n > 1000          # the planted (rounded) field itself
+    res = torch.empty((2, H, W), device=cuda)
+    sc, dp, dc = (torch.empty((H, W), device=cuda) for _ in range(3))
+    ctx = dfe.get_ctx(0)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 33, 33, cx, cy, 0.21,
+                                               res.data_ptr(), sc.data_ptr(), dp.data_ptr(), dc.data_ptr()))
+    (gx, gy), _ = dfe.sfm2.getFOEFromFlow(res, None, min_flow=1.0, iterations=3)
+    assert abs(gx - cx) < 1.0 and abs(gy - cy) < 1.0                       # from the matcher's own flow (occlusion / border outliers down-weighted)
+    bad = flow.astype(np.float32).copy()
+    bad[:, 20:60, 30:90] = rng_flow = np.random.default_rng(2).uniform(-8, 8, (2, 40, 60)).astype(np.float32)
+    (hx, hy), _ = dfe.sfm2.getFOEFromFlow(T(bad, cuda), None, min_flow=1.0, iterations=4)
+    assert abs(hx - cx) < 1.0 and abs(hy - cy) < 1.0
+    with pytest.raises(dfe.DfeError):
+        par = np.zeros((2, 40, 50), np.float32)
+        par[1] = 3.0                                                      # pure x translation: parallel lines, no FOE
+        dfe.sfm2.getFOEFromFlow(T(par, cuda), None)
