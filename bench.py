@@ -239,7 +239,7 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
             "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, 7x7 raw-patch SSD over %dx%d, "
                                    "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (W, H, Cc, list(ratios), maxh, maxw),
                        "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "whole step (4 launches)", "achieved": round(balg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "whole step (prep, volumes, one cascade launch per scale)", "achieved": round(balg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(balg / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": balg},
         }), flush=True)

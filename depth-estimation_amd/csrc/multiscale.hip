@@ -565,6 +565,129 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
     }
 }
 
+// ---- lane <-> PIXEL cascade for 8 x 8 windows and ratios 1, 2, 4, ... (the configurations of BASELINE configs[1], [3], [4]) ------------
+// cascade_argmax_kernel above keeps a window's 64 cells on the 64 lanes of a wave: every soft-min needs two wave
+// reductions, every cascade add a cross-lane read, the arg-max two 8-column butterflies -- ~50 VALU per pixel and latency
+// chains nothing overlaps (63.9 us at VGA, 11 % of the step's roofline).  Here a lane owns a whole pixel: its 64 costs sit in
+// registers, the maximum, the exponentials, the sum (added in the SAME tree as the wave reduction: partners at distance 32,
+// 16, 8, 4, 2, 1 -- bit-identical) and the arg-max are straight-line code with no cross-lane traffic at all (~17 VALU per
+// pixel).  One launch per scale, coarse to fine: scale s leaves its cascaded window [P_s][64] and its running best (value,
+// class) per pixel for scale s-1, whose pixel (y, x) reads the 4 x 4 cells (2 + a/2, 2 + b/2) of pixel (y/2, x/2)
+// (CascadingAddTable.lua:117-132 with maxh = 8: dh = dw = 2, q = 2); scale 1 writes class ids / flow only.  The same float
+// operations in the same order as softmin_kernel + cascade_ring + arg-max: bit-identical to the staged path.
+struct CascadePxArgs {
+    const float *cost;        // [Hs][Ws][64] raw SSD costs of this scale
+    const float *pcasc;       // cascaded windows of the coarser scale [Hs/2][Ws/2][64], or NULL (coarsest)
+    const float2 *pbest;      // its running best (value, class as int bits), or NULL
+    float *casc;              // out (scales > 1): this scale's cascaded windows
+    float2 *best;             // out (scales > 1)
+    long long *idx;           // out (scale 1): 1-based class ids, or NULL
+    float *fy, *fx;           // out (scale 1): decoded flow planes, or NULL
+    int Hs, Ws, scale, middle;
+    int cls_base;             // scales > 1: 0-based class id of the ring's first cell (g.base[scale])
+};
+
+template <bool FINEST>
+__global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, DecodeTab dt) {
+#pragma clang fp contract(off)
+    const long long P = (long long)a.Hs * a.Ws;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int y = (int)(p / a.Ws), x = (int)(p - (long long)y * a.Ws);
+    float v[64];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.cost + p * 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 t = src[j];
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+    }
+    // soft-min: p = e / sum, e = expf(-c - max(-c)); the sum in the association order of wave_sum_f32_ordered
+    float m = -v[0];
+#pragma unroll
+    for (int j = 1; j < 64; ++j) m = fmaxf(m, -v[j]);
+    float t[32];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) v[j] = expf(-v[j] - m);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) t[j] = v[j] + v[j + 32];
+#pragma unroll
+    for (int h = 16; h >= 1; h >>= 1)
+#pragma unroll
+        for (int j = 0; j < h; ++j) t[j] = t[j] + t[j + h];
+    const float rs = 1.0f / t[0];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) v[j] = v[j] * rs;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (a.pcasc) {                                                     // (launch-uniform)
+        const long long pp = (long long)(y >> 1) * (a.Ws >> 1) + (x >> 1);
+        const float *pc = a.pcasc + pp * 64;
+        float par[16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float2 lo = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 2), hi = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 4);
+            par[4 * r] = lo.x; par[4 * r + 1] = lo.y; par[4 * r + 2] = hi.x; par[4 * r + 3] = hi.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 64; ++j) v[j] = v[j] + par[((j >> 3) >> 1) * 4 + ((j & 7) >> 1)];
+        const float2 pb = a.pbest[pp];
+        bv = pb.x;
+        bi = __float_as_int(pb.y);
+    }
+    // Arg-max over this scale's classes, then against the coarser chain's best.  Rule (the cell-per-lane kernel's, i.e. TH's
+    // max + the reference's class order): the largest value, among equal values the smallest class id.  This scale's ids are all
+    // smaller than the coarser chain's, so: fv = max over the scale's class cells; fi = the first cell IN CLASS ORDER equal to
+    // fv; the scale wins ties against the chain (fv >= bv).  Straight-line v_max / v_cmp_eq / v_cndmask with static register
+    // indices -- the first version walked (value, class) pairs through a 3-way compare per cell: 400 v_cmp + 1400 scalar mask
+    // instructions per pixel-lane.
+    // 8 x 8 window, ring width 2 (round(8 (r - r/2) / (2 r)) = 2 for every ratio pair 2:1): class order of the ring cells =
+    // top two rows, left 4 x 2, right 4 x 2, bottom two rows (opticalflow_model_multiscale.lua:301-315).
+    {
+        float fv;
+        int fi = 0;
+        if constexpr (FINEST) {
+            fv = v[0];
+#pragma unroll
+            for (int j = 1; j < 64; ++j) fv = fmaxf(fv, v[j]);
+#pragma unroll
+            for (int j = 63; j >= 0; --j) fi = v[j] == fv ? j : fi;
+        } else {
+            constexpr int ORD[48] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,      // top d x maxw
+                                     16, 17, 24, 25, 32, 33, 40, 41,                                      // left (maxh-2d) x d
+                                     22, 23, 30, 31, 38, 39, 46, 47,                                      // right
+                                     48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};     // bottom
+            fv = v[ORD[0]];
+#pragma unroll
+            for (int k = 1; k < 48; ++k) fv = fmaxf(fv, v[ORD[k]]);
+#pragma unroll
+            for (int k = 47; k >= 0; --k) fi = v[ORD[k]] == fv ? k : fi;
+            fi += a.cls_base;                                          // 0-based class of ring position 0 at this scale
+        }
+        if (fv >= bv) { bv = fv; bi = fi; }
+    }
+    if constexpr (!FINEST) {
+        float4 *dst = reinterpret_cast<float4 *>(a.casc + p * 64);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        a.best[p] = make_float2(bv, __int_as_float(bi));
+    } else {
+        int id = bi + 1;
+        const int mc = (a.middle - 1) & 63;
+        float cen = 0.f;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) cen = j == mc ? v[j] : cen;      // (mc is launch-uniform: folds to one select chain)
+        if (a.middle > 0 && bv == cen) id = a.middle;
+        if (a.idx) a.idx[p] = id;
+        if (a.fy) {
+            const int d = dt.v[id - 1];
+            a.fy[p] = (float)(d >> 16);
+            a.fx[p] = (float)(short)(d & 0xffff);
+        }
+    }
+}
+
 int ring_width(int maxw, int r, int rprev) { return (int)floor((double)maxw * (r - rprev) / (2.0 * r) + 0.5); }
 
 int fill_cascade(dfe_ctx *ctx, CascadeGeom &g, const int *ratios, int nratios, int maxh, int maxw) {
@@ -648,7 +771,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     const int N = maxh * maxw;
     const int hp = maxh - 1 + k - 1, wp = maxw - 1 + k - 1;   // hPatch2-1 (opticalflow_model_multiscale.lua:136-141)
     const int pt = hp / 2, pl = wp / 2;
-    size_t off_p[DFE_MAX_RATIOS], off_v[DFE_MAX_RATIOS], off_q[DFE_MAX_RATIOS], total = 0;
+    size_t off_p[DFE_MAX_RATIOS], off_v[DFE_MAX_RATIOS], off_q[DFE_MAX_RATIOS], off_b[DFE_MAX_RATIOS], total = 0;
     for (int s = 0; s < nratios; ++s) {
         const int r = ratios[s];
         DFE_REQUIRE(ctx, H % r == 0 && W % r == 0, DFE_E_SHAPE,
@@ -657,6 +780,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         off_p[s] = total; total += (2 * np * sizeof(float) + 255) / 256 * 256;
         off_v[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
         off_q[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
+        off_b[s] = total; total += ((size_t)(H / r) * (W / r) * sizeof(float2) + 255) / 256 * 256;
     }
     // the per-scale cost volumes below use the same arena for their own temporaries only through cv_frames_dispatch, which
     // needs none; one allocation up front keeps every stage's buffers alive until the cascade has read them
@@ -690,6 +814,11 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     DFE_LAUNCH_CHECK(ctx);
     bool merged = false, soft_done = false;
     const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
+    // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
+    bool px_path = fast && maxh == 8 && maxw == 8;
+    for (int s = 0; s < nratios; ++s)
+        if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
+    if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
     {
         // one launch for every scale's volume; on the fast path the coarser scales leave it as soft-min probabilities already
         // (their blocks run next to the scale-1 blocks that dominate the launch), scale 1 as costs for the cascade's SOFT0
@@ -697,7 +826,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         float *vo[DFE_MAX_RATIOS], *pr[DFE_MAX_RATIOS];
         for (int s = 0; s < nratios; ++s) {
             f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s];
-            pr[s] = (fast && s > 0) ? ss.prob[s] : nullptr;
+            pr[s] = (fast && s > 0 && !px_path) ? ss.prob[s] : nullptr;
         }
         rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, pr, &merged, &soft_done);
         if (rc) return rc;
@@ -706,6 +835,35 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         rc = cv_frames_dispatch(ctx, ps.p0[s], ps.p1[s], C, ps.Hp[s], ps.Wp[s], (long long)ps.Hp[s] * ps.Wp[s], k, k, maxh, maxw,
                                 (float *)ss.cost[s]);
         if (rc) return rc;
+    }
+    const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
+    if (px_path) {
+        DecodeTab dt;
+        fill_decode_tab(mg, g.ncls, dt);
+        fill_cell_maps(g, dt);
+        for (int s = nratios - 1; s >= 0; --s) {                      // coarse -> fine: one launch per scale
+            const int r = ratios[s];
+            CascadePxArgs a{};
+            a.cost = (const float *)ss.cost[s];
+            a.Hs = H / r; a.Ws = W / r; a.scale = s; a.middle = middle; a.cls_base = g.base[s];
+            if (s + 1 < nratios) {
+                a.pcasc = (const float *)((char *)scr + off_q[s + 1]);
+                a.pbest = (const float2 *)((char *)scr + off_b[s + 1]);
+            }
+            const int blocks = (int)(((long long)a.Hs * a.Ws + 255) / 256);
+            if (s > 0) {
+                a.casc = (float *)((char *)scr + off_q[s]);
+                a.best = (float2 *)((char *)scr + off_b[s]);
+                hipLaunchKernelGGL(cascade_px_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+            } else {
+                a.idx = (long long *)idx;
+                a.fy = flow;
+                a.fx = flow ? flow + (size_t)H * W : nullptr;
+                hipLaunchKernelGGL(cascade_px_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+            }
+        }
+        DFE_LAUNCH_CHECK(ctx);
+        return DFE_OK;
     }
     // one-cell-per-lane path: the scale-1 soft-min happens inside the cascade kernel (SOFT0), the coarser scales' here
     int nsoft = nratios;
@@ -723,7 +881,6 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         DFE_LAUNCH_CHECK(ctx);
     }
     g.H = H; g.W = W;
-    const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
     size_t lds = (size_t)kWaves * 2 * N * sizeof(float);
     DFE_REQUIRE(ctx, lds <= 64 * 1024, DFE_E_UNSUPPORTED, "dfe_multiscale_flow_pair_f32: window %dx%d too large", maxh, maxw);
     if (lds < (size_t)g.ncls * sizeof(int2)) lds = (size_t)g.ncls * sizeof(int2);
