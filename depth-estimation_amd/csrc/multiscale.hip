@@ -585,25 +585,14 @@ struct CascadePxArgs {
     float *fy, *fx;           // out (scale 1): decoded flow planes, or NULL
     int Hs, Ws, scale, middle;
     int cls_base;             // scales > 1: 0-based class id of the ring's first cell (g.base[scale])
+    const float *pcost;       // INLINE: raw costs of the (coarsest) parent scale
+    int pcls_base;            // INLINE: its class base
 };
 
-template <bool FINEST>
-__global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, DecodeTab dt) {
+// soft-min of the 64 costs in v (in place): p = e / sum, e = expf(-c - max(-c)), the sum in the association order of
+// wave_sum_f32_ordered (partners at distance 32, 16, 8, 4, 2, 1)
+__device__ __forceinline__ void px_softmin64(float (&v)[64]) {
 #pragma clang fp contract(off)
-    const long long P = (long long)a.Hs * a.Ws;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    const int y = (int)(p / a.Ws), x = (int)(p - (long long)y * a.Ws);
-    float v[64];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.cost + p * 64);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float4 t = src[j];
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-        }
-    }
-    // soft-min: p = e / sum, e = expf(-c - max(-c)); the sum in the association order of wave_sum_f32_ordered
     float m = -v[0];
 #pragma unroll
     for (int j = 1; j < 64; ++j) m = fmaxf(m, -v[j]);
@@ -619,22 +608,70 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
     const float rs = 1.0f / t[0];
 #pragma unroll
     for (int j = 0; j < 64; ++j) v[j] = v[j] * rs;
+}
+__device__ __forceinline__ void px_load64(const float *__restrict__ src_, float (&v)[64]) {
+    const float4 *src = reinterpret_cast<const float4 *>(src_);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 t = src[j];
+        v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+}
+// Arg-max over a ring scale's 48 classes (see the comment in the kernel): (value, 0-based class)
+__device__ __forceinline__ void px_ring_best(const float (&v)[64], int cls_base, float &fv, int &fi) {
+    constexpr int ORD[48] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,      // top d x maxw
+                             16, 17, 24, 25, 32, 33, 40, 41,                                      // left (maxh-2d) x d
+                             22, 23, 30, 31, 38, 39, 46, 47,                                      // right
+                             48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};     // bottom
+    fv = v[ORD[0]];
+    fi = 0;
+#pragma unroll
+    for (int k = 1; k < 48; ++k) fv = fmaxf(fv, v[ORD[k]]);
+#pragma unroll
+    for (int k = 47; k >= 0; --k) fi = v[ORD[k]] == fv ? k : fi;
+    fi += cls_base;
+}
+
+// INLINE: the coarser scale is the coarsest one and is not launched at all: every lane recomputes its parent pixel's window
+// from the raw costs (a.pcost) with exactly the parent kernel's operations -- four lanes repeat the same ~1300 instructions,
+// which is cheaper than a launch of its own for a scale of a few hundred waves (VGA scale 4: 75 blocks, 11 us of latency).
+template <bool FINEST, bool INLINE>
+__global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, DecodeTab dt) {
+#pragma clang fp contract(off)
+    const long long P = (long long)a.Hs * a.Ws;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int y = (int)(p / a.Ws), x = (int)(p - (long long)y * a.Ws);
+    float v[64];
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    if (a.pcasc) {                                                     // (launch-uniform)
-        const long long pp = (long long)(y >> 1) * (a.Ws >> 1) + (x >> 1);
-        const float *pc = a.pcasc + pp * 64;
-        float par[16];
+    float par[16];
+    const long long pp = (long long)(y >> 1) * (a.Ws >> 1) + (x >> 1);
+    if constexpr (INLINE) {
+        px_load64(a.pcost + pp * 64, v);
+        px_softmin64(v);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float2 lo = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 2), hi = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 4);
-            par[4 * r] = lo.x; par[4 * r + 1] = lo.y; par[4 * r + 2] = hi.x; par[4 * r + 3] = hi.y;
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) par[4 * r + c] = v[(2 + r) * 8 + 2 + c];
+        px_ring_best(v, a.pcls_base, bv, bi);       // (the coarsest scale has no chain above it: its best is its own)
+    }
+    px_load64(a.cost + p * 64, v);
+    px_softmin64(v);
+    if (INLINE || a.pcasc) {                                           // (launch-uniform)
+        if constexpr (!INLINE) {
+            const float *pc = a.pcasc + pp * 64;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float2 lo = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 2), hi = *reinterpret_cast<const float2 *>(pc + (2 + r) * 8 + 4);
+                par[4 * r] = lo.x; par[4 * r + 1] = lo.y; par[4 * r + 2] = hi.x; par[4 * r + 3] = hi.y;
+            }
+            const float2 pb = a.pbest[pp];
+            bv = pb.x;
+            bi = __float_as_int(pb.y);
         }
 #pragma unroll
         for (int j = 0; j < 64; ++j) v[j] = v[j] + par[((j >> 3) >> 1) * 4 + ((j & 7) >> 1)];
-        const float2 pb = a.pbest[pp];
-        bv = pb.x;
-        bi = __float_as_int(pb.y);
     }
     // Arg-max over this scale's classes, then against the coarser chain's best.  Rule (the cell-per-lane kernel's, i.e. TH's
     // max + the reference's class order): the largest value, among equal values the smallest class id.  This scale's ids are all
@@ -654,16 +691,7 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
 #pragma unroll
             for (int j = 63; j >= 0; --j) fi = v[j] == fv ? j : fi;
         } else {
-            constexpr int ORD[48] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,      // top d x maxw
-                                     16, 17, 24, 25, 32, 33, 40, 41,                                      // left (maxh-2d) x d
-                                     22, 23, 30, 31, 38, 39, 46, 47,                                      // right
-                                     48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};     // bottom
-            fv = v[ORD[0]];
-#pragma unroll
-            for (int k = 1; k < 48; ++k) fv = fmaxf(fv, v[ORD[k]]);
-#pragma unroll
-            for (int k = 47; k >= 0; --k) fi = v[ORD[k]] == fv ? k : fi;
-            fi += a.cls_base;                                          // 0-based class of ring position 0 at this scale
+            px_ring_best(v, a.cls_base, fv, fi);
         }
         if (fv >= bv) { bv = fv; bi = fi; }
     }
@@ -841,12 +869,18 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
         DecodeTab dt;
         fill_decode_tab(mg, g.ncls, dt);
         fill_cell_maps(g, dt);
-        for (int s = nratios - 1; s >= 0; --s) {                      // coarse -> fine: one launch per scale
+        // coarse -> fine: one launch per scale, except that the coarsest scale is recomputed inside its child's launch
+        const int top = nratios >= 2 ? nratios - 2 : 0;
+        for (int s = top; s >= 0; --s) {
             const int r = ratios[s];
             CascadePxArgs a{};
             a.cost = (const float *)ss.cost[s];
             a.Hs = H / r; a.Ws = W / r; a.scale = s; a.middle = middle; a.cls_base = g.base[s];
-            if (s + 1 < nratios) {
+            const bool inl = nratios >= 2 && s == top;
+            if (inl) {
+                a.pcost = (const float *)ss.cost[s + 1];
+                a.pcls_base = g.base[s + 1];
+            } else if (s + 1 < nratios) {
                 a.pcasc = (const float *)((char *)scr + off_q[s + 1]);
                 a.pbest = (const float2 *)((char *)scr + off_b[s + 1]);
             }
@@ -854,12 +888,14 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
             if (s > 0) {
                 a.casc = (float *)((char *)scr + off_q[s]);
                 a.best = (float2 *)((char *)scr + off_b[s]);
-                hipLaunchKernelGGL(cascade_px_kernel<false>, dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                if (inl) hipLaunchKernelGGL((cascade_px_kernel<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                else hipLaunchKernelGGL((cascade_px_kernel<false, false>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
             } else {
                 a.idx = (long long *)idx;
                 a.fy = flow;
                 a.fx = flow ? flow + (size_t)H * W : nullptr;
-                hipLaunchKernelGGL(cascade_px_kernel<true>, dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                else hipLaunchKernelGGL((cascade_px_kernel<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
             }
         }
         DFE_LAUNCH_CHECK(ctx);
