@@ -424,8 +424,9 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md)
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("hbm_bytes_per_launch")
-                build_traffic = tj.get("build_only", {}).get("hbm_bytes_per_launch")
+                if tj.get("kernel_rev") == lib.dfe_kernel_revision().decode():   # counters of another kernel revision say nothing
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    build_traffic = tj.get("build_only", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = build_traffic = None
         out = {

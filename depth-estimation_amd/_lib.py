@@ -16,6 +16,7 @@ c_i32p = C.POINTER(C.c_int)
 # name -> (restype, argtypes); must list every symbol include/dfe.h declares
 PROTOTYPES = {
     "dfe_version": (C.c_int, []),
+    "dfe_kernel_revision": (C.c_char_p, []),
     "dfe_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "dfe_ctx_destroy": (None, [C.c_void_p]),
     "dfe_last_error": (C.c_char_p, [C.c_void_p]),

@@ -221,6 +221,13 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
+#define DFE_CV_KERNEL_REV "cv-r2.7"
+#ifndef DFE_SMEM_JIT
+#define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
+#endif
+#ifndef DFE_SCAN_AFTER_COPY
+#define DFE_SCAN_AFTER_COPY 0   // tuning: the fused arg-min scan behind the copy-out instead of in front of it
+#endif
 #ifndef DFE_CW0
 #define DFE_CW0 5    // row-image kernel: first wave that takes part in the copy-out (0 = all waves)
 #endif
@@ -897,7 +904,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     const int RUN = TX * D;                       // floats in the block's run
     const int l16 = lane & 15;
     float av[C][NE];
-    if constexpr (SM) {
+    if constexpr (SM && !DFE_SMEM_JIT) {
 #pragma unroll
         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + c * HW), av[c]);
     }
@@ -1049,9 +1056,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 px_t a{};
                 if constexpr (!SM) a = t0[t0r + l16];
                 float v[TX];
+                if constexpr (SM && DFE_SMEM_JIT) {   // this row's scalars, just in time: they land while the first LDS batch is in flight
+#pragma unroll
+                    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)r * p.W + c * HW), av[c]);
+                }
                 rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
                 if constexpr (SWEEP) ring_step(lp);
-                if constexpr (SM) {   // next row's scalars
+                if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars
 #pragma unroll
                     for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
                 }
@@ -1159,7 +1170,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         }
                     }
                 }
-                if constexpr (FUSE) {
+                if constexpr (FUSE && !DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
                 // Copy-out by the waves WITHOUT an extra task (DFE_CW0.., 10 or 11 of them): a CU's vector-memory path takes 64 B
@@ -1235,6 +1246,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                             if (wave == CW0 + 1 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
                         }
                     }
+                }
+                if constexpr (FUSE && DFE_SCAN_AFTER_COPY) {
+                    if (store_row) scan_row(st, pg_run);
                 }
             }
         });
@@ -1588,6 +1602,10 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 }
 
 extern "C" {
+
+// Bumped whenever a change can alter what the cost-volume kernels read or write: profiles/traffic_*.json carries the revision
+// its PMC counters were taken with, and bench.py reports `traffic` only when the two agree.
+const char *dfe_kernel_revision(void) { return DFE_CV_KERNEL_REV; }
 
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw,
                             int hWin, int wWin, float *out) {

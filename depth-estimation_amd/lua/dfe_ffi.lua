@@ -7,6 +7,7 @@ local ffi = require 'ffi'
 ffi.cdef[[
 typedef struct dfe_ctx dfe_ctx;
 int dfe_version(void);
+const char *dfe_kernel_revision(void);
 int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out);
 void dfe_ctx_destroy(dfe_ctx *ctx);
 const char *dfe_last_error(const dfe_ctx *ctx);

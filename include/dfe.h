@@ -42,6 +42,8 @@ typedef struct dfe_ctx dfe_ctx;
 
 /* ---- context, memory --------------------------------------------------- */
 int dfe_version(void);
+/* revision tag of the cost-volume kernels (profiles/traffic_*.json records the one its HBM counters were measured with) */
+const char *dfe_kernel_revision(void);
 /* own_stream != 0: the ctx creates (and owns) a private non-blocking stream, `stream` is ignored;
  * own_stream == 0: work is enqueued on the caller's hipStream_t `stream` (NULL = the HIP default
  * stream, which is what torch's default stream is) so it is ordered with the caller's other work */
