@@ -45,27 +45,86 @@ __device__ __forceinline__ float bilinear_at(const float *__restrict__ p, int H,
 
 // polar image [C][hdst][Wp], Wp = lpad + wdst + rpad; padded column jp shows grid column (jp - lpad) mod wdst
 // (cartesian2polar.lua:42-47: the left pad repeats the last lpad columns, the right pad the first rpad)
+// the grid's radius depends on the row only and its angle on the column only: r(i), sin / cos(theta(j)) -- the double-precision
+// pow / sin / cos of the reference's inline C -- are tabulated once per call (hdst + wdst values) instead of per pixel
+__global__ void polar_tables_kernel(int wdst, int hdst, float kr, float ktheta, float alpha, float *__restrict__ rt, double *__restrict__ sn,
+                                    double *__restrict__ cs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < hdst) rt[t] = (float)((double)kr * pow((double)(float)t, (double)alpha));   // cartesian2polar.lua:34
+    if (t < wdst) {
+        const float th = ktheta * (float)t;                                             // :35
+        sn[t] = sin((double)th);
+        cs[t] = cos((double)th);
+    }
+}
+
+// both frames as channel-interleaved float4 pixels (C <= 4): the warp's bilinear taps become one 16-B load each instead of C
+// scattered 4-B loads from planes H*W apart (the polar rows are circles in the frame: every tap is its own cache line)
+__global__ __launch_bounds__(256) void interleave_pair_kernel(const float *__restrict__ f0, const float *__restrict__ f1, int C, long long HW,
+                                                             float4 *__restrict__ o0, float4 *__restrict__ o1) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < HW; e += (long long)gridDim.x * blockDim.x) {
+        o0[e] = make_float4(f0[e], C > 1 ? f0[HW + e] : 0.f, C > 2 ? f0[2 * HW + e] : 0.f, C > 3 ? f0[3 * HW + e] : 0.f);
+        o1[e] = make_float4(f1[e], C > 1 ? f1[HW + e] : 0.f, C > 2 ? f1[2 * HW + e] : 0.f, C > 3 ? f1[3 * HW + e] : 0.f);
+    }
+}
+
+__device__ __forceinline__ float4 bilinear4_at(const float4 *__restrict__ p, int H, int W, float fy, float fx) {
+#pragma clang fp contract(off)
+    fy = fy < 0 ? 0 : (fy > (float)(H - 1) ? (float)(H - 1) : fy);
+    fx = fx < 0 ? 0 : (fx > (float)(W - 1) ? (float)(W - 1) : fx);
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float4 a = p[(long long)y0 * W + x0], b = p[(long long)y0 * W + x1], c = p[(long long)y1 * W + x0], d = p[(long long)y1 * W + x1];
+    float4 o;
+#define DFE_BL(m) { const float top = (1 - wx) * a.m + wx * b.m; const float bot = (1 - wx) * c.m + wx * d.m; o.m = (1 - wy) * top + wy * bot; }
+    DFE_BL(x) DFE_BL(y) DFE_BL(z) DFE_BL(w)
+#undef DFE_BL
+    return o;
+}
+
+template <bool IL>
 __global__ __launch_bounds__(256) void polar_warp_pair_kernel(const float *__restrict__ f0, const float *__restrict__ f1, int C, int H, int W,
-                                                             int wdst, int hdst, int Wp, int lpad, float xc, float yc, float kr, float ktheta,
-                                                             float alpha, float *__restrict__ o0, float *__restrict__ o1) {
+                                                             int wdst, int hdst, int Wp, int lpad, float xc, float yc, const float *__restrict__ rt,
+                                                             const double *__restrict__ sn, const double *__restrict__ cs, float *__restrict__ o0,
+                                                             float *__restrict__ o1) {
     const long long total = (long long)hdst * Wp, HW = (long long)H * W;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e / Wp), jp = (int)(e - (long long)i * Wp);
         int j = jp - lpad;
         j = j < 0 ? j + wdst : (j >= wdst ? j - wdst : j);
-        const float r = (float)((double)kr * pow((double)(float)i, (double)alpha));      // cartesian2polar.lua:34
-        const float th = ktheta * (float)j;                                             // :35
-        const float fy = (float)((double)r * sin((double)th) + (double)yc);             // :36
-        const float fx = (float)((double)r * cos((double)th) + (double)xc);             // :37
-        for (int c = 0; c < C; ++c) {
-            o0[c * total + e] = bilinear_at(f0 + c * HW, H, W, fy, fx);
-            o1[c * total + e] = bilinear_at(f1 + c * HW, H, W, fy, fx);
+        const float r = rt[i];
+        const float fy = (float)((double)r * sn[j] + (double)yc);                       // :36
+        const float fx = (float)((double)r * cs[j] + (double)xc);                       // :37
+        if constexpr (IL) {   // f0 / f1 are the interleaved float4 copies
+            const float4 v0 = bilinear4_at(reinterpret_cast<const float4 *>(f0), H, W, fy, fx);
+            const float4 v1 = bilinear4_at(reinterpret_cast<const float4 *>(f1), H, W, fy, fx);
+            const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+            for (int c = 0; c < C; ++c) {
+                o0[c * total + e] = a0[c];
+                o1[c * total + e] = a1[c];
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                o0[c * total + e] = bilinear_at(f0 + c * HW, H, W, fy, fx);
+                o1[c * total + e] = bilinear_at(f1 + c * HW, H, W, fy, fx);
+            }
         }
     }
 }
 
+// N consecutive wave-uniform floats through the scalar cache in as few s_load_dwordxN as possible (the compiler picks x8 / x4 /
+// x2 / x1 from the constant address space): a weight row costs 3 scalar instructions instead of 17.  One scalar load per
+// multiply-add -- the first version of these kernels -- left them bound by scalar-memory latency at a third of the VALU rate.
+typedef const float __attribute__((address_space(4))) *rp_cfptr;
+template <int N> __device__ __forceinline__ void load_uniform(const float *p, float (&v)[N]) {
+    rp_cfptr q = (rp_cfptr)p;
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = q[i];
+}
+
 // out[o][y][x] = bias[o] + sum_i sum_v w[o][i][v] * in[i][y][x+v]   (kH = 1)
-template <int NOUT, bool TANH>
+template <int NOUT, bool TANH, int KW = 0>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
                                                        int nIn, int H, int W, int kW, float *__restrict__ out) {
 #pragma clang fp contract(off)
@@ -83,12 +142,27 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const float *__restrict_
     float acc[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) acc[o] = bias ? bias[o] : 0.f;
+    if constexpr (KW > 0) {
+        for (int i = 0; i < nIn; ++i) {
+            float a[KW];
+#pragma unroll
+            for (int v = 0; v < KW; ++v) a[v] = tile[i * TW + tx + v];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                float wv[KW];
+                load_uniform<KW>(w + ((long long)o * nIn + i) * KW, wv);
+#pragma unroll
+                for (int v = 0; v < KW; ++v) acc[o] = acc[o] + wv[v] * a[v];
+            }
+        }
+    } else {
     for (int i = 0; i < nIn; ++i)
         for (int v = 0; v < kW; ++v) {
             const float a = tile[i * TW + tx + v];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) acc[o] = acc[o] + w[((long long)o * nIn + i) * kW + v] * a;   // (wave-uniform weights: scalar loads)
         }
+    }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) out[((long long)o * H + y) * Wo + x] = TANH ? tanhf(acc[o]) : acc[o];
 }
@@ -111,13 +185,14 @@ __global__ __launch_bounds__(256) void conv_cols_kernel(const float *__restrict_
 #pragma unroll
         for (int s = 0; s < RY + KH - 1; ++s) col[s] = in[((long long)i * H + min(y0 + s, H - 1)) * W + x];
 #pragma unroll
-        for (int u = 0; u < KH; ++u)
+        for (int o = 0; o < NOUT; ++o) {
+            float wv[KH];
+            load_uniform<KH>(w + ((long long)o * nIn + i) * KH, wv);
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                const float wv = w[((long long)o * nIn + i) * KH + u];
+            for (int u = 0; u < KH; ++u)
 #pragma unroll
-                for (int r = 0; r < RY; ++r) acc[r][o] = acc[r][o] + wv * col[r + u];
-            }
+                for (int r = 0; r < RY; ++r) acc[r][o] = acc[r][o] + wv[u] * col[r + u];
+        }
     }
 #pragma unroll
     for (int r = 0; r < RY; ++r)
@@ -217,7 +292,10 @@ int launch_conv_rows(dfe_ctx *ctx, const float *in, const float *w, const float 
     const int Wo = W - kW + 1;
     const size_t lds = (size_t)nIn * (256 + kW - 1) * sizeof(float);
     dim3 grid(dfe_cdiv(Wo, 256), H);
-    if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+    if (kW == 17) {
+        if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true, 17>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+        else hipLaunchKernelGGL((conv_rows_kernel<NOUT, false, 17>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+    } else if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
     else hipLaunchKernelGGL((conv_rows_kernel<NOUT, false>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
@@ -310,8 +388,11 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     const size_t polar_b = ((size_t)p->C * H * Wp * 4 + 255) / 256 * 256, tmp_b = ((size_t)p->n1 * H * W * 4 + 255) / 256 * 256;
     const size_t f2_b = ((size_t)p->n2 * Hf2 * W * 4 + 255) / 256 * 256, f1_b = f2_b;
     const size_t pf_b = ((size_t)hm * W * 4 + 255) / 256 * 256;
+    const size_t tab_b = ((size_t)H * 4 + 255) / 256 * 256 + 2 * (((size_t)W * 8 + 255) / 256 * 256);
+    const bool il = p->C <= 4;
+    const size_t il_b = il ? ((size_t)p->hImg * p->wImg * 16 + 255) / 256 * 256 : 0;
     void *scr = nullptr;
-    int rc = dfe_scratch(ctx, 2 * polar_b + tmp_b + f1_b + f2_b + pf_b, &scr);
+    int rc = dfe_scratch(ctx, 2 * polar_b + tmp_b + f1_b + f2_b + pf_b + tab_b + 2 * il_b, &scr);
     if (rc) return rc;
     float *pol0 = (float *)scr, *pol1 = (float *)((char *)scr + polar_b), *tmp = (float *)((char *)scr + 2 * polar_b);
     float *feat1 = (float *)((char *)tmp + tmp_b), *feat2 = (float *)((char *)feat1 + f1_b), *pflow = (float *)((char *)feat2 + f2_b);
@@ -321,8 +402,20 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     {   // 1. both frames to polar (getC2PMask's constants: cartesian2polar.lua:13-14)
         const float kr = (float)(rmax / pow((double)H, (double)p->alpha_polar));
         const float ktheta = (float)(2 * M_PI / W);
-        hipLaunchKernelGGL(polar_warp_pair_kernel, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, prev, cur, p->C, p->hImg, p->wImg, W, H,
-                           Wp, lpad, (float)e2x, (float)e2y, kr, ktheta, p->alpha_polar, pol0, pol1);
+        char *tb = (char *)scr + 2 * polar_b + tmp_b + f1_b + f2_b + pf_b;
+        float *rt = (float *)tb;
+        double *sn = (double *)(tb + ((size_t)H * 4 + 255) / 256 * 256), *cs = (double *)((char *)sn + ((size_t)W * 8 + 255) / 256 * 256);
+        hipLaunchKernelGGL(polar_tables_kernel, dim3(dfe_cdiv(H > W ? H : W, 256)), dim3(256), 0, ctx->stream, W, H, kr, ktheta, p->alpha_polar, rt, sn, cs);
+        if (il) {
+            float4 *i0 = (float4 *)(tb + tab_b), *i1 = (float4 *)(tb + tab_b + il_b);
+            hipLaunchKernelGGL(interleave_pair_kernel, dim3(grid1d((long long)p->hImg * p->wImg)), dim3(256), 0, ctx->stream, prev, cur, p->C,
+                               (long long)p->hImg * p->wImg, i0, i1);
+            hipLaunchKernelGGL(polar_warp_pair_kernel<true>, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, (const float *)i0,
+                               (const float *)i1, p->C, p->hImg, p->wImg, W, H, Wp, lpad, (float)e2x, (float)e2y, rt, sn, cs, pol0, pol1);
+        } else {
+            hipLaunchKernelGGL(polar_warp_pair_kernel<false>, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, prev, cur, p->C, p->hImg,
+                               p->wImg, W, H, Wp, lpad, (float)e2x, (float)e2y, rt, sn, cs, pol0, pol1);
+        }
         DFE_LAUNCH_CHECK(ctx);
     }
     // 2. shared filter on both polar frames.  The reference crops the previous frame's last hWin-1 rows BEFORE its filter
