@@ -22,6 +22,10 @@
 #include "dfe_internal.h"
 #include <cmath>
 
+#ifndef DFE_RADIAL_RY
+#define DFE_RADIAL_RY 8   // output rows per thread of the radial matcher (measured 720p, K = 10, hWin = 15: 4 rows 33.7 us, 6 rows 35.5, 8 rows 27.6, 10 rows 48.6 -- 256 VGPRs, one wave per SIMD)
+#endif
+
 namespace {
 
 int grid1d(long long n, int bs = 256) {
@@ -354,14 +358,15 @@ int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_ro
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W > 0 && hWin > 0, DFE_E_SHAPE, "dfe_radial_match_argmin_f32: K=%d H1=%d W=%d hWin=%d", K, H1, W, hWin);
     DFE_REQUIRE(ctx, hWin == 15 || hWin == 12 || hWin == 8 || hWin == 16, DFE_E_UNSUPPORTED,
                 "dfe_radial_match_argmin_f32: hWin %d has no instantiation (8, 12, 15, 16); use dfe_radial_matching_f32 + dfe_argbest_center", hWin);
-    dim3 grid(dfe_cdiv(W, 64), dfe_cdiv(H1, 4 * 4));
+    constexpr int RYM = DFE_RADIAL_RY;
+    dim3 grid(dfe_cdiv(W, 64), dfe_cdiv(H1, 4 * RYM));
     {
         DfeProfScope prof(ctx);
         switch (hWin) {
-            case 15: hipLaunchKernelGGL((radial_match_kernel<15, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
-            case 12: hipLaunchKernelGGL((radial_match_kernel<12, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
-            case 16: hipLaunchKernelGGL((radial_match_kernel<16, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
-            default: hipLaunchKernelGGL((radial_match_kernel<8, 4>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            case 15: hipLaunchKernelGGL((radial_match_kernel<15, RYM>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            case 12: hipLaunchKernelGGL((radial_match_kernel<12, RYM>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            case 16: hipLaunchKernelGGL((radial_match_kernel<16, RYM>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
+            default: hipLaunchKernelGGL((radial_match_kernel<8, RYM>), grid, dim3(256), 0, ctx->stream, in1, in1_plane_rows, in2, K, H1, W, volume, flow, zero_last_row); break;
         }
     }
     DFE_LAUNCH_CHECK(ctx);
