@@ -246,7 +246,7 @@ def radial_out_shape(networkp):
 def radialFlowDepth(networkp, network, prev_img, img, e2, kinfty=0.65, alpha_polar=1.0, one_call=True, want_volume=False):
     """radial/test_radial_opticalflow.lua:186-225 for one frame pair: polar warps of both frames around the epipole e2,
     getTesterNetwork:forward, min(3) - 1, back to cartesian through getP2CMaskOF, flow2depth.  prev_img is the previous
-    frame after the caller's ego-motion correction (sfm2.removeEgoMotion is outside this library).  Returns a dict
+    frame after the caller's ego-motion correction (sfm2.removeEgoMotion: `sfm2.removeEgoMotion` of this package, or the caller's own).  Returns a dict
     polar_flow, flow (cartesian), depth, confs [, output = the matcher volume].
     one_call: everything inside dfe_radial_flow_depth_pair_f32 (default separable filter stacks); else the staged module
     calls -- same numbers bit for bit."""
