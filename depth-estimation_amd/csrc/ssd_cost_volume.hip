@@ -221,9 +221,45 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r2.7"
+#define DFE_CV_KERNEL_REV "cv-r2.8"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
+#endif
+#ifndef DFE_TIMELINE
+#define DFE_TIMELINE 0   // tuning only (side builds): s_memtime stamps of the row phases of two blocks, read back with dfe_debug_timeline
+#endif
+#if DFE_TIMELINE
+#ifndef DFE_TL_MASK
+#define DFE_TL_MASK 127
+#endif
+__device__ unsigned long long dfe_tl[2][16][256][8];
+#define DFE_TL(i)                                                                                              \
+    do {                                                                                                       \
+        if (((DFE_TL_MASK) >> (i)) & 1) if (tl_blk >= 0 && (threadIdx.x & 63) == 0) dfe_tl[tl_blk][threadIdx.x >> 6][min(r, 255)][i] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define DFE_TL(i) do { } while (0)
+#endif
+#ifndef DFE_ROLES
+#define DFE_ROLES 1
+#endif
+#ifndef DFE_QW0
+#define DFE_QW0 0
+#endif
+#ifndef DFE_MINI_FIRST
+#define DFE_MINI_FIRST 0
+#endif
+#ifndef DFE_Q_FIRST
+#define DFE_Q_FIRST 0
+#endif
+#ifndef DFE_DMA_EXP
+#define DFE_DMA_EXP 0    // timing experiment only (wrong results): the last n waves before LW do the whole copy-out and no main task
+#endif
+#ifndef DFE_REFILL_AHEAD
+#define DFE_REFILL_AHEAD 2   // column sweep: row steps between the request of a ring row and its deposit in LDS (1, 2 or 3)
+#endif
+#ifndef DFE_LW_PRIO
+#define DFE_LW_PRIO 0        // column sweep: issue priority of the wave that refills the rings
 #endif
 #ifndef DFE_SCAN_AFTER_COPY
 #define DFE_SCAN_AFTER_COPY 0   // tuning: the fused arg-min scan behind the copy-out instead of in front of it
@@ -725,7 +761,7 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
         px_t b[BS];
 #pragma unroll
         for (int s = 0; s < BS; ++s)
-            if (bb * BS + s < NEL) b[s] = lr[bb * BS + s];
+            if (bb * BS + s < NEL) b[s] = lr[(DFE_ABLATE & 2) ? bb * BS : bb * BS + s];   // (2: one LDS read per batch)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (C == 3) {
 #pragma unroll
@@ -804,6 +840,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     constexpr int NE = TX + K - 1;
     constexpr int NQW = DFE_NQW;                 // waves that carry a share of the 17th chunk (tuning: 4 or 8)
     constexpr int TQ = TX / NQW;                 // columns of such a share ("quarter task")
+    // Fused column sweep: the waves split the work behind the barrier -- waves 0..7 scan one pixel's run each for its minimum,
+    // waves 8..14 copy the image out (wave 15 refills the rings) -- instead of every wave doing a half-pixel scan AND three
+    // pieces of the copy-out before it can start on the next row: per wave the chain scan -> stores (each wave's own stores
+    // issue one behind the other, 130+ cycles apiece, more when the memory pushes back) -> main task was the row's critical
+    // path, 2.7 of 5.1 kilocycles of a VGA row spent before the slowest waves began their main task (timeline, DFE_TIMELINE).
+    constexpr bool ROLES = FUSE && SWEEP && DFE_ROLES && TX == 8 && DC == 1089;
+    constexpr int QW0 = ROLES ? DFE_QW0 : 0;     // first wave with a quarter task
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
     // 33 x 33 instantiation: the LDS geometry is a compile-time constant (rowimg_plan / launch_cv_rowimg_sweep compute the same
@@ -850,6 +893,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         by = t / (int)gridDim.x;
         bx = t - by * (int)gridDim.x;
     }
+#if DFE_TIMELINE
+    const int tl_blk = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : -1;
+#endif
   for (;;) {   // pieces of this block (static tiles: one)
     // Every per-lane quantity is derived afresh from the thread id in each piece: nothing per-lane is then live across the
     // piece loop's back edge, and the register allocation of a piece is that of a one-piece kernel (with the ids taken
@@ -941,18 +987,18 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             return lds + packed + r * g_pitch;
     };
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
-    const bool has_q = wave < NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
+    const bool has_q = wave >= QW0 && wave < QW0 + NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
     const int dq = 1024 + lane;
     const bool validq = DC >= 1088 ? true : dq < D;
     int lpq;
     {
         const int dc = validq ? dq : D - 1;
-        const int dy = dc / g_wWin, dx = dc - dy * g_wWin + TQ * wave;
+        const int dy = dc / g_wWin, dx = dc - dy * g_wWin + TQ * (wave - QW0);
         lpq = SWEEP ? (dy << 16 | dx) : dy * g_pitch + dx;
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane; with tail-line ownership its
     // lanes 32..62 are the cells 0..30 of the pixel after the run (column TX)
-    constexpr int MW = NQW;                      // the mini task's wave: the first one without a quarter task
+    constexpr int MW = QW0 + NQW;                // the mini task's wave: the first one behind the quarter tasks
     const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
@@ -971,12 +1017,15 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     //  de-phase LDS reads and reductions across the lock-stepped waves -- 13 % slower.)
     if (has_q) __builtin_amdgcn_s_setprio(3);
     else if (has_m) __builtin_amdgcn_s_setprio(2);
+    else if (SWEEP && DFE_LW_PRIO && wave == LW) __builtin_amdgcn_s_setprio(DFE_LW_PRIO);
     float ring[U][TX], ringq[U][TQ];
     // the mini task's box-filter state lives in LDS ([U][64] floats behind the frame-0 tile; only wave 4 touches it)
     float *rm = reinterpret_cast<float *>(dfe_smem + g_tile0_off + t0rows * kT0W * sizeof(px_t)) + lane;
-    float hold[C];                                // column sweep, wave LW: the tile pixels loaded one row step ahead
+    float hold[DFE_REFILL_AHEAD][C];              // column sweep, wave LW: the tile pixels requested DFE_REFILL_AHEAD row steps ago
 #pragma unroll
-    for (int c = 0; c < C; ++c) hold[c] = 0.f;
+    for (int i = 0; i < DFE_REFILL_AHEAD; ++i)
+#pragma unroll
+        for (int c = 0; c < C; ++c) hold[i][c] = 0.f;
 #pragma unroll
     for (int i = 0; i < U; ++i) {
 #pragma unroll
@@ -1031,6 +1080,46 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 fa.part[(long long)hh * fa.Ptot + pgp + xx] = make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
         }
     };
+    // ROLES: one wave per pixel.  121 lanes' worth of 9 cells = lanes 0..63 (cells 9 l ..) and a second unit on lanes 0..56
+    // (cells 9 (64 + l) ..); both units' reads in flight together, ONE wave minimum for both, the first index from the lower
+    // unit if any of its lanes attains the minimum.  Plane 1 of fa.part gets +inf (finalize keeps the smaller of the two).
+    auto scan_row_whole = [&](const float *stp, long long pgp) {
+        if (DFE_ABLATE & 512) return;
+        constexpr int CPL = 9;
+        static_assert(!ROLES || DC % CPL == 0, "whole lanes only");
+        int lsc = lane;
+        asm volatile("" : "+v"(lsc));
+        const int xx = wave;
+        const bool out1 = (64 + lsc) * CPL >= D;
+        const int *pc0 = reinterpret_cast<const int *>(stp + xx * D) + lsc * CPL;
+        const int *pc1 = pc0 + (out1 ? 0 : 64 * CPL);
+        int c0[CPL], c1[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) c0[i] = pc0[i];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) c1[i] = pc1[i];
+        int b0 = min(min(min(c0[0], c0[1]), min(c0[2], c0[3])), min(min(min(c0[4], c0[5]), min(c0[6], c0[7])), c0[8]));
+        int i0 = CPL - 1;
+#pragma unroll
+        for (int i = CPL - 2; i >= 0; --i) i0 = c0[i] == b0 ? i : i0;
+        int b1 = min(min(min(c1[0], c1[1]), min(c1[2], c1[3])), min(min(min(c1[4], c1[5]), min(c1[6], c1[7])), c1[8]));
+        int i1 = CPL - 1;
+#pragma unroll
+        for (int i = CPL - 2; i >= 0; --i) i1 = c1[i] == b1 ? i : i1;
+        b1 = out1 ? 0x7f800000 : b1;
+        const int vmin = wave_min1(min(b0, b1));
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0 == vmin);
+        int idx;
+        if (m0) {                                                          // wave-uniform
+            const int f = __builtin_ctzll(m0);
+            idx = f * CPL + __builtin_amdgcn_readlane(i0, f);
+        } else {
+            const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == vmin));
+            idx = (64 + f) * CPL + __builtin_amdgcn_readlane(i1, f);
+        }
+        if (lsc < 2 && xx >= nover)
+            fa.part[(long long)lsc * fa.Ptot + pgp + xx] = lsc == 0 ? make_float2(__int_as_float(vmin), __int_as_float(idx)) : make_float2(__int_as_float(0x7f800000), 0.f);
+    };
     long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
     long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
     const int nq = (nsweep + U - 1) / U;
@@ -1052,91 +1141,110 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
-            if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
-                px_t a{};
-                if constexpr (!SM) a = t0[t0r + l16];
-                float v[TX];
-                if constexpr (SM && DFE_SMEM_JIT) {   // this row's scalars, just in time: they land while the first LDS batch is in flight
-#pragma unroll
-                    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)r * p.W + c * HW), av[c]);
-                }
-                rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
-                if constexpr (SWEEP) ring_step(lp);
-                if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars
-#pragma unroll
-                    for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
-                }
-                // deposit at once (image (r&1) was last read for row r-2, before the barrier of row r-1)
-                if (store_row && valid) {
-#pragma unroll
-                    for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
-                }
-                if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
-                    if (store_row) {
-                        int lf = lane;
-                        asm volatile("" : "+v"(lf));
-                        // (33 x 33: the centre cell, 1-based 545, is lane 32 of chunk 8)
-                        fuse_plain_stores<TX>(v, lf, wave, pg_run, fa, nover, CG ? 8 : fa.cmid, CG ? 32 : fa.lmid);
+            DFE_TL(0);
+            auto do_main = [&]() {
+                if (!(DFE_ABLATE & 65536) && !(SWEEP && DFE_DMA_EXP && wave >= LW - DFE_DMA_EXP && wave < LW)) {   // (65536: barrier + copy-out only)
+                    px_t a{};
+                    if constexpr (!SM) a = t0[t0r + l16];
+                    float v[TX];
+                    if constexpr (SM && DFE_SMEM_JIT) {   // this row's scalars, just in time: they land while the first LDS batch is in flight
+    #pragma unroll
+                        for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)r * p.W + c * HW), av[c]);
+                    }
+                    rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
+                    DFE_TL(1);
+                    if constexpr (SWEEP) ring_step(lp);
+                    if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars (requested behind the last squared difference instead --
+                                                           // inside the task row, in front of the sums -- the 42 scalars are live across the
+                                                           // sums as well and the 3-channel sweeps spill: 62 / 99 scalars, 104 / 124 B of scratch)
+    #pragma unroll
+                        for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
+                    }
+                    // deposit at once (image (r&1) was last read for row r-2, before the barrier of row r-1)
+                    if (store_row && valid) {
+    #pragma unroll
+                        for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
+                    }
+                    if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
+                        if (store_row) {
+                            int lf = lane;
+                            asm volatile("" : "+v"(lf));
+                            // (33 x 33: the centre cell, 1-based 545, is lane 32 of chunk 8)
+                            fuse_plain_stores<TX>(v, lf, wave, pg_run, fa, nover, CG ? 8 : fa.cmid, CG ? 32 : fa.lmid);
+                        }
                     }
                 }
-            }
-            if (has_q) {
-                // the quarter's frame-0 window always comes through LDS + DPP: its column offset is a run-time value and a
-                // second set of 24 scalars next to the main task's 42 does not fit the SGPR file
-                const px_t a = t0[t0r + TQ * wave + l16];
-                const float avq[C][TQ + K - 1] = {};
-                float v[TQ];
-                rowimg_task_row<C, K, TQ, m, false>(row_ptr(lpq, r), a, avq, ringq, v);
-                if constexpr (SWEEP) ring_step(lpq);
-                if (store_row && validq) {
-#pragma unroll
-                    for (int x = 0; x < TQ; ++x) st[(TQ * wave + x) * D + dq] = v[x];
+            };
+            auto do_quarter = [&]() {
+                if (has_q) {
+                    // the quarter's frame-0 window always comes through LDS + DPP: its column offset is a run-time value and a
+                    // second set of 24 scalars next to the main task's 42 does not fit the SGPR file
+                    const px_t a = t0[t0r + TQ * (wave - QW0) + l16];
+                    const float avq[C][TQ + K - 1] = {};
+                    float v[TQ];
+                    rowimg_task_row<C, K, TQ, m, false>(row_ptr(lpq, r), a, avq, ringq, v);
+                    if constexpr (SWEEP) ring_step(lpq);
+                    if (store_row && validq) {
+    #pragma unroll
+                        for (int x = 0; x < TQ; ++x) st[(TQ * (wave - QW0) + x) * D + dq] = v[x];
+                    }
                 }
-            }
-            if (has_m) {
-                // per-lane frame-0 pixels: no broadcast here, every lane has its own column
-                const px_t *lr = row_ptr(lpm, r);
-                if constexpr (SWEEP) ring_step(lpm);
-                const px_t *ar = t0 + t0r + xm;
-                float e[K];
-#pragma unroll
-                for (int j = 0; j < K; ++j) {
-                    if (j % 3 == 0) __builtin_amdgcn_sched_barrier(0);   // at most 6 pixel reads in flight (registers)
-                    const px_t av = ar[j], bv = lr[j];
-                    if constexpr (C == 1) {
-                        const float a1[1] = {av};
-                        e[j] = sqdiff<1>(a1, bv);
+            };
+            auto do_mini = [&]() {
+                if (has_m) {
+                    // per-lane frame-0 pixels: no broadcast here, every lane has its own column
+                    const px_t *lr = row_ptr(lpm, r);
+                    if constexpr (SWEEP) ring_step(lpm);
+                    const px_t *ar = t0 + t0r + xm;
+                    float e[K];
+    #pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        if (j % 3 == 0) __builtin_amdgcn_sched_barrier(0);   // at most 6 pixel reads in flight (registers)
+                        const px_t av = ar[j], bv = lr[j];
+                        if constexpr (C == 1) {
+                            const float a1[1] = {av};
+                            e[j] = sqdiff<1>(a1, bv);
+                        } else {
+                            const float a3[3] = {av.x, av.y, av.z};
+                            e[j] = sqdiff<3>(a3, bv);
+                        }
+                    }
+                    // right-to-left chain = the association of column 0 of a main task (hsum_vh: sa[0]): the tail cells this task
+                    // computes for the pixel after the run are bit-identical to what that pixel's own tile holds in its image
+                    float h[1], v;
+                    h[0] = e[K - 1];
+    #pragma unroll
+                    for (int j = K - 2; j >= 0; --j) h[0] = e[j] + h[0];
+                    if constexpr (K == 7) {
+                        const float r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
+                        v = (r0 + r2) + (r4 + h[0]);
+                        rm[((m + 5) % 6) * 64] = r5 + h[0];
+                        rm[m * 64] = h[0];
                     } else {
-                        const float a3[3] = {av.x, av.y, av.z};
-                        e[j] = sqdiff<3>(a3, bv);
+                        rm[m * 64] = h[0];
+                        v = rm[((m + 1) % K) * 64];
+    #pragma unroll
+                        for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
+                    }
+                    if (store_row) {
+                        int lm = lane;
+                        asm volatile("" : "+v"(lm));   // (keeps this address and the lane masks out of the scalar file / the spill slots)
+                        const bool mt = TOWN && lm >= 32;
+                        // (tail cells: only those that complete the run's last line, a0 + RUN + ntl == 0 mod 32)
+                        const bool ok = mt ? has_next && lm - 32 < ((-(a0 + RUN)) & 31) : 1088 + (lm >> 3) < D && (!TOWN || lm < 32);
+                        if (ok) st[mt ? TX * D + (lm - 32) : (lm & 7) * D + 1088 + (lm >> 3)] = v;
                     }
                 }
-                // right-to-left chain = the association of column 0 of a main task (hsum_vh: sa[0]): the tail cells this task
-                // computes for the pixel after the run are bit-identical to what that pixel's own tile holds in its image
-                float h[1], v;
-                h[0] = e[K - 1];
-#pragma unroll
-                for (int j = K - 2; j >= 0; --j) h[0] = e[j] + h[0];
-                if constexpr (K == 7) {
-                    const float r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
-                    v = (r0 + r2) + (r4 + h[0]);
-                    rm[((m + 5) % 6) * 64] = r5 + h[0];
-                    rm[m * 64] = h[0];
-                } else {
-                    rm[m * 64] = h[0];
-                    v = rm[((m + 1) % K) * 64];
-#pragma unroll
-                    for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
-                }
-                if (store_row) {
-                    int lm = lane;
-                    asm volatile("" : "+v"(lm));   // (keeps this address and the lane masks out of the scalar file / the spill slots)
-                    const bool mt = TOWN && lm >= 32;
-                    // (tail cells: only those that complete the run's last line, a0 + RUN + ntl == 0 mod 32)
-                    const bool ok = mt ? has_next && lm - 32 < ((-(a0 + RUN)) & 31) : 1088 + (lm >> 3) < D && (!TOWN || lm < 32);
-                    if (ok) st[mt ? TX * D + (lm - 32) : (lm & 7) * D + 1088 + (lm >> 3)] = v;
-                }
-            }
+            };
+            // order of a wave's tasks within a row (tuning): the latency-bound extra task first runs while the SIMD's other waves
+            // are busy with their main tasks, instead of alone behind them
+            if (DFE_MINI_FIRST) do_mini();
+            if (DFE_Q_FIRST) do_quarter();
+            do_main();
+            DFE_TL(2);
+            if (!DFE_Q_FIRST) do_quarter();
+            if (!DFE_MINI_FIRST) do_mini();
+            DFE_TL(3);
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
                 // global stores to be acknowledged before every barrier and serialise stores with compute.
@@ -1144,6 +1252,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // after the barrier of row r+1, which every wave reaches after its copy-out of row r.
                 // (The column sweep needs it in the warm-up rows too: it also frees the tile row the sweep has just left.)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                DFE_TL(4);
                 if constexpr (SWEEP) {
                     if (wave == LW && !(DFE_ABLATE & 131072)) {
                         // Stream the rings: the pixels requested one row step ago go into the slots of the rows the sweep
@@ -1154,11 +1263,16 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         int lw = lane;
                         asm volatile("" : "+v"(lw));
                         const bool t1lane = lw < g_lcols, t0lane = !t1lane && lw - g_lcols <= NE;
-                        if (r >= 1 && !(DFE_ABLATE & 262144)) {
+                        // (the requests are DFE_REFILL_AHEAD = 2 row steps old when they are waited for: one step -- 1.3 us -- is
+                        //  about a memory round trip behind this kernel's own store stream, and the wait is on every wave's path
+                        //  to the next barrier)
+                        constexpr int RA = DFE_REFILL_AHEAD, hs = m % RA;
+                        static_assert(VUnroll<K>::value % RA == 0, "hold slot = row step mod RA must be a compile-time value");
+                        if (r >= RA && !(DFE_ABLATE & 262144)) {
                             px_t px;
-                            if constexpr (C == 1) px = hold[0]; else px = make_float4(hold[0], hold[1], hold[2], 0.f);
-                            if (t1lane) lds[((r - 1) & (g_lrows - 1)) * g_pitch + lw] = px;
-                            if (t0lane) t0w[((r - 1) & (R0 - 1)) * kT0W + lw - g_lcols] = px;
+                            if constexpr (C == 1) px = hold[hs][0]; else px = make_float4(hold[hs][0], hold[hs][1], hold[hs][2], 0.f);
+                            if (t1lane) lds[((r - RA) & (g_lrows - 1)) * g_pitch + lw] = px;
+                            if (t0lane) t0w[((r - RA) & (R0 - 1)) * kT0W + lw - g_lcols] = px;
                         }
                         // (running row pointers instead of these multiplies -- one add per row, fewer scalars to keep -- measured 4 %
                         //  slower on the plain build and changed nothing in the spill count)
@@ -1166,13 +1280,16 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                                                   : I0 + (long long)min(y0 + oy + r + R0, p.H - 1) * p.W + x0 + ox + (lw - g_lcols);
                         if (t1lane || t0lane) {
 #pragma unroll
-                            for (int c = 0; c < C; ++c) hold[c] = src[c * HW];
+                            for (int c = 0; c < C; ++c) hold[hs][c] = src[c * HW];
                         }
                     }
                 }
-                if constexpr (FUSE && !DFE_SCAN_AFTER_COPY) {
+                if constexpr (ROLES) {
+                    if (store_row && wave < TX) scan_row_whole(st, pg_run);
+                } else if constexpr (FUSE && !DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
+                DFE_TL(5);
                 // Copy-out by the waves WITHOUT an extra task (DFE_CW0.., 10 or 11 of them): a CU's vector-memory path takes 64 B
                 // per clock, i.e. ~545 cycles for the 34 848 B of a row, and every wave that stores waits its turn in it.  With all
                 // waves copying, the four quarter-task waves -- the critical path of the sweep -- started the next row up to 0.2 us
@@ -1180,7 +1297,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // have that much slack before the next barrier.
                 // (Fused build: all waves copy -- they are all held by the scan before it, and fewer copiers then only take
                 //  longer: 298 against 290 us.)
-                constexpr int CW0 = FUSE ? 0 : DFE_CW0;                      // first copier wave
+                constexpr int CW0 = (SWEEP && DFE_DMA_EXP) ? LW - DFE_DMA_EXP : ROLES ? TX : FUSE ? 0 : DFE_CW0;   // first copier wave
                 constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
                 if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
@@ -1227,13 +1344,19 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
                     constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
-                    f4_t val[NPC];
+                    constexpr int GP = NPC <= 4 ? NPC : 6;                        // pieces in flight per thread
 #pragma unroll
-                    for (int i = 0; i < NPC; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
+                    for (int g0 = 0; g0 < NPC; g0 += GP) {
+                        f4_t val[GP];
 #pragma unroll
-                    for (int i = 0; i < NPC; ++i)
-                        if (tj + i * STR < nbody4)
-                            asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                        for (int i = 0; i < GP; ++i)
+                            if (g0 + i < NPC) val[i] = sb[min(tj + (g0 + i) * STR, nbody4 - 1)];
+#pragma unroll
+                        for (int i = 0; i < GP; ++i)
+                            if (g0 + i < NPC)
+                                if (tj + (g0 + i) * STR < nbody4)
+                                    asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + (g0 + i) * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                    }
                     }
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
@@ -1250,6 +1373,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 if constexpr (FUSE && DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
+                DFE_TL(6);
             }
         });
     }
@@ -1602,6 +1726,9 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 }
 
 extern "C" {
+#if DFE_TIMELINE
+int dfe_debug_timeline(void *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dfe_tl), sizeof(dfe_tl)); }
+#endif
 
 // Bumped whenever a change can alter what the cost-volume kernels read or write: profiles/traffic_*.json carries the revision
 // its PMC counters were taken with, and bench.py reports `traffic` only when the two agree.

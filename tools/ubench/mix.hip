@@ -1,0 +1,108 @@
+// The arithmetic of one row-image task row (14 squared differences with frame-0 operands in SGPRs, block-form horizontal
+// sums, pair-sum vertical ring) on register-resident data: what VALU issue rate does this instruction mix reach by itself?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef const float __attribute__((address_space(4))) *cfptr;
+extern __shared__ float4 lds4[];
+template <int VAR> __global__ __launch_bounds__(1024) void k(const float *__restrict__ a0, float *out, int iters) {
+    if (VAR >= 3) {
+        for (int i = threadIdx.x; i < 64 * 49; i += blockDim.x) lds4[i] = make_float4(i * 0.5f, i * 0.25f, i * 0.125f, 0.f);
+        __syncthreads();
+    }
+    float *stage = reinterpret_cast<float *>(lds4 + 64 * 49);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 *lr0 = lds4 + (lane / 33) * 49 + (lane % 33);
+    float ring[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) ring[i][x] = 0.f;
+    float av[3][14];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int s = 0; s < 14; ++s) av[c][s] = ((cfptr)a0)[c * 14 + s];    // uniform -> SGPRs
+    float bx = threadIdx.x * 0.25f, acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            float e[14];
+            float4 bb[14];
+            if (VAR >= 3) {
+                const float4 *lr = lr0 + ((it * 6 + m) & 15) * 49;
+#pragma unroll
+                for (int s = 0; s < 5; ++s) bb[s] = lr[s];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                if (VAR >= 3 && (s == 5 || s == 10)) {
+                    const float4 *lr = lr0 + ((it * 6 + m) & 15) * 49;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = s; t < s + 5 && t < 14; ++t) bb[t] = lr[t];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                float b0 = bx + s, b1 = bx - s, b2 = bx * 0.5f;   // stand-ins for the LDS pixels (3 cheap VALU, counted below)
+                if (VAR >= 3) { b0 = bb[s].x; b1 = bb[s].y; b2 = bb[s].z; asm volatile("" :: "v"(bb[s].w)); }
+                if (VAR == 1) { asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2)); }
+                float d0, d1, d2;
+                if (VAR == 2) {   // frame-0 operands from VGPRs instead of SGPRs
+                    float a0v = av[0][s], a1v = av[1][s], a2v = av[2][s];
+                    asm volatile("" : "+v"(a0v), "+v"(a1v), "+v"(a2v));
+                    d0 = a0v - b0; d1 = a1v - b1; d2 = a2v - b2;
+                } else {
+                    d0 = av[0][s] - b0; d1 = av[1][s] - b1; d2 = av[2][s] - b2;
+                }
+                e[s] = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+            }
+            float sa[7], pb[7], h[8];
+            sa[6] = e[6];
+#pragma unroll
+            for (int i = 5; i >= 0; --i) sa[i] = e[i] + sa[i + 1];
+            pb[0] = e[7];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) pb[j] = pb[j - 1] + e[7 + j];
+            h[0] = sa[0];
+#pragma unroll
+            for (int x = 1; x < 7; ++x) h[x] = sa[x] + pb[x - 1];
+            h[7] = pb[6];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float v = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
+                ring[(m + 5) % 6][x] += h[x];
+                ring[m][x] = h[x];
+                if (VAR >= 4) stage[(m & 1) * 8800 + x * 1089 + wave * 64 + lane] = v; else
+                acc += v;                       // stands in for the deposit
+            }
+            if (VAR >= 5) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            bx += 1.f;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <int VAR> void run(const float *a0, float *d, int wps, const char *name) {
+    int iters = 512, blocks = 256, threads = 256 * wps;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void *)k<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
+    hipLaunchKernelGGL(k<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, 8);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    double rows = (double)iters * 6;                         // task rows per wave
+    double us_per_row = best * 1e3 / rows;                   // per wave-row with wps waves on each SIMD -> per SIMD: x wps rows
+    printf("%-28s waves/SIMD=%d  %.3f ms  %.4f us per row step (all waves of a SIMD)  = %.0f cycles @2.3GHz per wave-row\n", name, wps, best,
+           us_per_row, us_per_row * 2300.0 / wps);
+}
+int main() {
+    float *a0, *d; (void)hipMalloc(&a0, 64 * 4); (void)hipMalloc(&d, 256 * 1024 * 4);
+    (void)hipMemset(a0, 0, 64 * 4);
+    for (int w : {4, 2, 1}) { run<0>(a0, d, w, "arithmetic only"); run<3>(a0, d, w, "+ 14 ds_read_b128"); run<4>(a0, d, w, "+ reads + 8 ds_write_b32"); run<5>(a0, d, w, "+ reads, writes, barrier"); }
+    return 0;
+}
