@@ -246,6 +246,21 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #ifndef DFE_QW0
 #define DFE_QW0 0
 #endif
+#ifndef DFE_ROLES_CW0
+#define DFE_ROLES_CW0 8
+#endif
+#ifndef DFE_HELP_WAVES
+#define DFE_HELP_WAVES 4
+#endif
+#ifndef DFE_HELP_PIECES
+#define DFE_HELP_PIECES 0
+#endif
+#ifndef DFE_MINI_ON_LW
+#define DFE_MINI_ON_LW 1
+#endif
+#ifndef DFE_MINI_GROUP
+#define DFE_MINI_GROUP 4
+#endif
 #ifndef DFE_MINI_FIRST
 #define DFE_MINI_FIRST 0
 #endif
@@ -811,6 +826,13 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
 // row of 16 a DPP broadcast reaches)
 constexpr int kT0W = 24;
 // compile-time LDS geometry of the 33 x 33 instantiations (what rowimg_plan / launch_cv_rowimg_sweep compute at run time)
+// the lane id from the execution mask (v_mbcnt): two instructions and no live register -- the row loop's branches re-derive
+// their lane geometry from this instead of holding threadIdx.x (or spilling it: every register counts in the 3-channel sweeps)
+__device__ __forceinline__ int lane_id_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 template <int C, int K, int TX> struct RowimgGeom {
     static constexpr int R = 64, R0 = 8;                                   // column sweep: rows of the frame-1 / frame-0 rings
     static constexpr int lcols33 = TX + K - 1 + 32;
@@ -998,7 +1020,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane; with tail-line ownership its
     // lanes 32..62 are the cells 0..30 of the pixel after the run (column TX)
-    constexpr int MW = QW0 + NQW;                // the mini task's wave: the first one behind the quarter tasks
+    // the mini task's wave: the first one behind the quarter tasks; fused sweep with split roles: the wave that refills the rings
+    // (it neither scans nor copies)
+    constexpr int MW = (ROLES && DFE_MINI_ON_LW) ? LW : QW0 + NQW;
     const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
@@ -1099,21 +1123,23 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
         for (int i = 0; i < CPL; ++i) c1[i] = pc1[i];
         int b0 = min(min(min(c0[0], c0[1]), min(c0[2], c0[3])), min(min(min(c0[4], c0[5]), min(c0[6], c0[7])), c0[8]));
-        int i0 = CPL - 1;
-#pragma unroll
-        for (int i = CPL - 2; i >= 0; --i) i0 = c0[i] == b0 ? i : i0;
         int b1 = min(min(min(c1[0], c1[1]), min(c1[2], c1[3])), min(min(min(c1[4], c1[5]), min(c1[6], c1[7])), c1[8]));
-        int i1 = CPL - 1;
-#pragma unroll
-        for (int i = CPL - 2; i >= 0; --i) i1 = c1[i] == b1 ? i : i1;
         b1 = out1 ? 0x7f800000 : b1;
         const int vmin = wave_min1(min(b0, b1));
+        // the cell index is looked for only in the unit that holds the first minimum (wave-uniform choice): the lower unit if
+        // any of its lanes attains it
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0 == vmin);
         int idx;
-        if (m0) {                                                          // wave-uniform
+        if (m0) {
+            int i0 = CPL - 1;
+#pragma unroll
+            for (int i = CPL - 2; i >= 0; --i) i0 = c0[i] == vmin ? i : i0;
             const int f = __builtin_ctzll(m0);
             idx = f * CPL + __builtin_amdgcn_readlane(i0, f);
         } else {
+            int i1 = CPL - 1;
+#pragma unroll
+            for (int i = CPL - 2; i >= 0; --i) i1 = c1[i] == vmin ? i : i1;
             const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == vmin));
             idx = (64 + f) * CPL + __builtin_amdgcn_readlane(i1, f);
         }
@@ -1185,8 +1211,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     rowimg_task_row<C, K, TQ, m, false>(row_ptr(lpq, r), a, avq, ringq, v);
                     if constexpr (SWEEP) ring_step(lpq);
                     if (store_row && validq) {
+                        const int dqf = 1024 + lane_id_fresh();
     #pragma unroll
-                        for (int x = 0; x < TQ; ++x) st[(TQ * (wave - QW0) + x) * D + dq] = v[x];
+                        for (int x = 0; x < TQ; ++x) st[(TQ * (wave - QW0) + x) * D + dqf] = v[x];
                     }
                 }
             };
@@ -1196,10 +1223,14 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     const px_t *lr = row_ptr(lpm, r);
                     if constexpr (SWEEP) ring_step(lpm);
                     const px_t *ar = t0 + t0r + xm;
+                    float r0 = 0.f, r2 = 0.f, r4 = 0.f, r5 = 0.f;
+                    if constexpr (K == 7) {   // the box-filter state, in flight with the first pixel reads
+                        r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
+                    }
                     float e[K];
     #pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        if (j % 3 == 0) __builtin_amdgcn_sched_barrier(0);   // at most 6 pixel reads in flight (registers)
+                        if (j % DFE_MINI_GROUP == 0) __builtin_amdgcn_sched_barrier(0);   // at most 2 x DFE_MINI_GROUP pixel reads in flight (registers)
                         const px_t av = ar[j], bv = lr[j];
                         if constexpr (C == 1) {
                             const float a1[1] = {av};
@@ -1216,7 +1247,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     #pragma unroll
                     for (int j = K - 2; j >= 0; --j) h[0] = e[j] + h[0];
                     if constexpr (K == 7) {
-                        const float r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
                         v = (r0 + r2) + (r4 + h[0]);
                         rm[((m + 5) % 6) * 64] = r5 + h[0];
                         rm[m * 64] = h[0];
@@ -1297,9 +1327,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // have that much slack before the next barrier.
                 // (Fused build: all waves copy -- they are all held by the scan before it, and fewer copiers then only take
                 //  longer: 298 against 290 us.)
-                constexpr int CW0 = (SWEEP && DFE_DMA_EXP) ? LW - DFE_DMA_EXP : ROLES ? TX : FUSE ? 0 : DFE_CW0;   // first copier wave
+                constexpr int CW0 = (SWEEP && DFE_DMA_EXP) ? LW - DFE_DMA_EXP : ROLES ? DFE_ROLES_CW0 : FUSE ? 0 : DFE_CW0;   // first copier wave
                 constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
-                if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
+                // ROLES: NHW of the scan waves without a quarter task (the last ones) take NPH pieces per thread off the copy waves
+                constexpr int NHW = ROLES ? DFE_HELP_WAVES : 0, NPH = ROLES ? DFE_HELP_PIECES : 0, HL0 = TX - NHW;
+                if (store_row && (wave >= CW0 || (NHW > 0 && NPH > 0 && wave >= HL0)) && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
                     int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
@@ -1343,6 +1375,21 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
+                    if constexpr (NHW > 0 && NPH > 0) {
+                        // helper threads: pieces [0, NA) at stride NHW * 64; copy waves: the rest at stride STR (wave-uniform choice)
+                        constexpr int NTOT = (TX * 1096 + 32) / 4, NA = NPH * NHW * 64;
+                        constexpr int NPCC = (NTOT - NA + STR - 1) / STR, NPC = NPH > NPCC ? NPH : NPCC;
+                        const bool hw = wave < CW0;
+                        const int pb = hw ? tj + (CW0 - HL0) * 64 : NA + tj, ps = hw ? NHW * 64 : STR, pn = hw ? NPH : NPCC, pend = hw ? min(NA, nbody4) : nbody4;
+                        f4_t val[NPC];
+#pragma unroll
+                        for (int i = 0; i < NPC; ++i)
+                            if (i < pn) val[i] = sb[min(pb + i * ps, nbody4 - 1)];
+#pragma unroll
+                        for (int i = 0; i < NPC; ++i)
+                            if (i < pn && pb + i * ps < pend)
+                                asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(pb + i * ps) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                    } else {
                     constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
                     constexpr int GP = NPC <= 4 ? NPC : 6;                        // pieces in flight per thread
 #pragma unroll
@@ -1356,6 +1403,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                             if (g0 + i < NPC)
                                 if (tj + (g0 + i) * STR < nbody4)
                                     asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + (g0 + i) * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                    }
                     }
                     }
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
