@@ -221,7 +221,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r2.8"
+#define DFE_CV_KERNEL_REV "cv-r2.9"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -867,7 +867,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // pieces of the copy-out before it can start on the next row: per wave the chain scan -> stores (each wave's own stores
     // issue one behind the other, 130+ cycles apiece, more when the memory pushes back) -> main task was the row's critical
     // path, 2.7 of 5.1 kilocycles of a VGA row spent before the slowest waves began their main task (timeline, DFE_TIMELINE).
-    constexpr bool ROLES = FUSE && SWEEP && DFE_ROLES && TX == 8 && DC == 1089;
+    // (3-channel frames only: with one channel the main task is half as long and the all-waves scan of the plain layout
+    //  wins, VGA luminance 215 against 254 us)
+    constexpr bool ROLES = FUSE && SWEEP && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
     constexpr int QW0 = ROLES ? DFE_QW0 : 0;     // first wave with a quarter task
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
@@ -1020,9 +1022,10 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     }
     // mini task (wave 4): cells 1088 + (lane >> 3), column lane & 7 -- one output per lane; with tail-line ownership its
     // lanes 32..62 are the cells 0..30 of the pixel after the run (column TX)
-    // the mini task's wave: the first one behind the quarter tasks; fused sweep with split roles: the wave that refills the rings
-    // (it neither scans nor copies)
-    constexpr int MW = (ROLES && DFE_MINI_ON_LW) ? LW : QW0 + NQW;
+    // the mini task's wave: the first one behind the quarter tasks; 3-channel column sweeps: the wave that refills the rings
+    // (it neither scans nor copies; with the mini task on wave 4, behind that wave's main task and scan, it was the last one
+    //  at the barrier: VGA fused 258 -> 250 us, plain 228 -> 222 us)
+    constexpr int MW = (SWEEP && C == 3 && DFE_MINI_ON_LW && (ROLES || !FUSE)) ? LW : QW0 + NQW;
     const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
