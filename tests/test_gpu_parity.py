@@ -755,3 +755,45 @@ def test_flow_depth_pair_f16_indices_identical_to_f32_path(dfe, cuda, H, W, C):
         assert np.array_equal(idx16.cpu().numpy(), ref["idx"]) and np.array_equal(best16.cpu().numpy(), ref["best"])
     with pytest.raises(dfe.DfeError):   # no fused fp16 kernel for a 9x9 window: the caller takes the fp32 path
         ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, 9, 9, cx, cy, 2.0 ** -8, None, None, flow16.data_ptr(), None, None))
+
+
+# ------------------------------------------------------------------ one device per ctx
+def test_entry_points_run_on_their_ctx_device_and_leave_the_callers_alone(dfe, cuda):
+    """Every entry point switches to its ctx's device for the call and restores the caller's current device (DFE_ENTER); two
+    ctxs in one host thread give the same result.  With a second GPU present, a ctx on device 1 is driven while device 0 is
+    current (and the other way round)."""
+    import ctypes as C
+
+    lib = dfe.lib()
+    hip = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+
+    def current():
+        assert hip.hipGetDevice(C.byref(cur)) == 0
+        return cur.value
+
+    ndev = torch.cuda.device_count()
+    f0, f1, _, _ = rp.synth_pair(60, 64, C=3, seed=3)
+    ref = None
+    for dev in range(min(ndev, 2)):
+        before = current()
+        h = C.c_void_p()
+        assert lib.dfe_ctx_create(dev, None, 1, C.byref(h)) == 0
+        assert current() == before, "dfe_ctx_create changed the caller's device"
+        d = torch.device("cuda", dev)
+        t0, t1 = T(f0, d), T(f1, d)
+        out = torch.empty((60 - 7 - 8 + 2, 64 - 7 - 8 + 2, 8, 8), device=d)
+        other = (dev + 1) % ndev
+        assert hip.hipSetDevice(other) == 0            # the caller's device is NOT the ctx's (when there are two)
+        rc = lib.dfe_ssd_cost_volume_f32(h, t0.data_ptr(), t1.data_ptr(), 3, 60, 64, 7, 7, 8, 8, out.data_ptr())
+        assert rc == 0, lib.dfe_last_error(h)
+        assert current() == other, "an entry point left the device switched"
+        torch.cuda.synchronize(d)
+        got = out.cpu().numpy()
+        if ref is None:
+            ref = got
+            np.testing.assert_array_equal(got, orc.ssd_cost_volume(f0, f1, 7, 7, 8, 8))
+        else:
+            np.testing.assert_array_equal(got, ref)
+        lib.dfe_ctx_destroy(h)
+        assert hip.hipSetDevice(before) == 0
