@@ -211,6 +211,11 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
     SSD volume, softmin; then the fused cascade / ring / arg-max / decode).  Several small kernels, so `roofline` prices
     the WHOLE step against the algorithmic bytes of SURVEY 8(d) (frames read once + every scale's native volume once)."""
     H, W, Cc, k, maxh, maxw, ratios = PYRAMIDS[args.workload]
+    if os.environ.get("DFE_GRAPHS") == "1":
+        # libdfe enqueues on torch's current stream; on a real stream (not the legacy default one) it can replay this
+        # launch-bound step -- 4 or 5 kernels of 9-33 us -- as a hipGraph (measured slower than the direct launches: 0.0857
+        # against 0.0803 ms at VGA, so off by default)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     rmax = ratios[-1]
     Hp, Wp = -(-H // rmax) * rmax, -(-W // rmax) * rmax            # the reference pads to a multiple of the coarsest ratio
     f0, f1, _, _ = rp.synth_pair(H, W, C=Cc, seed=rank, max_flow=12)

@@ -1,5 +1,6 @@
 // dfe_ctx.hip -- context, error text, device memory helpers of the C ABI (include/dfe.h).
 #include "dfe_internal.h"
+#include <cstring>
 #include <cstdlib>
 
 static thread_local char g_create_err[512] = "";
@@ -29,6 +30,41 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
     return DFE_OK;
 }
 
+int dfe_graph_lookup(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, const void *key, size_t bytes) {
+    if (!ctx->graphs || !ctx->stream || ctx->profile) return 0;
+    const unsigned char *k = (const unsigned char *)key;
+    if (slot.key.size() == bytes && memcmp(slot.key.data(), k, bytes) == 0) {
+        if (slot.exec) return 2;
+        if (++slot.hits < 1) return 0;
+        // capture: everything the launcher enqueues on the ctx stream until dfe_graph_finish
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->graphs = false;   // a stream that cannot be captured (e.g. a legacy default stream handed in by the caller)
+            return 0;
+        }
+        return 1;
+    }
+    if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+    slot.key.assign(k, k + bytes);
+    slot.hits = 0;
+    return 0;
+}
+
+int dfe_graph_finish(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, int rc) {
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (rc != DFE_OK) {   // the launcher failed half way: nothing has run, the caller sees its error
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) return dfe_fail(ctx, DFE_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&slot.exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) { slot.exec = nullptr; return dfe_fail(ctx, DFE_E_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    DFE_HIP(ctx, hipGraphLaunch(slot.exec, ctx->stream));
+    return DFE_OK;
+}
+
 extern "C" {
 
 int dfe_version(void) { return 100; }
@@ -55,6 +91,7 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *e = getenv("DFE_GRAPHS")) ctx->graphs = atoi(e) != 0;
     if (const char *e = getenv("DFE_CV_MODE")) { int m = atoi(e); if (m >= 0 && m <= 3) ctx->cv_mode = m; }   // tuning: initial kernel mode
     if (const char *e = getenv("DFE_CV_TILE")) { int t = atoi(e); if ((t >= 0 && t <= 7) || (t > 100 && t <= 164)) ctx->cv_tyq = t; }   // tuning: initial tile code
     if (!own_stream) {
@@ -74,6 +111,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     if (!ctx) return;
     DfeDeviceGuard guard(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ms_graph.exec) (void)hipGraphExecDestroy(ctx->ms_graph.exec);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->dflag) (void)hipFree(ctx->dflag);

@@ -25,7 +25,24 @@ struct dfe_ctx {
     bool profile = false;
     int prof_depth = 0;               // only the outermost DfeProfScope records (a launcher may nest another)
     std::vector<hipEvent_t> prof_events;   // start/stop pairs, resolved by dfe_profile_read
+    // launch-bound one-call pipelines (the multiscale matcher: 4-6 launches of 9-33 us) can be replayed as a hipGraph when
+    // they are called again with the same arguments (same buffers, same shapes): the second such call captures, later ones
+    // replay.  OFF unless DFE_GRAPHS=1 is in the environment when the ctx is created: on ROCm 7.2 / MI355X the replay
+    // measured SLOWER than the direct launches (VGA 3-level pyramid 0.0857 against 0.0803 ms per pair, 1080p 0.543 against
+    // 0.537 ms: the graph launch costs more than four back-to-back kernel launches on one stream).  Profiling and the
+    // legacy null stream (not capturable) also turn it off.
+    struct GraphSlot {
+        std::vector<unsigned char> key;
+        int hits = 0;
+        hipGraphExec_t exec = nullptr;
+    };
+    GraphSlot ms_graph;
+    bool graphs = false;
 };
+// key = the bytes of a POD describing the call; returns 0 = launch directly, 1 = capture this call, 2 = replay slot.exec
+int dfe_graph_lookup(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, const void *key, size_t bytes);
+// ends a capture begun after dfe_graph_lookup returned 1 (rc = the launcher's result), instantiates and launches the graph
+int dfe_graph_finish(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, int rc);
 
 // brackets the cost-volume kernel launch with events on the ctx stream when profiling is on
 struct DfeProfScope {

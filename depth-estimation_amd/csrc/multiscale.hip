@@ -7,6 +7,7 @@
 // H x W x 64 temporaries; here volumes stay at native scale and one kernel per finest pixel gathers its
 // window from each scale, cascades and ring-selects in LDS, writing only the H x W x nclasses result.
 #include "dfe_internal.h"
+#include <cstring>
 #include <type_traits>
 #include <cmath>
 
@@ -815,6 +816,19 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     void *scr = nullptr;
     rc = dfe_scratch(ctx, total, &scr);
     if (rc) return rc;
+    // the same call again (same buffers, shapes and arena): replay its launches as a graph
+    struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; } gkey;
+    memset(&gkey, 0, sizeof gkey);
+    gkey.I0 = I0; gkey.I1 = I1; gkey.flow = flow; gkey.idx = idx; gkey.scr = scr;
+    gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios;
+    for (int s = 0; s < nratios; ++s) gkey.ratios[s] = ratios[s];
+    const int gmode = dfe_graph_lookup(ctx, ctx->ms_graph, &gkey, sizeof gkey);
+    if (gmode == 2) {
+        DFE_HIP(ctx, hipGraphLaunch(ctx->ms_graph.exec, ctx->stream));
+        ctx->last_kernel = "multiscale graph";
+        return DFE_OK;
+    }
+    auto launch_all = [&]() -> int {
     MultiGeom mg;
     mg.maxh = maxh; mg.maxw = maxw; mg.nratios = nratios;
     // the scales are independent until the cascade: one launch prepares every scale's frames, one per scale builds its
@@ -934,6 +948,9 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     }
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
+    };
+    if (gmode == 1) return dfe_graph_finish(ctx, ctx->ms_graph, launch_all());
+    return launch_all();
 }
 
 int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {

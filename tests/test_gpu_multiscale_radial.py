@@ -883,3 +883,48 @@ def test_epipole_and_foe_from_dense_flow(dfe, cuda):
         par = np.zeros((2, 40, 50), np.float32)
         par[1] = 3.0                                                      # pure x translation: parallel lines, no FOE
         dfe.sfm2.getFOEFromFlow(T(par, cuda), None)
+
+
+def test_multiscale_one_call_graph_replay_equals_direct_launches(dfe, cuda):
+    """With DFE_GRAPHS=1 the one-call matcher replays its launches as a hipGraph from the third call with the same buffers on
+    (the second captures): every call gives the result of the direct launches, also after the frames were overwritten in
+    place, and a call with other buffers drops the graph.  (Off by default: the replay measured slower.)"""
+    from depth_estimation_amd._lib import ratios_array
+
+    H, W, k, mh, ratios = 96, 128, 7, 8, [1, 2, 4]
+    fa0, fa1, _, _ = rp.synth_pair(H, W, C=3, seed=21)
+    fb0, fb1, _, _ = rp.synth_pair(H, W, C=3, seed=22)
+    want_a = _one_call(dfe, cuda, fa0, fa1, k, mh, mh, ratios)      # default (legacy) stream: cannot be captured, direct launches
+    want_b = _one_call(dfe, cuda, fb0, fb1, k, mh, mh, ratios)
+    rr, n = ratios_array(ratios)
+    side = torch.cuda.Stream(device=cuda)
+    with torch.cuda.stream(side):                                   # a ctx on a real stream: its launches can be captured
+        os.environ["DFE_GRAPHS"] = "1"                              # read when the ctx is created (a new one: new stream)
+        try:
+            ctx = dfe.get_ctx(0)
+        finally:
+            del os.environ["DFE_GRAPHS"]
+        t0, t1 = T(fa0, cuda), T(fa1, cuda)
+        flow = torch.empty((2, H, W), device=cuda)
+        idx = torch.empty((H, W), dtype=torch.int64, device=cuda)
+
+        def call():
+            ctx.check(dfe.lib().dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, mh, mh, rr, n, flow.data_ptr(), idx.data_ptr()))
+            ctx.synchronize()
+            return idx.cpu().numpy(), flow.cpu().numpy()
+
+        kernels = []
+        for i in range(4):           # direct, capture + launch, replay, replay
+            gi, gf = call()
+            kernels.append(ctx.last_kernel())
+            assert np.array_equal(gi, want_a[0]) and np.array_equal(gf, want_a[1]), "call %d" % i
+        assert kernels[3] == "multiscale graph", kernels
+        t0.copy_(T(fb0, cuda)); t1.copy_(T(fb1, cuda))   # same buffers, new frames: the replay reads them at run time
+        side.synchronize()
+        for i in range(2):
+            gi, gf = call()
+            assert np.array_equal(gi, want_b[0]) and np.array_equal(gf, want_b[1]), "replay %d on new frames" % i
+        flow2 = torch.empty((2, H, W), device=cuda)                  # another output buffer: the key changes, direct launches again
+        ctx.check(dfe.lib().dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, mh, mh, rr, n, flow2.data_ptr(), idx.data_ptr()))
+        ctx.synchronize()
+        assert ctx.last_kernel() != "multiscale graph" and np.array_equal(flow2.cpu().numpy(), want_b[1])
