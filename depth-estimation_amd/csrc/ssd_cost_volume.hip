@@ -243,33 +243,6 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #ifndef DFE_ROLES
 #define DFE_ROLES 1
 #endif
-#ifndef DFE_QW0
-#define DFE_QW0 0
-#endif
-#ifndef DFE_ROLES_CW0
-#define DFE_ROLES_CW0 8
-#endif
-#ifndef DFE_HELP_WAVES
-#define DFE_HELP_WAVES 4
-#endif
-#ifndef DFE_HELP_PIECES
-#define DFE_HELP_PIECES 0
-#endif
-#ifndef DFE_MINI_ON_LW
-#define DFE_MINI_ON_LW 1
-#endif
-#ifndef DFE_MINI_GROUP
-#define DFE_MINI_GROUP 4
-#endif
-#ifndef DFE_MINI_FIRST
-#define DFE_MINI_FIRST 0
-#endif
-#ifndef DFE_Q_FIRST
-#define DFE_Q_FIRST 0
-#endif
-#ifndef DFE_DMA_EXP
-#define DFE_DMA_EXP 0    // timing experiment only (wrong results): the last n waves before LW do the whole copy-out and no main task
-#endif
 #ifndef DFE_REFILL_AHEAD
 #define DFE_REFILL_AHEAD 2   // column sweep: row steps between the request of a ring row and its deposit in LDS (1, 2 or 3)
 #endif
@@ -870,7 +843,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // (3-channel frames only: with one channel the main task is half as long and the all-waves scan of the plain layout
     //  wins, VGA luminance 215 against 254 us)
     constexpr bool ROLES = FUSE && SWEEP && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
-    constexpr int QW0 = ROLES ? DFE_QW0 : 0;     // first wave with a quarter task
+    constexpr int QW0 = 0;                       // first wave with a quarter task (on the copy waves, 8..11, instead: 265 against 258 us)
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
     // 33 x 33 instantiation: the LDS geometry is a compile-time constant (rowimg_plan / launch_cv_rowimg_sweep compute the same
@@ -1025,7 +998,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // the mini task's wave: the first one behind the quarter tasks; 3-channel column sweeps: the wave that refills the rings
     // (it neither scans nor copies; with the mini task on wave 4, behind that wave's main task and scan, it was the last one
     //  at the barrier: VGA fused 258 -> 250 us, plain 228 -> 222 us)
-    constexpr int MW = (SWEEP && C == 3 && DFE_MINI_ON_LW && (ROLES || !FUSE)) ? LW : QW0 + NQW;
+    constexpr int MW = (SWEEP && C == 3 && (ROLES || !FUSE)) ? LW : QW0 + NQW;
     const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
@@ -1172,12 +1145,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
             DFE_TL(0);
             auto do_main = [&]() {
-                if (!(DFE_ABLATE & 65536) && !(SWEEP && DFE_DMA_EXP && wave >= LW - DFE_DMA_EXP && wave < LW)) {   // (65536: barrier + copy-out only)
+                if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
                     px_t a{};
                     if constexpr (!SM) a = t0[t0r + l16];
                     float v[TX];
                     if constexpr (SM && DFE_SMEM_JIT) {   // this row's scalars, just in time: they land while the first LDS batch is in flight
-    #pragma unroll
+#pragma unroll
                         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)r * p.W + c * HW), av[c]);
                     }
                     rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
@@ -1186,12 +1159,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars (requested behind the last squared difference instead --
                                                            // inside the task row, in front of the sums -- the 42 scalars are live across the
                                                            // sums as well and the 3-channel sweeps spill: 62 / 99 scalars, 104 / 124 B of scratch)
-    #pragma unroll
+#pragma unroll
                         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
                     }
                     // deposit at once (image (r&1) was last read for row r-2, before the barrier of row r-1)
                     if (store_row && valid) {
-    #pragma unroll
+#pragma unroll
                         for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
                     }
                     if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
@@ -1215,7 +1188,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     if constexpr (SWEEP) ring_step(lpq);
                     if (store_row && validq) {
                         const int dqf = 1024 + lane_id_fresh();
-    #pragma unroll
+#pragma unroll
                         for (int x = 0; x < TQ; ++x) st[(TQ * (wave - QW0) + x) * D + dqf] = v[x];
                     }
                 }
@@ -1231,9 +1204,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         r0 = rm[m * 64], r2 = rm[((m + 2) % 6) * 64], r4 = rm[((m + 4) % 6) * 64], r5 = rm[((m + 5) % 6) * 64];
                     }
                     float e[K];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < K; ++j) {
-                        if (j % DFE_MINI_GROUP == 0) __builtin_amdgcn_sched_barrier(0);   // at most 2 x DFE_MINI_GROUP pixel reads in flight (registers)
+                        if (j % 4 == 0) __builtin_amdgcn_sched_barrier(0);   // two groups: at most 8 pixel reads in flight (registers)
                         const px_t av = ar[j], bv = lr[j];
                         if constexpr (C == 1) {
                             const float a1[1] = {av};
@@ -1247,7 +1220,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // computes for the pixel after the run are bit-identical to what that pixel's own tile holds in its image
                     float h[1], v;
                     h[0] = e[K - 1];
-    #pragma unroll
+#pragma unroll
                     for (int j = K - 2; j >= 0; --j) h[0] = e[j] + h[0];
                     if constexpr (K == 7) {
                         v = (r0 + r2) + (r4 + h[0]);
@@ -1256,7 +1229,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     } else {
                         rm[m * 64] = h[0];
                         v = rm[((m + 1) % K) * 64];
-    #pragma unroll
+#pragma unroll
                         for (int i = 2; i <= K; ++i) v += (i == K) ? h[0] : rm[((m + i) % K) * 64];
                     }
                     if (store_row) {
@@ -1269,14 +1242,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     }
                 }
             };
-            // order of a wave's tasks within a row (tuning): the latency-bound extra task first runs while the SIMD's other waves
-            // are busy with their main tasks, instead of alone behind them
-            if (DFE_MINI_FIRST) do_mini();
-            if (DFE_Q_FIRST) do_quarter();
+            // (order of a wave's tasks within a row: the latency-bound extra tasks in front of the main task -- so that they run
+            //  while the SIMD's other waves are busy, instead of alone behind them -- measured +-1 %)
             do_main();
             DFE_TL(2);
-            if (!DFE_Q_FIRST) do_quarter();
-            if (!DFE_MINI_FIRST) do_mini();
+            do_quarter();
+            do_mini();
             DFE_TL(3);
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
@@ -1328,13 +1299,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // waves copying, the four quarter-task waves -- the critical path of the sweep -- started the next row up to 0.2 us
                 // late (per-CU row step 1.48 us against 1.27 us of compute, measured with the memory unsaturated); the copier waves
                 // have that much slack before the next barrier.
-                // (Fused build: all waves copy -- they are all held by the scan before it, and fewer copiers then only take
-                //  longer: 298 against 290 us.)
-                constexpr int CW0 = (SWEEP && DFE_DMA_EXP) ? LW - DFE_DMA_EXP : ROLES ? DFE_ROLES_CW0 : FUSE ? 0 : DFE_CW0;   // first copier wave
+                // (Fused build, one channel or static tiles: all waves copy -- they are all held by the scan before it, and fewer
+                //  copiers then only take longer: 298 against 290 us.  Fused 3-channel sweep: ROLES above -- the copy waves are 8..14;
+                //  6 / 5 / 4 of them measured 269 / 277 / 297 against 258 us, scan waves taking one or two pieces each 289 / 294 us,
+                //  only the four scan waves without a quarter task taking them 270 us.)
+                constexpr int CW0 = ROLES ? TX : FUSE ? 0 : DFE_CW0;          // first copier wave
                 constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
-                // ROLES: NHW of the scan waves without a quarter task (the last ones) take NPH pieces per thread off the copy waves
-                constexpr int NHW = ROLES ? DFE_HELP_WAVES : 0, NPH = ROLES ? DFE_HELP_PIECES : 0, HL0 = TX - NHW;
-                if (store_row && (wave >= CW0 || (NHW > 0 && NPH > 0 && wave >= HL0)) && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
+                if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
                     int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
@@ -1378,21 +1349,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
-                    if constexpr (NHW > 0 && NPH > 0) {
-                        // helper threads: pieces [0, NA) at stride NHW * 64; copy waves: the rest at stride STR (wave-uniform choice)
-                        constexpr int NTOT = (TX * 1096 + 32) / 4, NA = NPH * NHW * 64;
-                        constexpr int NPCC = (NTOT - NA + STR - 1) / STR, NPC = NPH > NPCC ? NPH : NPCC;
-                        const bool hw = wave < CW0;
-                        const int pb = hw ? tj + (CW0 - HL0) * 64 : NA + tj, ps = hw ? NHW * 64 : STR, pn = hw ? NPH : NPCC, pend = hw ? min(NA, nbody4) : nbody4;
-                        f4_t val[NPC];
-#pragma unroll
-                        for (int i = 0; i < NPC; ++i)
-                            if (i < pn) val[i] = sb[min(pb + i * ps, nbody4 - 1)];
-#pragma unroll
-                        for (int i = 0; i < NPC; ++i)
-                            if (i < pn && pb + i * ps < pend)
-                                asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(pb + i * ps) * 16u), "v"(val[i]), "s"(gb) : "memory");
-                    } else {
                     constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
                     constexpr int GP = NPC <= 4 ? NPC : 6;                        // pieces in flight per thread
 #pragma unroll
@@ -1406,7 +1362,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                             if (g0 + i < NPC)
                                 if (tj + (g0 + i) * STR < nbody4)
                                     asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + (g0 + i) * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
-                    }
                     }
                     }
                     if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
