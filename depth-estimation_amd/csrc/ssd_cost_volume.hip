@@ -221,7 +221,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r2.9"
+#define DFE_CV_KERNEL_REV "cv-r2.10"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -239,6 +239,9 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
     } while (0)
 #else
 #define DFE_TL(i) do { } while (0)
+#endif
+#ifndef DFE_ROLES_STATIC
+#define DFE_ROLES_STATIC 1
 #endif
 #ifndef DFE_ROLES
 #define DFE_ROLES 1
@@ -842,7 +845,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // path, 2.7 of 5.1 kilocycles of a VGA row spent before the slowest waves began their main task (timeline, DFE_TIMELINE).
     // (3-channel frames only: with one channel the main task is half as long and the all-waves scan of the plain layout
     //  wins, VGA luminance 215 against 254 us)
-    constexpr bool ROLES = FUSE && SWEEP && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
+    constexpr bool ROLES = FUSE && (SWEEP || DFE_ROLES_STATIC) && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
+    // the last wave neither scans nor copies: in the column sweep it refills the rings, with roles it carries the mini task
+    constexpr bool HAS_XW = SWEEP || ROLES;
     constexpr int QW0 = 0;                       // first wave with a quarter task (on the copy waves, 8..11, instead: 265 against 258 us)
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
@@ -998,7 +1003,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // the mini task's wave: the first one behind the quarter tasks; 3-channel column sweeps: the wave that refills the rings
     // (it neither scans nor copies; with the mini task on wave 4, behind that wave's main task and scan, it was the last one
     //  at the barrier: VGA fused 258 -> 250 us, plain 228 -> 222 us)
-    constexpr int MW = (SWEEP && C == 3 && (ROLES || !FUSE)) ? LW : QW0 + NQW;
+    constexpr int MW = (C == 3 && (ROLES || (SWEEP && !FUSE))) ? LW : QW0 + NQW;
     const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
@@ -1304,8 +1309,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 //  6 / 5 / 4 of them measured 269 / 277 / 297 against 258 us, scan waves taking one or two pieces each 289 / 294 us,
                 //  only the four scan waves without a quarter task taking them 270 us.)
                 constexpr int CW0 = ROLES ? TX : FUSE ? 0 : DFE_CW0;          // first copier wave
-                constexpr int NCW = (SWEEP ? LW : NW) - CW0;                 // copier waves
-                if (store_row && wave >= CW0 && (!SWEEP || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
+                constexpr int NCW = (HAS_XW ? LW : NW) - CW0;                // copier waves
+                if (store_row && wave >= CW0 && (!HAS_XW || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
                     int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
