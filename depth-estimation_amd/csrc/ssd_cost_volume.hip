@@ -240,6 +240,9 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #else
 #define DFE_TL(i) do { } while (0)
 #endif
+#ifndef DFE_LEAD_FROM_IMAGE
+#define DFE_LEAD_FROM_IMAGE 1
+#endif
 #ifndef DFE_ROLES_STATIC
 #define DFE_ROLES_STATIC 1
 #endif
@@ -1126,6 +1129,18 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         }
         if (lsc < 2 && xx >= nover)
             fa.part[(long long)lsc * fa.Ptot + pgp + xx] = lsc == 0 ? make_float2(__int_as_float(vmin), __int_as_float(idx)) : make_float2(__int_as_float(0x7f800000), 0.f);
+        if (DFE_LEAD_FROM_IMAGE && !(DFE_ABLATE & 192)) {
+            // the pixel's lead cells (lanes 0..15) and its centre cell (lane 16) leave from the image too: ONE store of this wave
+            // instead of eight dword stores of wave 0 and two of wave 8 from their registers in front of the barrier -- a wave's
+            // own stores issue one behind the other, and wave 0 also carries a quarter task
+            static_assert(!ROLES || DC == 1089, "centre cell 544");
+            const float val = stp[xx * D + (lsc < DFE_LEAD ? lsc : 544)];
+            const float *lb = fa.lead + (pgp + xx) * DFE_LEAD, *cb = fa.centre + pgp + xx;   // (scalar bases, 32-bit lane offsets: no per-lane pointers)
+            if (xx >= nover) {
+                if (lsc < DFE_LEAD) asm volatile("global_store_dword %0, %1, %2" ::"v"((unsigned)lsc * 4u), "v"(val), "s"(lb) : "memory");
+                if (lsc == DFE_LEAD) asm volatile("global_store_dword %0, %1, %2" ::"v"(0u), "v"(val), "s"(cb) : "memory");
+            }
+        }
     };
     long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
     long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
@@ -1172,7 +1187,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
                         for (int x = 0; x < TX; ++x) st[x * D + d] = v[x];
                     }
-                    if constexpr (FUSE) {   // centre cell and lead cells leave from registers; the minimum comes from the image
+                    if constexpr (FUSE && !(ROLES && DFE_LEAD_FROM_IMAGE)) {   // centre cell and lead cells leave from registers; the minimum comes from the image
                         if (store_row) {
                             int lf = lane;
                             asm volatile("" : "+v"(lf));
