@@ -91,3 +91,18 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"dfe_oracle|libdfe_oracle|from tests|import tests|oracle/", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, "product files reference the oracle: %s" % bad
+
+
+def test_committed_traffic_summary_belongs_to_the_committed_kernel():
+    """profiles/traffic_vga.json (PMC-derived HBM bytes that bench.py reports as roofline.traffic) is tagged with the kernel
+    revision it was measured on; bench.py drops it when the library reports another one.  A kernel change that bumps
+    DFE_CV_KERNEL_REV without new PMC passes shows up here instead of as a silent `"traffic": null` in the bench line."""
+    import json
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "depth-estimation_amd", "csrc", "ssd_cost_volume.hip")).read()
+    rev = re.search(r'#define DFE_CV_KERNEL_REV "([^"]+)"', src).group(1)
+    traffic = json.load(open(os.path.join(root, "profiles", "traffic_vga.json")))
+    assert traffic["kernel_rev"] == rev, "profiles/traffic_vga.json is from %s, the source is %s: rerun tools/pmc_cv.sh + tools/make_traffic.py" % (traffic["kernel_rev"], rev)
+    assert traffic["hbm_bytes_per_launch"] >= traffic["algorithmic_bytes_per_launch"]
