@@ -532,6 +532,20 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                             const float sum = wave_sum_f32_ordered(e);
                             if (valid) store_uniform_base(prow + (long long)x * D * 4, dbytes, e * (1.0f / sum));
                         }
+                    } else if (!FUSE && TX == 8 && store_row && D == 64 && p.stage_off > 0) {
+                        // one-chunk windows (the pyramid's 8 x 8): the task row is 8 pixels x 256 B = 2 KB of contiguous volume.
+                        // Through a 2-KB LDS scratch of this wave it leaves as two dwordx4 stores (1 KB each) instead of eight
+                        // dword stores of 256 B: a wave's stores issue one behind the other, and the launch is bound by that.
+                        float *xp = reinterpret_cast<float *>(dfe_smem + p.stage_off) + wave * (TX * 64);
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) xp[x * 64 + lane] = vrow[x];
+                        const f4_t lo = *reinterpret_cast<const f4_t *>(xp + 4 * lane), hi = *reinterpret_cast<const f4_t *>(xp + 256 + 4 * lane);
+                        // (non-temporal when the call's volumes exceed what the caches hold -- 1080p, 4 scales: 0.570 -> 0.471 ms per
+                        //  pair; at VGA, where the cascade kernels find the 110 MB still cached, the hint costs 6 %)
+                        if (p.stage_len)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx4 %0, %3, %2 offset:1024 nt" ::"v"((unsigned)lane * 16u), "v"(lo), "s"(orow), "v"(hi) : "memory");
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:1024" ::"v"((unsigned)lane * 16u), "v"(lo), "s"(orow), "v"(hi) : "memory");
                     } else if (store_row) {
 #pragma unroll
                         for (int x = 0; x < TX; ++x)
@@ -1635,6 +1649,9 @@ __global__ __launch_bounds__(256) void cv_to_half_kernel(const float *__restrict
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) out[e] = (_Float16)(in[e] * scale);
 }
 
+// volumes of one call above this size leave the tiled multi kernel with the non-temporal hint (they will not be found in the
+// 256-MB memory-side cache by the cascade kernels anyway; below it the cascade's reads hit what plain stores left there)
+constexpr size_t kXposeNtBytes = (size_t)160 << 20;
 // the volumes of n independent frame pairs with windows of at most one chunk (C = 3, k = 7) in one launch; *handled = false
 // when some pair has no plan with the common block shape (the caller then launches them one by one)
 template <int NQ>
@@ -1658,6 +1675,15 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         if (m.gx[i] > gxm) gxm = m.gx[i];
         if (m.gy[i] > gym) gym = m.gy[i];
         if (pl.lds_bytes > lds) lds = pl.lds_bytes;
+    }
+    if (hWin * wWin == 64 && !getenv("DFE_NO_XPOSE")) {   // a 2-KB transpose scratch per wave behind the largest tile (see the kernel's store path)
+        const size_t xoff = (lds + 255) / 256 * 256;
+        size_t vol_bytes = 0;
+        for (int i = 0; i < n; ++i) vol_bytes += (size_t)m.p[i].Ho * m.p[i].Wo * 64 * sizeof(float);
+        int nt = vol_bytes > kXposeNtBytes;
+        if (const char *e = getenv("DFE_XPOSE_NT")) nt = atoi(e) != 0;   // tuning
+        for (int i = 0; i < n; ++i) { m.p[i].stage_off = (int)xoff; m.p[i].stage_len = nt; }
+        lds = xoff + (size_t)NW * TX * 64 * sizeof(float);
     }
     // The soft-min epilogue makes a block ~3x longer.  It pays when the first (largest) pair has enough blocks to hide the
     // other pairs' few long ones behind (1080p: 3600 blocks, -5.5 % on the step; 720p: 1600 blocks, -5.6 %); at VGA (540
