@@ -618,6 +618,48 @@ __device__ __forceinline__ void px_load64(const float *__restrict__ src_, float 
         v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
     }
 }
+// The same load for the 64 pixels of a wave, coalesced: a lane's own 256 B sit 256 B from its neighbour's, so the plain form
+// touches 64 cache lines with every instruction.  Here the wave reads its 16 KB front to back (eight lanes per 128-B line),
+// parks them in an LDS scratch of 9 float4 per pixel and half window (one float4 of padding: conflict-free on the way out),
+// and every lane picks up its own pixel.  No barrier: the scratch belongs to the wave, and a wave's LDS operations execute
+// in order.  `first`: the wave's first pixel, `P`: pixels in the plane (lanes past the end still help loading).
+__device__ __forceinline__ void px_load64_staged(const float *__restrict__ plane, long long first, long long P, int lane, float4 *scr, float (&v)[64]) {
+    const float4 *src = reinterpret_cast<const float4 *>(plane) + first * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 t[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int g = jj * 64 + lane, q = g >> 3, w = g & 7;
+            t[jj] = first + q < P ? src[q * 16 + h * 8 + w] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int g = jj * 64 + lane, q = g >> 3, w = g & 7;
+            scr[q * 9 + w] = t[jj];
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float4 u = scr[lane * 9 + w];
+            v[h * 32 + 4 * w] = u.x; v[h * 32 + 4 * w + 1] = u.y; v[h * 32 + 4 * w + 2] = u.z; v[h * 32 + 4 * w + 3] = u.w;
+        }
+    }
+}
+// ... and the way back (the cascaded window a coarser scale leaves for its child)
+__device__ __forceinline__ void px_store64_staged(float *__restrict__ plane, long long first, long long P, int lane, float4 *scr, const float (&v)[64]) {
+    float4 *dst = reinterpret_cast<float4 *>(plane) + first * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) scr[lane * 9 + w] = make_float4(v[h * 32 + 4 * w], v[h * 32 + 4 * w + 1], v[h * 32 + 4 * w + 2], v[h * 32 + 4 * w + 3]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int g = jj * 64 + lane, q = g >> 3, w = g & 7;
+            const float4 u = scr[q * 9 + w];
+            if (first + q < P) dst[q * 16 + h * 8 + w] = u;
+        }
+    }
+}
 // Arg-max over a ring scale's 48 classes (see the comment in the kernel): (value, 0-based class)
 __device__ __forceinline__ void px_ring_best(const float (&v)[64], int cls_base, float &fv, int &fi) {
     constexpr int ORD[48] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,      // top d x maxw
@@ -639,10 +681,15 @@ __device__ __forceinline__ void px_ring_best(const float (&v)[64], int cls_base,
 template <bool FINEST, bool INLINE>
 __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, DecodeTab dt) {
 #pragma clang fp contract(off)
+    __shared__ float4 stage[4][64 * 9];
     const long long P = (long long)a.Hs * a.Ws;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= P) return;
-    const int y = (int)(p / a.Ws), x = (int)(p - (long long)y * a.Ws);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long wfirst = (long long)blockIdx.x * 256 + wv * 64;      // the wave's first pixel
+    if (wfirst >= P) return;                                             // (wave-uniform)
+    const bool live = p < P;                                             // lanes past the end help with the staged loads / stores
+    const long long pc_ = live ? p : P - 1;
+    const int y = (int)(pc_ / a.Ws), x = (int)(pc_ - (long long)y * a.Ws);
     float v[64];
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -657,7 +704,7 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
             for (int c = 0; c < 4; ++c) par[4 * r + c] = v[(2 + r) * 8 + 2 + c];
         px_ring_best(v, a.pcls_base, bv, bi);       // (the coarsest scale has no chain above it: its best is its own)
     }
-    px_load64(a.cost + p * 64, v);
+    px_load64_staged(a.cost, wfirst, P, lane, stage[wv], v);
     px_softmin64(v);
     if (INLINE || a.pcasc) {                                           // (launch-uniform)
         if constexpr (!INLINE) {
@@ -697,11 +744,10 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
         if (fv >= bv) { bv = fv; bi = fi; }
     }
     if constexpr (!FINEST) {
-        float4 *dst = reinterpret_cast<float4 *>(a.casc + p * 64);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) dst[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-        a.best[p] = make_float2(bv, __int_as_float(bi));
+        px_store64_staged(a.casc, wfirst, P, lane, stage[wv], v);
+        if (live) a.best[p] = make_float2(bv, __int_as_float(bi));
     } else {
+        if (!live) return;
         int id = bi + 1;
         const int mc = (a.middle - 1) & 63;
         float cen = 0.f;
