@@ -131,7 +131,7 @@ __device__ __forceinline__ void softmin_body(const float *__restrict__ cost, lon
             for (int i = 0; i < NPX; ++i) {
                 if (p0 + i >= P) break;                                   // wave-uniform
                 const float m = wave_max_f32(on ? -c[i] : -INFINITY);
-                const float e = on ? expf(-c[i] - m) : 0.f;
+                const float e = on ? dfe_exp_nonpos(-c[i] - m) : 0.f;
                 const float sum = wave_sum_f32_ordered(e);
                 if (on) prob[(p0 + i) * N + lane] = e * (1.0f / sum);
             }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void softmin_body(const float *__restrict__ cost, lon
         for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         float s = 0.f;
         for (int n = lane; n < N; n += 64) {
-            float e = expf(-c[n] - m);
+            float e = dfe_exp_nonpos(-c[n] - m);
             o[n] = e;
             s += e;
         }
@@ -350,7 +350,7 @@ __device__ __forceinline__ void cascade_inputs_pow2(const CascadeGeom &g, const 
             for (int j = 0; j < cnt; ++j) {
                 const float c = v[j];
                 const float m = wave_max_f32(on ? -c : -INFINITY);
-                const float e = on ? expf(-c - m) : 0.f;
+                const float e = on ? dfe_exp_nonpos(-c - m) : 0.f;
                 const float sum = wave_sum_f32_ordered(e);
                 v[j] = on ? e * (1.0f / sum) : 0.f;
             }
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kWaves * 64) void cascade_argmax_kernel(CascadeGeom
                 for (int i = 0; i < NPX; ++i) {
                     const float c = vin[i][0];
                     const float m = wave_max_f32(on ? -c : -INFINITY);
-                    const float e = on ? expf(-c - m) : 0.f;
+                    const float e = on ? dfe_exp_nonpos(-c - m) : 0.f;
                     const float sum = wave_sum_f32_ordered(e);
                     vin[i][0] = on ? e * (1.0f / sum) : 0.f;
                 }
@@ -599,7 +599,7 @@ __device__ __forceinline__ void px_softmin64(float (&v)[64]) {
     for (int j = 1; j < 64; ++j) m = fmaxf(m, -v[j]);
     float t[32];
 #pragma unroll
-    for (int j = 0; j < 64; ++j) v[j] = expf(-v[j] - m);
+    for (int j = 0; j < 64; ++j) v[j] = dfe_exp_nonpos(-v[j] - m);
 #pragma unroll
     for (int j = 0; j < 32; ++j) t[j] = v[j] + v[j + 32];
 #pragma unroll

@@ -528,7 +528,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                         for (int x = 0; x < TX; ++x) {
                             const float c = vrow[x];
                             const float m = wave_max_f32(valid ? -c : -INFINITY);
-                            const float e = valid ? expf(-c - m) : 0.f;
+                            const float e = valid ? dfe_exp_nonpos(-c - m) : 0.f;
                             const float sum = wave_sum_f32_ordered(e);
                             if (valid) store_uniform_base(prow + (long long)x * D * 4, dbytes, e * (1.0f / sum));
                         }
