@@ -1490,7 +1490,9 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
 // of one-segment blocks; every CU ends within one row step of the others.
 constexpr int kSweepOvh = 9;    // row steps a piece costs before its first stored row: K-1 = 6 warm-up rows + ~3 for staging the rings
 constexpr int kSweepMin = 8;    // no piece shorter than this
-constexpr double kSweepFusedPenalty = 1.08;   // fused build: cost of a swept row of the sweep relative to static tiles (VGA: 2.05 against 1.88 us)
+// fused build: cost of a swept row of the sweep relative to static tiles.  One channel (all waves scan and copy): 2.05 against
+// 1.88 us at VGA.  Three channels (scan / copy roles in both forms): 1.62 against 1.66 us.
+constexpr double kSweepFusedPenalty1 = 1.08, kSweepFusedPenalty3 = 1.0;
 static double sweep_cost(int ncols, int Ho, int B) { return ((double)ncols * Ho + (double)kSweepOvh * (ncols + B)) / B; }
 static int sweep_blocks(const dfe_ctx *ctx, int ncols, int Ho) {
     long long b = (long long)ncols * Ho / 24;          // at least ~24 rows of work per block
@@ -1603,7 +1605,7 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
     else {
         // Static tiles or the persistent column sweep?  Both cost about the same per swept row in the plain build; the sweep pays
         // the K-1 warm-up rows once per piece and ends all CUs together, so the smaller count of row steps per CU wins.  In the
-        // fused build a swept row of the sweep costs more (128 VGPRs + spilled scalars), DFE_SWEEP_FUSED_PENALTY.
+        // fused one-channel build a swept row of the sweep costs more (kSweepFusedPenalty1).
         const int Ho = H - K + 1 - hWin + 1, Wo = W - K + 1 - wWin + 1;
         double cost_static = 1e30;
         ty = rowimg_pick_ty<C, K, TX>(ctx, H, W, plane, hWin, wWin, &cost_static);
@@ -1611,7 +1613,7 @@ static int launch_cv_rowimg(dfe_ctx *ctx, const float *I0, const float *I1, int 
             const int ncols = dfe_cdiv(Wo, TX);
             const int ka = FUSE ? 0 : sweep_aligned_k(ctx, ncols, Ho);
             const double cost_sweep = ka ? dfe_cdiv(Ho, ka) + K - 1 : sweep_cost(ncols, Ho, sweep_blocks(ctx, ncols, Ho));
-            if (cost_sweep * (FUSE ? kSweepFusedPenalty : 1.0) < cost_static) {
+            if (cost_sweep * (FUSE ? (C == 3 ? kSweepFusedPenalty3 : kSweepFusedPenalty1) : 1.0) < cost_static) {
                 int rc = launch_cv_rowimg_sweep<C, K, TX, FUSE>(ctx, I0, I1, H, W, plane, hWin, wWin, out, fa, handled);
                 if (rc != DFE_OK || *handled) return rc;
             }
