@@ -46,6 +46,12 @@ PYRAMIDS = {
     "vga-pyramid": (480, 640, 3, 7, 8, 8, (1, 2, 4)),
     "720p-pyramid": (720, 1280, 3, 7, 8, 8, (1, 2, 4, 8)),
     "1080p-pyramid": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
+    # BASELINE.json configs[4]: 3840x2160, 5-level pyramid, fp16 cost volumes (dfe_multiscale_flow_pair_f16, scale 1: frames / 64);
+    # the *-f16 variants of the smaller frames are there to compare with their fp32 lines
+    "4k-pyramid-f16": (2160, 3840, 3, 7, 8, 8, (1, 2, 4, 8, 16)),
+    "4k-pyramid": (2160, 3840, 3, 7, 8, 8, (1, 2, 4, 8, 16)),
+    "1080p-pyramid-f16": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
+    "vga-pyramid-f16": (480, 640, 3, 7, 8, 8, (1, 2, 4)),
 }
 # BASELINE.json configs[2]: 1280x720 radial (polar-warped) flow: C2P warp of both frames around the epipole, the default
 # separable filter stack {{3,1,17,5},{5,17,1,10}}, SpatialRadialMatching(15), arg-min, P2C warp, flow2depth, through
@@ -228,21 +234,28 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
     lib = d.lib()
     rr = (C.c_int32 * len(ratios))(*ratios)
 
+    f16 = args.workload.endswith("-f16")
+
     def step():
+        if f16:
+            ctx.check(lib.dfe_multiscale_flow_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, k, maxh, maxw, rr, len(ratios), 1.0,
+                                                      flow.data_ptr(), None))
+            return
         ctx.check(lib.dfe_multiscale_flow_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, k, maxh, maxw, rr, len(ratios),
                                                   flow.data_ptr(), None))
 
     elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize)
     if rank == 0:
-        balg = 2 * Cc * Hp * Wp * 4 + sum((Hp // r) * (Wp // r) * maxh * maxw * 4 for r in ratios)
+        balg = 2 * Cc * Hp * Wp * 4 + sum((Hp // r) * (Wp // r) * maxh * maxw * (2 if f16 else 4) for r in ratios)
         step_s = elapsed / args.steps
         print(json.dumps({
             "metric": "Mpixels/s dense flow, %dx%d pair, %d-level pyramid, 7x7 patch, %dx%d window per scale" % (W, H, len(ratios), maxh, maxw),
             "value": round(world * args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, 7x7 raw-patch SSD over %dx%d, "
-                                   "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (W, H, Cc, list(ratios), maxh, maxw),
+            "vs_baseline": None, "dtype": "f32 sums, f16 volumes" if f16 else "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, 7x7 raw-patch SSD over %dx%d%s, "
+                                   "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (W, H, Cc, list(ratios), maxh, maxw,
+                                                                                                             " stored as fp16" if f16 else ""),
                        "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "whole step (prep, volumes, one cascade launch per scale)", "achieved": round(balg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(balg / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "dfe_radial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_cascade_flow_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfe_multiscale_flow_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_multiscale_flow_pair_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "dfe_cascading_add_backward_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dfe_cascade_ring_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p] + [C.c_int] * 5 + [C.c_void_p]),
     "dfe_polar_grid_c2p_f32": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),

@@ -69,7 +69,7 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 // prob (may be NULL): per pair, non-null = leave soft-min probabilities there instead of the costs in out[i] -- if the
 // launcher finds that worthwhile for the shape (*prob_used)
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used);
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale = 0.f);
 int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
 
 #define DFE_HIP(ctx, expr)                                                              \

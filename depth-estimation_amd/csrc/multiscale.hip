@@ -588,6 +588,7 @@ struct CascadePxArgs {
     int cls_base;             // scales > 1: 0-based class id of the ring's first cell (g.base[scale])
     const float *pcost;       // INLINE: raw costs of the (coarsest) parent scale
     int pcls_base;            // INLINE: its class base
+    float inv_scale;          // H16: cost and pcost are half volumes holding half(cost * scale); inv_scale = 1 / scale
 };
 
 // soft-min of the 64 costs in v (in place): p = e / sum, e = expf(-c - max(-c)), the sum in the association order of
@@ -645,6 +646,39 @@ __device__ __forceinline__ void px_load64_staged(const float *__restrict__ plane
         }
     }
 }
+// fp16 volumes (dfe_multiscale_flow_pair_f16): the stored value is half(cost * scale); the cascade works on
+// float(stored) * inv_scale in fp32 registers, exactly as if the fp32 volume had been rounded to half precision in place.
+__device__ __forceinline__ void px_unpack8h(const uint4 &t, float inv, float *v) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    union { uint4 u; h2_t h[4]; } c;
+    c.u = t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = (float)c.h[i][0] * inv; v[2 * i + 1] = (float)c.h[i][1] * inv; }
+}
+__device__ __forceinline__ void px_load64_h(const void *__restrict__ src_, float inv, float (&v)[64]) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(src_);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) px_unpack8h(src[j], inv, &v[8 * j]);
+}
+// the wave's 64 windows = 8 KB of halves, front to back (eight lanes per 128-B window), through the same LDS scratch
+__device__ __forceinline__ void px_load64_staged_h(const void *__restrict__ plane, long long first, long long P, int lane, float4 *scr_, float inv,
+                                                   float (&v)[64]) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(plane) + first * 8;
+    uint4 *scr = reinterpret_cast<uint4 *>(scr_);
+    uint4 t[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int g = jj * 64 + lane, q = g >> 3, w = g & 7;
+        t[jj] = first + q < P ? src[q * 8 + w] : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int g = jj * 64 + lane, q = g >> 3, w = g & 7;
+        scr[q * 9 + w] = t[jj];
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) px_unpack8h(scr[lane * 9 + w], inv, &v[8 * w]);
+}
 // ... and the way back (the cascaded window a coarser scale leaves for its child)
 __device__ __forceinline__ void px_store64_staged(float *__restrict__ plane, long long first, long long P, int lane, float4 *scr, const float (&v)[64]) {
     float4 *dst = reinterpret_cast<float4 *>(plane) + first * 16;
@@ -678,7 +712,7 @@ __device__ __forceinline__ void px_ring_best(const float (&v)[64], int cls_base,
 // INLINE: the coarser scale is the coarsest one and is not launched at all: every lane recomputes its parent pixel's window
 // from the raw costs (a.pcost) with exactly the parent kernel's operations -- four lanes repeat the same ~1300 instructions,
 // which is cheaper than a launch of its own for a scale of a few hundred waves (VGA scale 4: 75 blocks, 11 us of latency).
-template <bool FINEST, bool INLINE>
+template <bool FINEST, bool INLINE, bool H16 = false>
 __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, DecodeTab dt) {
 #pragma clang fp contract(off)
     __shared__ float4 stage[4][64 * 9];
@@ -696,7 +730,8 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
     float par[16];
     const long long pp = (long long)(y >> 1) * (a.Ws >> 1) + (x >> 1);
     if constexpr (INLINE) {
-        px_load64(a.pcost + pp * 64, v);
+        if constexpr (H16) px_load64_h(reinterpret_cast<const _Float16 *>(a.pcost) + pp * 64, a.inv_scale, v);
+        else px_load64(a.pcost + pp * 64, v);
         px_softmin64(v);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -704,7 +739,8 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
             for (int c = 0; c < 4; ++c) par[4 * r + c] = v[(2 + r) * 8 + 2 + c];
         px_ring_best(v, a.pcls_base, bv, bi);       // (the coarsest scale has no chain above it: its best is its own)
     }
-    px_load64_staged(a.cost, wfirst, P, lane, stage[wv], v);
+    if constexpr (H16) px_load64_staged_h(a.cost, wfirst, P, lane, stage[wv], a.inv_scale, v);
+    else px_load64_staged(a.cost, wfirst, P, lane, stage[wv], v);
     px_softmin64(v);
     if (INLINE || a.pcasc) {                                           // (launch-uniform)
         if constexpr (!INLINE) {
@@ -761,6 +797,12 @@ __global__ __launch_bounds__(256) void cascade_px_kernel(CascadePxArgs a, Decode
             a.fx[p] = (float)(short)(d & 0xffff);
         }
     }
+}
+
+// shapes without an fp16 volume kernel: the fp32 volume rounded to half precision in place, v = float(half(v * scale)) / scale
+__global__ __launch_bounds__(256) void round_half_kernel(float *__restrict__ v, long long n, float scale, float inv) {
+#pragma clang fp contract(off)
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) v[e] = (float)(_Float16)(v[e] * scale) * inv;
 }
 
 int ring_width(int maxw, int r, int rprev) { return (int)floor((double)maxw * (r - rprev) / (2.0 * r) + 0.5); }
@@ -835,9 +877,9 @@ int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     return cv_frames_dispatch(ctx, p0, p1, C, Hp, Wp, (long long)Hp * Wp, kh, kw, maxh, maxw, out);
 }
 
-int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
-                                 const int *ratios, int nratios, float *flow, int64_t *idx) {
-    DFE_ENTER(ctx);
+// f16_scale != 0: every scale's volume is stored as half(cost * f16_scale) (dfe_multiscale_flow_pair_f16)
+static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                const int *ratios, int nratios, float *flow, int64_t *idx, float f16_scale) {
     DFE_REQUIRE(ctx, I0 && I1 && (flow || idx), DFE_E_ARG, "dfe_multiscale_flow_pair_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && k > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_f32: bad size");
     CascadeGeom g;
@@ -863,10 +905,10 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     rc = dfe_scratch(ctx, total, &scr);
     if (rc) return rc;
     // the same call again (same buffers, shapes and arena): replay its launches as a graph
-    struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; } gkey;
+    struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; float f16; } gkey;
     memset(&gkey, 0, sizeof gkey);
     gkey.I0 = I0; gkey.I1 = I1; gkey.flow = flow; gkey.idx = idx; gkey.scr = scr;
-    gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios;
+    gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios; gkey.f16 = f16_scale;
     for (int s = 0; s < nratios; ++s) gkey.ratios[s] = ratios[s];
     const int gmode = dfe_graph_lookup(ctx, ctx->ms_graph, &gkey, sizeof gkey);
     if (gmode == 2) {
@@ -900,7 +942,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     }
     hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
     DFE_LAUNCH_CHECK(ctx);
-    bool merged = false, soft_done = false;
+    bool merged = false, soft_done = false, half_vol = false;
     const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
     // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
     bool px_path = fast && maxh == 8 && maxw == 8;
@@ -916,13 +958,29 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
             f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s];
             pr[s] = (fast && s > 0 && !px_path) ? ss.prob[s] : nullptr;
         }
-        rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, pr, &merged, &soft_done);
-        if (rc) return rc;
+        // fp16 volumes: written as halves by the volume kernel itself where the lane <-> pixel cascade will read them (8 x 8
+        // windows, C = 3, k = 7); any other shape builds fp32 volumes and rounds them to half precision in place -- same values
+        if (f16_scale != 0.f && px_path) {
+            rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, nullptr, &merged, &soft_done, f16_scale);
+            if (rc) return rc;
+            half_vol = merged;
+        }
+        if (!merged) {
+            rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, f16_scale != 0.f ? nullptr : pr, &merged, &soft_done);
+            if (rc) return rc;
+        }
     }
     for (int s = 0; s < nratios && !merged; ++s) {
         rc = cv_frames_dispatch(ctx, ps.p0[s], ps.p1[s], C, ps.Hp[s], ps.Wp[s], (long long)ps.Hp[s] * ps.Wp[s], k, k, maxh, maxw,
                                 (float *)ss.cost[s]);
         if (rc) return rc;
+    }
+    if (f16_scale != 0.f && !half_vol) {
+        for (int s = 0; s < nratios; ++s) {
+            const long long n = ss.P[s] * N;
+            hipLaunchKernelGGL(round_half_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, (float *)ss.cost[s], n, f16_scale, 1.0f / f16_scale);
+        }
+        DFE_LAUNCH_CHECK(ctx);
     }
     const int middle = ((maxh + 1) / 2 - 1) * maxw + (maxw + 1) / 2;   // yx2xMulti(0, 0)
     if (px_path) {
@@ -936,6 +994,7 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
             CascadePxArgs a{};
             a.cost = (const float *)ss.cost[s];
             a.Hs = H / r; a.Ws = W / r; a.scale = s; a.middle = middle; a.cls_base = g.base[s];
+            a.inv_scale = half_vol ? 1.0f / f16_scale : 1.0f;
             const bool inl = nratios >= 2 && s == top;
             if (inl) {
                 a.pcost = (const float *)ss.cost[s + 1];
@@ -948,13 +1007,19 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
             if (s > 0) {
                 a.casc = (float *)((char *)scr + off_q[s]);
                 a.best = (float2 *)((char *)scr + off_b[s]);
-                if (inl) hipLaunchKernelGGL((cascade_px_kernel<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                if (half_vol) {
+                    if (inl) hipLaunchKernelGGL((cascade_px_kernel<false, true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                    else hipLaunchKernelGGL((cascade_px_kernel<false, false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                } else if (inl) hipLaunchKernelGGL((cascade_px_kernel<false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
                 else hipLaunchKernelGGL((cascade_px_kernel<false, false>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
             } else {
                 a.idx = (long long *)idx;
                 a.fy = flow;
                 a.fx = flow ? flow + (size_t)H * W : nullptr;
-                if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                if (half_vol) {
+                    if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                    else hipLaunchKernelGGL((cascade_px_kernel<true, false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
+                } else if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
                 else hipLaunchKernelGGL((cascade_px_kernel<true, false>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
             }
         }
@@ -997,6 +1062,19 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
     };
     if (gmode == 1) return dfe_graph_finish(ctx, ctx->ms_graph, launch_all());
     return launch_all();
+}
+
+int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                 const int *ratios, int nratios, float *flow, int64_t *idx) {
+    DFE_ENTER(ctx);
+    return multiscale_flow_pair(ctx, I0, I1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx, 0.f);
+}
+
+int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                 const int *ratios, int nratios, float scale, float *flow, int64_t *idx) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, scale > 0.f && scale < INFINITY, DFE_E_ARG, "dfe_multiscale_flow_pair_f16: scale=%g must be positive", (double)scale);
+    return multiscale_flow_pair(ctx, I0, I1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx, scale);
 }
 
 int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {

@@ -187,6 +187,7 @@ struct CvTiledArgs {
     int sw_ovh;        // column sweep: cost of starting a piece, in row steps (warm-up rows + ring staging)
     int sw_min;        // column sweep: a piece is never shorter than this many output rows
     float scale;       // fp16 volume: stored value = cost * scale (2^-8 keeps 147 * 255^2 inside the half range)
+    int f16 = 0;       // tiled multi kernel (pyramid volumes): out is a half volume, out[..] = half(cost * scale)
 };
 
 // Persistent column sweep: the (column, output row) grid is walked column-major as one linear sequence of ncols*Ho row
@@ -532,6 +533,26 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                             const float sum = wave_sum_f32_ordered(e);
                             if (valid) store_uniform_base(prow + (long long)x * D * 4, dbytes, e * (1.0f / sum));
                         }
+                    } else if (SOFT && TX == 8 && store_row && D == 64 && p.stage_off > 0 && p.f16) {
+                        // fp16 pyramid volume: the task row is 8 pixels x 128 B = 1 KB of contiguous volume -- through the wave's
+                        // transpose scratch a lane picks up 8 adjacent cells, converts them (cost * scale, round to nearest even:
+                        // v_cvt_f16_f32, not the truncating pkrtz) and the row leaves as ONE dwordx4 store per lane
+                        float *xp = reinterpret_cast<float *>(dfe_smem + p.stage_off) + wave * (TX * 64);
+#pragma unroll
+                        for (int x = 0; x < TX; ++x) xp[x * 64 + lane] = vrow[x];
+                        const f4_t lo = *reinterpret_cast<const f4_t *>(xp + 8 * lane), hi = *reinterpret_cast<const f4_t *>(xp + 8 * lane + 4);
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        union { h2_t h[4]; f4_t v; } u;
+                        const float sc = p.scale;
+                        u.h[0] = h2_t{(_Float16)(lo[0] * sc), (_Float16)(lo[1] * sc)};
+                        u.h[1] = h2_t{(_Float16)(lo[2] * sc), (_Float16)(lo[3] * sc)};
+                        u.h[2] = h2_t{(_Float16)(hi[0] * sc), (_Float16)(hi[1] * sc)};
+                        u.h[3] = h2_t{(_Float16)(hi[2] * sc), (_Float16)(hi[3] * sc)};
+                        const char *orow_h = (const char *)out + ((long long)y * p.Wo + xt) * (D * 2);
+                        if (p.stage_len)
+                            asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"((unsigned)lane * 16u), "v"(u.v), "s"(orow_h) : "memory");
+                        else
+                            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)lane * 16u), "v"(u.v), "s"(orow_h) : "memory");
                     } else if (!FUSE && TX == 8 && store_row && D == 64 && p.stage_off > 0) {
                         // one-chunk windows (the pyramid's 8 x 8): the task row is 8 pixels x 256 B = 2 KB of contiguous volume.
                         // Through a 2-KB LDS scratch of this wave it leaves as two dwordx4 stores (1 KB each) instead of eight
@@ -1658,7 +1679,7 @@ constexpr size_t kXposeNtBytes = (size_t)160 << 20;
 // when some pair has no plan with the common block shape (the caller then launches them one by one)
 template <int NQ>
 static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, const int *H, const int *W,
-                                     int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used) {
+                                     int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale) {
     constexpr int C = 3, K = 7, TX = 8, NT = 4, NW = 4;
     CvTiledMulti m;
     size_t lds = 0;
@@ -1678,10 +1699,15 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         if (m.gy[i] > gym) gym = m.gy[i];
         if (pl.lds_bytes > lds) lds = pl.lds_bytes;
     }
-    if (hWin * wWin == 64 && !getenv("DFE_NO_XPOSE")) {   // a 2-KB transpose scratch per wave behind the largest tile (see the kernel's store path)
+    const bool xpose = hWin * wWin == 64 && !getenv("DFE_NO_XPOSE");
+    if (f16_scale != 0.f && !xpose) return DFE_OK;   // (the fp16 store path is the transposed one; the caller converts otherwise)
+    if (xpose) {   // a 2-KB transpose scratch per wave behind the largest tile (see the kernel's store path)
         const size_t xoff = (lds + 255) / 256 * 256;
         size_t vol_bytes = 0;
-        for (int i = 0; i < n; ++i) vol_bytes += (size_t)m.p[i].Ho * m.p[i].Wo * 64 * sizeof(float);
+        for (int i = 0; i < n; ++i) {
+            vol_bytes += (size_t)m.p[i].Ho * m.p[i].Wo * 64 * (f16_scale != 0.f ? 2 : sizeof(float));
+            if (f16_scale != 0.f) { m.p[i].f16 = 1; m.p[i].scale = f16_scale; }
+        }
         int nt = vol_bytes > kXposeNtBytes;
         if (const char *e = getenv("DFE_XPOSE_NT")) nt = atoi(e) != 0;   // tuning
         for (int i = 0; i < n; ++i) { m.p[i].stage_off = (int)xoff; m.p[i].stage_len = nt; }
@@ -1690,7 +1716,7 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
     // The soft-min epilogue makes a block ~3x longer.  It pays when the first (largest) pair has enough blocks to hide the
     // other pairs' few long ones behind (1080p: 3600 blocks, -5.5 % on the step; 720p: 1600 blocks, -5.6 %); at VGA (540
     // blocks) those long blocks set the launch time and the separate soft-min launch is faster (0.119 against 0.134 ms).
-    bool use_prob = prob && m.gx[0] * m.gy[0] >= 1000;
+    bool use_prob = prob && m.gx[0] * m.gy[0] >= 1000 && f16_scale == 0.f;
     if (const char *e = getenv("DFE_SOFT_EPILOGUE")) use_prob = prob && atoi(e) != 0;   // tuning / tests: force on (1) or off (0)
     if (!use_prob)
         for (int i = 0; i < n; ++i) m.prob[i] = nullptr;
@@ -1702,13 +1728,14 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         hipLaunchKernelGGL(kern, dim3(gxm, gym, n), dim3(NW * 64), lds, ctx->stream, m);
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = "ssd_cv_tiled_kernel";
+    ctx->last_kernel = f16_scale != 0.f ? "ssd_cv_tiled_multi_kernel_f16" : "ssd_cv_tiled_kernel";
     *handled = true;
     return DFE_OK;
 }
 
+// f16_scale != 0: out[i] are HALF volumes, out[i][..] = half(cost * f16_scale) (8 x 8 windows only: *handled = false otherwise)
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used) {
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale) {
     *handled = false;
     if (prob_used) *prob_used = false;
     if (ctx->cv_mode == 1 || ctx->cv_mode == 3 || C != 3 || k != 7 || hWin * wWin > 64 || n < 2 || n > DFE_MAX_RATIOS) return DFE_OK;
@@ -1716,10 +1743,10 @@ int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const 
     // 0.155 ms per pair (short tiles pay the K-1 warm-up rows too often, tall ones leave the coarse scales too few blocks)
     const int nq = (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5) ? ctx->cv_tyq : 4;
     switch (nq) {
-        case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
-        case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
-        case 3: return launch_cv_tiled_multi_one<3>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
-        default: return launch_cv_tiled_multi_one<4>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used);
+        case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);
+        case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);
+        case 3: return launch_cv_tiled_multi_one<3>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);
+        default: return launch_cv_tiled_multi_one<4>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);
     }
 }
 

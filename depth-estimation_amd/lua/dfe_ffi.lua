@@ -53,6 +53,7 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
 int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *out);
 int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, int64_t *idx, float *best, float *flow_y, float *flow_x);
 int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
+int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float scale, float *flow, int64_t *idx);
 int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *gradIn);
 int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, float *out);
 int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, int lpadding, int rpadding, float rmax, float alpha, float *mask);

@@ -121,10 +121,12 @@ class MultiscaleModel(Module):
         return out
 
 
-    def forwardFlow(self, input, process_full=True, one_call=True):
+    def forwardFlow(self, input, process_full=True, one_call=True, f16_scale=None):
         """model:forward(input) followed by processOutput(geometry, output, process_full) for the 'max' extraction
         without a threshold (opticalflow_model.lua:201-252), fused: the H x W x nclasses tensor is never built
-        (dfe_cascade_flow_f32).  Returns the same table: index, confidences (all 1), y, x [, full, full_confidences]."""
+        (dfe_cascade_flow_f32).  Returns the same table: index, confidences (all 1), y, x [, full, full_confidences].
+        f16_scale: the per-scale cost volumes are stored as half(cost * f16_scale) (dfe_multiscale_flow_pair_f16; the staged
+        path rounds its fp32 volumes to half precision the same way)."""
         g = self.geometry
         i0, i1 = input
         i0, i1 = _f32c(i0, "MultiscaleModel: input[1]"), _f32c(i1, "MultiscaleModel: input[2]")   # the C ABI is typed: float32 frames
@@ -146,7 +148,10 @@ class MultiscaleModel(Module):
         if one_call and kh == kw:
             # everything in one C call (dfe_multiscale_flow_pair_f32): no per-scale tensors on the host side
             flow = torch.empty((2, H, W), dtype=torch.float32, device=i0.device)
-            ctx.check(l.dfe_multiscale_flow_pair_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, kh, maxh, maxw, rr, n, ptr(flow), ptr(idx)))
+            if f16_scale:
+                ctx.check(l.dfe_multiscale_flow_pair_f16(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, kh, maxh, maxw, rr, n, float(f16_scale), ptr(flow), ptr(idx)))
+            else:
+                ctx.check(l.dfe_multiscale_flow_pair_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, kh, maxh, maxw, rr, n, ptr(flow), ptr(idx)))
             fy, fx = flow[0], flow[1]
             self.volumes, self.probs = None, None
         else:
@@ -154,6 +159,8 @@ class MultiscaleModel(Module):
             for r in self.ratios:
                 vol = torch.empty((H // r, W // r, maxh, maxw), dtype=torch.float32, device=i0.device)
                 ctx.check(l.dfe_pyramid_scale_volume_f32(ctx.handle, ptr(i0), ptr(i1), Cc, H, W, r, kh, kw, maxh, maxw, ptr(vol)))
+                if f16_scale:   # what the fp16 volume holds: half(cost * scale) read back as float(stored) * (1 / scale)
+                    vol = (vol * float(f16_scale)).to(torch.float16).to(torch.float32) * (1.0 / float(f16_scale))
                 prob = torch.empty_like(vol)
                 ctx.check(l.dfe_softmin_f32(ctx.handle, ptr(vol), vol.numel() // N, N, ptr(prob)))
                 self.volumes.append(vol)

@@ -287,6 +287,16 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
 int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k,
                                  int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
 
+/* dfe_multiscale_flow_pair_f32 with every scale's cost volume stored as IEEE half (BASELINE configs[4]: "5-level pyramid, fp16
+ * cost volume"; SURVEY 8(d): the 4K 5-level volumes are 1.6 GB in fp32).  The SSD sums are fp32; a volume holds
+ * half(cost * scale), round to nearest even, and the cascade works on float(stored) * (1 / scale) in fp32 registers: soft-min,
+ * cascade adds and arg-max are fp32 as in the f32 entry.  The result is that of the fp32 chain run on volumes rounded to half
+ * precision (11 significant bits) where they are stored.  scale: 1 for frames in [0, 1] (and up to a few units), 2^-8 for
+ * uint8-valued frames (147 * 255^2 overflows half).  8 x 8 windows with ratios 1, 2, 4, ... (C = 3, k = 7) write and read real
+ * half volumes; any other shape builds fp32 volumes and rounds them in place -- the same values. */
+int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k,
+                                 int maxh, int maxw, const int *ratios, int nratios, float scale, float *flow, int64_t *idx);
+
 /* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
 /* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
  *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];

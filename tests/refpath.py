@@ -133,7 +133,7 @@ def synth_pair(H, W, C=3, seed=0, max_flow=12, integer=True, noise_sigma=2.0):
     return f0, f1, flow, (cx, cy)
 
 
-def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios):
+def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios, f16_scale=None):
     """getModelMultiscale(...):forward + processOutput ('max', no threshold) for the identity patch filter, on the oracle:
     per ratio pyramid_scale_volume (A2) -> softmin over the window (A3) -> cascade + ring extraction (A4 + A5) -> arg-max
     with the centre tie-break (A6) -> x2yxMulti decode (A10).  opticalflow_model_multiscale.lua:134-333,
@@ -142,6 +142,9 @@ def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios):
 
     H, W = f0.shape[1:]
     vols = [orc.pyramid_scale_volume(f0, f1, r, k, k, maxh, maxw) for r in ratios]
+    if f16_scale:   # fp16 volumes (BASELINE configs[4]): the fp32 chain with half() applied where the volume is stored
+        sc, inv = np.float32(f16_scale), np.float32(1.0) / np.float32(f16_scale)
+        vols = [(v * sc).astype(np.float16).astype(np.float32) * inv for v in vols]
     probs = [orc.softmin(v.reshape(-1, maxh * maxw)).reshape(v.shape) for v in vols]
     rc, joined = orc.cascade_ring(probs, ratios, H, W, maxh, maxw)
     assert rc == 0
@@ -149,7 +152,7 @@ def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios):
     idx, best = orc.argbest_center(joined, middle, True)
     rc, y, x = orc.x2yx_multi(maxh, maxw, ratios, idx)
     assert rc == 0
-    return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle)
+    return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle, vols=vols)
 
 
 def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between=False, kinfty=0.65, alpha=1.0):

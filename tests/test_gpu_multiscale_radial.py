@@ -554,6 +554,101 @@ def test_full_size_pyramid_properties(dfe, cuda, H, W, ratios):
     assert ok[inner].mean() > 0.9
 
 
+# ------------------------------------------------------------------ fp16 pyramid volumes (BASELINE configs[4])
+def _one_call_f16(dfe, cuda, f0, f1, k, mh, mw, ratios, scale):
+    from depth_estimation_amd._lib import ratios_array
+
+    Cc, H, W = f0.shape
+    ctx = dfe.get_ctx(0)
+    rr, n = ratios_array(ratios)
+    flow = torch.empty((2, H, W), device=cuda)
+    idx = torch.empty((H, W), dtype=torch.int64, device=cuda)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx.check(dfe.lib().dfe_multiscale_flow_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, mh, mw, rr, n, scale, flow.data_ptr(), idx.data_ptr()))
+    return idx.cpu().numpy(), flow.cpu().numpy(), ctx.last_kernel()
+
+
+@pytest.mark.parametrize("ratios,mh,H,W,C,integer", [
+    ([1, 2, 4], 8, 96, 128, 3, False),
+    ([1, 2, 4, 8], 8, 96, 136, 3, False),
+    ([1, 2, 4, 8, 16], 8, 288, 512, 3, False),    # BASELINE configs[4] geometry (5 levels, 8 x 8 windows): real half volumes
+    ([1, 2, 4, 8, 16], 8, 288, 512, 3, True),     # uint8-valued frames, scale 2^-8
+    ([1, 2, 4, 8, 16], 8, 96, 144, 3, False),     # coarsest scale smaller than a tile: fp32 volumes rounded in place
+    ([1, 2, 4, 8, 16], 4, 80, 112, 3, False),     # maxhHR = 64 -> 4 x 4 windows: fp32 volumes rounded in place
+    ([1, 2, 4, 8], 16, 64, 96, 3, False),
+    ([1, 2, 4], 8, 96, 128, 1, False),            # luminance frames: no merged volume launch -> rounded in place
+])
+def test_one_call_multiscale_f16_equals_oracle_chain(dfe, cuda, ratios, mh, H, W, C, integer):
+    """dfe_multiscale_flow_pair_f16 against the ORACLE chain with half() applied where the volume is stored
+    (pyramid_scale_volume -> half(cost * scale) -> float * 1/scale -> softmin -> cascade_ring -> arg-max -> decode): tie-aware on
+    the indices (the fast volume kernel's summation order can move a cost across a half rounding boundary: such pixels have
+    their two best classes within the half quantum's effect and are counted), decode exact."""
+    f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=H + len(ratios) + mh, max_flow=min(10, 2 * ratios[-1]), noise_sigma=0)
+    if integer:
+        scale = 2.0 ** -8
+    else:
+        f0, f1, scale = f0 / np.float32(64), f1 / np.float32(64), 1.0
+    ref = rp.multiscale_flow_oracle(f0, f1, 7, mh, mh, ratios, f16_scale=scale)
+    gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, mh, mh, ratios, scale)
+    if mh == 8 and C == 3 and H // ratios[-1] >= 18 and W // ratios[-1] >= 32:
+        assert kern == "ssd_cv_tiled_multi_kernel_f16"     # the volumes really were written and read as halves
+    if integer:
+        # integer-valued frames: fp32 sums are exact in any order -> the half volumes are bit-identical to the oracle's
+        _assert_matches_oracle(gi, gflow, ref, mh, mh, ratios)
+    else:
+        # float frames: a cost that lands within an fp32 ulp of a half rounding boundary can round the other way on the device
+        # (different summation order): its soft-min changes by up to a half quantum (2^-11 relative on the cost)
+        top2 = np.sort(ref["joined"], -1)[..., -2:]
+        tie = top2[..., 1] - top2[..., 0] <= 2e-3 * np.maximum(top2[..., 1], 1e-6) + 1e-5
+        same = gi == ref["idx"]
+        assert (same | tie).all(), "%d pixels differ from the oracle outside ties" % int((~(same | tie)).sum())
+        assert (~same).mean() <= 0.02
+        rc, ey, ex = orc.x2yx_multi(mh, mh, ratios, gi)
+        assert rc == 0 and np.array_equal(gflow[0], ey.astype(np.float32)) and np.array_equal(gflow[1], ex.astype(np.float32))
+    # the fp16 result is NOT simply the fp32 one: on some pixel the rounding of the volume must have changed the class,
+    # or the two must agree almost everywhere
+    gi32, _ = _one_call(dfe, cuda, f0, f1, 7, mh, mh, ratios)
+    assert (gi32 == gi).mean() > 0.9
+
+
+def test_one_call_multiscale_f16_equals_staged_bitwise(dfe, cuda):
+    """one-call fp16 (real half volumes through ssd_cv_tiled_multi_kernel + cascade_px_kernel<H16>) == the staged HIP path with its
+    fp32 volumes rounded to half on the host side, bit for bit (same volume kernel arithmetic, same soft-min / cascade)."""
+    H, W, ratios = 288, 512, [1, 2, 4, 8, 16]
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=9, max_flow=12, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    Hp, Wp = -(-H // 16) * 16, -(-W // 16) * 16
+    gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
+    assert kern == "ssd_cv_tiled_multi_kernel_f16"
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=Hp, wImg=Wp, output_extraction_method="max")
+    staged = dfe.getModelMultiscale(geo).forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False, f16_scale=1.0)
+    assert np.array_equal(staged["index"].cpu().numpy(), gi)
+    assert np.array_equal(staged["y"].cpu().numpy(), gflow[0].astype(np.int64)) and np.array_equal(staged["x"].cpu().numpy(), gflow[1].astype(np.int64))
+
+
+def test_4k_five_level_f16_pyramid_properties(dfe, cuda):
+    """BASELINE configs[4] at its size: 3840x2160, ratios {1,2,4,8,16}, 8x8 windows, fp16 volumes.  Size-independent properties:
+    one-call == staged (volumes rounded to half on the host side) bit for bit, the planted flow is recovered within the step of the
+    scale that reaches it, and the fp16 result agrees with the fp32 one-call except on a small fraction of pixels."""
+    H, W, ratios = 2160, 3840, [1, 2, 4, 8, 16]
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=4, max_flow=12, noise_sigma=0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
+    assert kern == "ssd_cv_tiled_multi_kernel_f16"
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    staged = dfe.getModelMultiscale(geo).forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False, f16_scale=1.0)
+    assert np.array_equal(staged["index"].cpu().numpy(), gi)
+    del staged
+    gi32, gflow32 = _one_call(dfe, cuda, f0, f1, 7, 8, 8, ratios)
+    assert (gi32 == gi).mean() > 0.98
+    inner = (slice(80, H - 80), slice(80, W - 80))
+    mag = np.maximum(np.abs(flow[0]), np.abs(flow[1]))
+    tol = np.where(mag <= 3, 1, np.where(mag <= 6, 2, np.where(mag <= 12, 4, 8)))
+    for g in (gflow, gflow32):
+        ok = (np.abs(g[0] - flow[0]) < tol + 1) & (np.abs(g[1] - flow[1]) < tol + 1)
+        assert ok[inner].mean() > 0.9
+
+
 # ------------------------------------------------------------------ the radial path as a path (BASELINE configs[2])
 def _radial_setup(dfe, cuda, hImg, wImg, hIn, wIn, layers, hWin=15, seed=0):
     networkp = dict(hImg=hImg, wImg=wImg, hInput=hIn, wInput=wIn, hWin=hWin, layers=layers)

@@ -7,11 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import depth_estimation_amd as d
 from tests import refpath as rp
-from bench import WORKLOADS
+from bench import WORKLOADS, F16_WORKLOADS
 wl = sys.argv[1] if len(sys.argv) > 1 else "vga"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 what = sys.argv[3] if len(sys.argv) > 3 else os.environ.get("CV_MODE", "pair")
-H, W, C, k, hW, wW = WORKLOADS[wl]
+H, W, C, k, hW, wW = (WORKLOADS.get(wl) or F16_WORKLOADS[wl])
 f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=C, seed=0)
 dev = torch.device("cuda:0")
 t0, t1 = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
@@ -22,6 +22,17 @@ if what == "pair":
     for _ in range(n):
         ctx.check(d.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, hW, wW, cx, cy, 0.21,
                                                  flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), conf.data_ptr()))
+elif what == "pair16":   # dfe_flow_depth_pair_f16: the fp16-volume step
+    flow = torch.empty((2, H, W), device=dev)
+    depth, conf = (torch.empty((H, W), device=dev) for _ in range(2))
+    for _ in range(n):
+        ctx.check(d.lib().dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, hW, wW, cx, cy, 2.0 ** -8, None, None,
+                                                 flow.data_ptr(), depth.data_ptr(), conf.data_ptr()))
+    print("scratch arena", ctx.scratch_info() if hasattr(ctx, "scratch_info") else "")
+elif what == "build16":
+    out = torch.empty((H - k - hW + 2, W - k - wW + 2, hW, wW), device=dev, dtype=torch.float16)
+    for _ in range(n):
+        ctx.check(d.lib().dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, k, hW, wW, 2.0 ** -8, out.data_ptr()))
 else:
     out = torch.empty((H - k - hW + 2, W - k - wW + 2, hW, wW), device=dev)
     ctx.set_cost_volume_kernel(int(what))
