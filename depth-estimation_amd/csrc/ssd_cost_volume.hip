@@ -1834,8 +1834,12 @@ static int band_rows(const dfe_ctx *ctx, int Ho, int Wo, int D, int elem = (int)
     long long band = (long long)ctx->scratch_limit / row_bytes;
     if (band < 1) band = 1;
     if (band > Ho) band = Ho;
-    return (int)band;
+    // balanced: the same number of bands, rows dealt evenly (band i = rows [i Ho / nb, (i+1) Ho / nb)), so that no short last
+    // band is left over -- the fast kernels need at least a tile of rows, and the fp16 pipeline has no other kernel to fall back to
+    const long long nb = (Ho + band - 1) / band;
+    return (int)((Ho + nb - 1) / nb);
 }
+static int band_count(int Ho, int band) { return (Ho + band - 1) / band; }
 
 // One pair through build + flow extraction.  Preferred: the fused build (per-chunk minimum + first index, the centre
 // cell and the pixel's first 16 cells leave the kernel with the volume, ~210 compact bytes per pixel) + a finalize that
@@ -1870,8 +1874,9 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);   // radial/radial_opticalflow_groundtruth.lua:91
         fa.cmid = (middle - 1) >> 6; fa.lmid = (middle - 1) & 63;
     }
-    for (int r0 = 0; r0 < Ho; r0 += band) {
-        const int nr = (r0 + band <= Ho) ? band : Ho - r0;
+    const int nb = band_count(Ho, band);
+    for (int bi = 0; bi < nb; ++bi) {
+        const int r0 = (int)((long long)bi * Ho / nb), nr = (int)((long long)(bi + 1) * Ho / nb) - r0;   // (nr <= band)
         const int Hb = nr + kh - 1 + hWin - 1;
         const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
         bool fused = false;
@@ -1881,7 +1886,7 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
             rc = cv_frames_dispatch_f16(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, f16_scale, vol, &fa, &fused);
             if (rc) return rc;
             nparts = 2;
-            if (!fused) return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no fused fp16 cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d", C, kh, hWin, wWin, Ho, Wo);
+            if (!fused) return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no fused fp16 cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d (band of %d rows)", C, kh, hWin, wWin, Ho, Wo, nr);
         } else if (kh == kw) {
             fa.row_off = r0;
             rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused, &nparts);
@@ -1964,8 +1969,9 @@ int dfe_ssd_cost_volume_f16(dfe_ctx *ctx, const float *I0, const float *I1, int 
     void *scr = nullptr;
     int rc = dfe_scratch(ctx, (size_t)band * Wo * D * sizeof(float), &scr);
     if (rc) return rc;
-    for (int r0 = 0; r0 < Ho; r0 += band) {
-        const int nr = (r0 + band <= Ho) ? band : Ho - r0;
+    const int nb = band_count(Ho, band);
+    for (int bi = 0; bi < nb; ++bi) {
+        const int r0 = (int)((long long)bi * Ho / nb), nr = (int)((long long)(bi + 1) * Ho / nb) - r0;
         rc = cv_frames_dispatch(ctx, I0 + (long long)r0 * W, I1 + (long long)r0 * W, C, nr + kh - 1 + hWin - 1, W, (long long)H * W, kh, kw, hWin, wWin,
                                 (float *)scr);
         if (rc) return rc;

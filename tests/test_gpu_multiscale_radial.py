@@ -658,6 +658,29 @@ def _radial_setup(dfe, cuda, hImg, wImg, hIn, wIn, layers, hWin=15, seed=0):
     return networkp, net, f0 / np.float32(255), f1 / np.float32(255), (cx, cy)
 
 
+def test_radial_path_at_bench_size_one_call_equals_staged(dfe, cuda):
+    """The `720p-radial` bench workload (1280x720 frames, polar 720x1280, default filter stack, hWin 15): radial_match_kernel with
+    8 rows per thread and 1280-column rows, the separable filters at full width.  One call == staged module path bit for bit on
+    every output; the polar flow is a valid arg-min of the volume (first minimum - 1); expansion is outward."""
+    layers = [[3, 1, 17, 5], [5, 17, 1, 10]]
+    networkp, net, f0, f1, e2 = _radial_setup(dfe, cuda, 720, 1280, 720, 1280, layers, seed=3)
+    one = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=True, want_volume=True)
+    stg = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=False, want_volume=True)
+    hm, hOut, wOut = dfe.radial_out_shape(networkp)
+    assert tuple(one["output"].shape) == (hm, 1280, 15) and hm == 720 - 17 - 15 + 2
+    for k in ("output", "polar_flow", "flow", "depth", "confs"):
+        assert torch.equal(one[k], stg[k]), k
+    vol, pf = one["output"], one["polar_flow"]
+    am = vol.argmin(2).float()            # torch.argmin returns the first minimum on this backend only by luck: compare values instead
+    picked = vol.gather(2, pf.long().unsqueeze(2)).squeeze(2)
+    rows = slice(0, hm - 1) if float(pf[-1].abs().max()) == 0 else slice(0, hm)
+    assert torch.equal(picked[rows], vol.min(2).values[rows])
+    first = (vol == vol.min(2, keepdim=True).values).float().argmax(2).float()    # index of the first cell equal to the minimum
+    assert torch.equal(first[rows], pf[rows])
+    assert float(pf.min()) >= 0 and float(pf.max()) <= 14 and float((pf[: hm // 2] > 0).float().mean()) > 0.2
+    del am
+
+
 @pytest.mark.parametrize("layers,hIn,wIn", [
     ([[3, 1, 17, 5], [5, 17, 1, 10]], 200, 200),             # the reference's defaults (train_radial:27-33)
     ([[3, 1, 17, 5], "tanh", [5, 17, 1, 10]], 120, 136),

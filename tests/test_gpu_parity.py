@@ -9,6 +9,8 @@ COST_ATOL_FRAC below) and its arg-min may differ only where the two best costs a
 import math
 import os
 
+from ctypes import byref, c_double as C_double, c_int as C_int
+
 import numpy as np
 import pytest
 import torch
@@ -755,6 +757,137 @@ def test_flow_depth_pair_f16_indices_identical_to_f32_path(dfe, cuda, H, W, C):
         assert np.array_equal(idx16.cpu().numpy(), ref["idx"]) and np.array_equal(best16.cpu().numpy(), ref["best"])
     with pytest.raises(dfe.DfeError):   # no fused fp16 kernel for a 9x9 window: the caller takes the fp32 path
         ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, 9, 9, cx, cy, 2.0 ** -8, None, None, flow16.data_ptr(), None, None))
+
+
+def test_flow_depth_pair_f16_multiband_equals_oracle(dfe, cuda):
+    """dfe_flow_depth_pair_f16 with the scratch arena limited so that the fp16 volume is built in several row bands (the path the
+    4K workload takes: two bands under the default 16-GiB limit) -- idx / best against the oracle, flow / depth against the
+    one-band fp32 pipeline, and the band split itself: balanced, so no short last band is left for which the fp16 pipeline
+    would have no kernel."""
+    H, W, C, k, win = 131, 140, 3, 7, 33
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=C, seed=21, max_flow=10)
+    Ho, Wo = H - k - win + 2, W - k - win + 2
+    ref = rp.dense_flow_oracle(f0, f1, win, win, k, k)
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    flow32 = torch.empty((2, H, W), device=cuda)
+    sc, d32, c32 = (torch.empty((H, W), device=cuda) for _ in range(3))
+    ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 0.21, flow32.data_ptr(), sc.data_ptr(),
+                                          d32.data_ptr(), c32.data_ptr()))
+    vol16 = Ho * Wo * win * win * 2
+    for limit in (vol16 // 3, vol16 // 7, vol16 // 12):      # 4, 8 and 14 bands (the last: bands of 6-7 rows, one minimal tile each)
+        ctx.check(lib.dfe_set_scratch_limit(ctx.handle, max(limit, 1 << 20)))
+        try:
+            idx = torch.full((Ho, Wo), -1, dtype=torch.int64, device=cuda)
+            best = torch.full((Ho, Wo), -1.0, device=cuda)
+            flow = torch.full((2, H, W), -7.0, device=cuda)
+            dd, cc = torch.full((H, W), -7.0, device=cuda), torch.full((H, W), -7.0, device=cuda)
+            ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
+            ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 2.0 ** -8, idx.data_ptr(),
+                                                  best.data_ptr(), flow.data_ptr(), dd.data_ptr(), cc.data_ptr()))
+            ms, n = C_double(), C_int()
+            ctx.check(lib.dfe_profile_read(ctx.handle, byref(ms), byref(n)))
+            assert n.value >= 3, "expected a multi-band build, got %d launch(es)" % n.value
+            assert ctx.last_kernel() == "ssd_cv_rowimg_kernel_f16+fused_tail"
+        finally:
+            ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+            ctx.check(lib.dfe_set_scratch_limit(ctx.handle, 16 << 30))
+        assert np.array_equal(idx.cpu().numpy(), ref["idx"]) and np.array_equal(best.cpu().numpy(), ref["best"])
+        assert torch.equal(flow, flow32) and torch.equal(dd, d32) and torch.equal(cc, c32)
+
+
+def test_4k_f16_two_bands_equals_f32_path(dfe, cuda):
+    """BASELINE configs[4] at its size, single scale: 3840x2160 / 33x33 through dfe_flow_depth_pair_f16 (17.8 GB of fp16 volume:
+    two bands under the default limit) == dfe_flow_depth_pair_f32 (35.5 GB of fp32 volume: three bands) on flow, depth and
+    confidence; idx / best == dfe_ssd_flow_f32's; the planted flow is recovered."""
+    H, W, C, k, win = 2160, 3840, 3, 7, 33
+    f0, f1, pflow, (cx, cy) = rp.synth_pair(H, W, C=C, seed=1, max_flow=12, noise_sigma=0)
+    Ho, Wo = H - k - win + 2, W - k - win + 2
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    idx16 = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best16 = torch.empty((Ho, Wo), device=cuda)
+    flow16 = torch.empty((2, H, W), device=cuda)
+    d16, c16 = torch.empty((H, W), device=cuda), torch.empty((H, W), device=cuda)
+    ctx.check(lib.dfe_profile_enable(ctx.handle, 1))
+    try:
+        ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 2.0 ** -8, idx16.data_ptr(),
+                                              best16.data_ptr(), flow16.data_ptr(), d16.data_ptr(), c16.data_ptr()))
+        ms, n = C_double(), C_int()
+        ctx.check(lib.dfe_profile_read(ctx.handle, byref(ms), byref(n)))
+    finally:
+        ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+    assert n.value == 2 and ctx.last_kernel() == "ssd_cv_rowimg_kernel_f16+fused_tail"
+    flow32 = torch.empty((2, H, W), device=cuda)
+    sc, d32, c32 = (torch.empty((H, W), device=cuda) for _ in range(3))
+    ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, 0.21, flow32.data_ptr(), sc.data_ptr(),
+                                          d32.data_ptr(), c32.data_ptr()))
+    assert torch.equal(flow16, flow32) and torch.equal(d16, d32) and torch.equal(c16, c32)
+    idx32 = torch.empty_like(idx16)
+    best32 = torch.empty_like(best16)
+    ctx.check(lib.dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, k, win, win, 0.21, idx32.data_ptr(), best32.data_ptr(),
+                                   None, None, None, None))
+    assert torch.equal(idx16, idx32) and torch.equal(best16, best32)
+    fy, fx = flow16[0].cpu().numpy(), flow16[1].cpu().numpy()
+    inner = (slice(40, H - 40), slice(40, W - 40))
+    assert ((fy == pflow[0]) & (fx == pflow[1]))[inner].mean() > 0.95
+
+
+@pytest.mark.parametrize("H,W", [(720, 1280), (1080, 1920)])
+def test_benched_single_scale_sizes_properties(dfe, cuda, H, W):
+    """The 720p / 1080p workloads of bench.py (33x33, C=3), where the persistent sweep's cut, the aligned-front schedule and the
+    band logic take other branches than at VGA.  Size-independent properties: (a) the auto (row-image, swept) build == the
+    tiled kernel == the oracle on row bands at the top, across the middle and at the bottom, bit for bit (integer frames);
+    (b) the fused pipeline's idx / best == dfe_argbest_center over the materialised volume; (c) the planted flow is the
+    arg-min; (d) dfe_flow_depth_pair_f32 (the bench step) agrees with (b) and zeroes its border."""
+    k, win = 7, 33
+    f0, f1, pflow, (cx, cy) = rp.synth_pair(H, W, C=3, seed=3, max_flow=12, noise_sigma=0)
+    Ho, Wo = H - k - win + 2, W - k - win + 2
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    op = dfe.nn.SSDCostVolume(win, win, k, k)
+    vol = op.forward([t0, t1])
+    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel" and tuple(vol.shape) == (Ho, Wo, win, win)
+    nb = 20
+    for r0 in (0, Ho // 3 - 7, Ho // 2 - 10, Ho - nb):
+        rows = slice(r0, r0 + nb + k - 1 + win - 1)
+        b0, b1 = np.ascontiguousarray(f0[:, rows]), np.ascontiguousarray(f1[:, rows])
+        ctx.set_cost_volume_kernel(2)
+        try:
+            band = op.forward([T(b0, cuda), T(b1, cuda)])
+            assert ctx.last_kernel() == "ssd_cv_tiled_kernel"
+        finally:
+            ctx.set_cost_volume_kernel(0)
+        assert torch.equal(band, vol[r0 : r0 + nb]), "rows %d.." % r0
+        cpu = orc.ssd_cost_volume(b0[:, : 3 + k - 1 + win - 1], b1[:, : 3 + k - 1 + win - 1], k, k, win, win)
+        assert np.array_equal(vol[r0 : r0 + 3].cpu().numpy(), cpu)
+    mid = rp.middle_index(win, win)
+    idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best = torch.empty((Ho, Wo), device=cuda)
+    ctx.check(lib.dfe_argbest_center(ctx.handle, vol.data_ptr(), idx.numel(), win * win, mid, 0, idx.data_ptr(), best.data_ptr()))
+    del vol
+    fidx, fbest = torch.empty_like(idx), torch.empty_like(best)
+    ffy, ffx = torch.empty_like(best), torch.empty_like(best)
+    ctx.check(lib.dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, 0.21, fidx.data_ptr(), fbest.data_ptr(),
+                                   ffy.data_ptr(), ffx.data_ptr(), None, None))
+    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel+fused_tail"
+    assert torch.equal(fidx, idx) and torch.equal(fbest, best)
+    y, x = dfe.x2yx(dict(maxh=win, maxw=win), idx)
+    assert torch.equal((y - 17).float(), ffy) and torch.equal((x - 17).float(), ffx)
+    inner = (slice(12, Ho - 12), slice(12, Wo - 12))
+    py, px = pflow[0][19:-19, 19:-19], pflow[1][19:-19, 19:-19]
+    assert ((ffy.cpu().numpy() == py) & (ffx.cpu().numpy() == px))[inner].mean() > 0.95
+    flow = torch.full((2, H, W), -9.0, device=cuda)
+    sc, dd, cc = (torch.full((H, W), -9.0, device=cuda) for _ in range(3))
+    ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, win, win, cx, cy, 0.21, flow.data_ptr(), sc.data_ptr(),
+                                          dd.data_ptr(), cc.data_ptr()))
+    assert torch.equal(flow[0, 19:-19, 19:-19], ffy) and torch.equal(flow[1, 19:-19, 19:-19], ffx)
+    assert float(flow[:, :19].abs().max()) == 0 and float(flow[:, :, -19:].abs().max()) == 0
+    ed, ec = orc.flow_to_depth_cartesian(flow.cpu().numpy(), cx, cy)
+    assert np.allclose(dd.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(cc.cpu().numpy(), ec)
 
 
 # ------------------------------------------------------------------ one device per ctx
