@@ -52,7 +52,12 @@ PYRAMIDS = {
     "4k-pyramid": (2160, 3840, 3, 7, 8, 8, (1, 2, 4, 8, 16)),
     "1080p-pyramid-f16": (1080, 1920, 3, 7, 8, 8, (1, 2, 4, 8)),
     "vga-pyramid-f16": (480, 640, 3, 7, 8, 8, (1, 2, 4)),
+    # the same matcher with LEARNED patch filters in front of every scale (getModelMultiscale + getFilter, shared parameters):
+    # layers {3,5,5,4},{4,5,5,4},{4,5,5,10} of tests/time_matching.lua:13 (13 x 13 receptive field, K = 10 features), random-init
+    "vga-pyramid-learned": (480, 640, 3, 13, 8, 8, (1, 2, 4)),
+    "1080p-pyramid-learned": (1080, 1920, 3, 13, 8, 8, (1, 2, 4, 8)),
 }
+LEARNED_LAYERS = [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)]
 # BASELINE.json configs[2]: 1280x720 radial (polar-warped) flow: C2P warp of both frames around the epipole, the default
 # separable filter stack {{3,1,17,5},{5,17,1,10}}, SpatialRadialMatching(15), arg-min, P2C warp, flow2depth, through
 # dfe_radial_flow_depth_pair_f32; polar image = frame size ("bench at 720x1280 polar").
@@ -235,8 +240,18 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
     rr = (C.c_int32 * len(ratios))(*ratios)
 
     f16 = args.workload.endswith("-f16")
+    learned = args.workload.endswith("-learned")
+    if learned:
+        from depth_estimation_amd.multiscale import filter_layers_array
+
+        filt = d.getFilter(dict(layers=LEARNED_LAYERS), device=dev, generator=torch.Generator().manual_seed(0))   # random-init weights of the architecture
+        larr, nl, _keep = filter_layers_array([filt])
 
     def step():
+        if learned:
+            ctx.check(lib.dfe_multiscale_flow_pair_filtered_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, maxh, maxw, rr, len(ratios), larr, nl, 1, 0.0,
+                                                               flow.data_ptr(), None))
+            return
         if f16:
             ctx.check(lib.dfe_multiscale_flow_pair_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, Hp, Wp, k, maxh, maxw, rr, len(ratios), 1.0,
                                                       flow.data_ptr(), None))
@@ -249,13 +264,14 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
         balg = 2 * Cc * Hp * Wp * 4 + sum((Hp // r) * (Wp // r) * maxh * maxw * (2 if f16 else 4) for r in ratios)
         step_s = elapsed / args.steps
         print(json.dumps({
-            "metric": "Mpixels/s dense flow, %dx%d pair, %d-level pyramid, 7x7 patch, %dx%d window per scale" % (W, H, len(ratios), maxh, maxw),
+            "metric": "Mpixels/s dense flow, %dx%d pair, %d-level pyramid, %s, %dx%d window per scale" % (W, H, len(ratios), "13x13 learned filters" if learned else "7x7 patch", maxh, maxw),
             "value": round(world * args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 sums, f16 volumes" if f16 else "f32", "data": "synthetic",
-            "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, 7x7 raw-patch SSD over %dx%d%s, "
-                                   "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (W, H, Cc, list(ratios), maxh, maxw,
-                                                                                                             " stored as fp16" if f16 else ""),
+            "config": {"workload": "%dx%d C=%d multiscale matcher ratios %s (per scale: box down-sample, zero-pad, %s over %dx%d%s, "
+                                   "softmin) + cascade / ring / arg-max / decode, one pair per GPU per step" % (
+                                       W, H, Cc, list(ratios), ("learned filter stack %s (shared, random-init) + SpatialMatching" % LEARNED_LAYERS) if learned else "7x7 raw-patch SSD",
+                                       maxh, maxw, " stored as fp16" if f16 else ""),
                        "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": "whole step (prep, volumes, one cascade launch per scale)", "achieved": round(balg / step_s / 1e9, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(balg / step_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,

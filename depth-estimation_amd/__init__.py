@@ -35,7 +35,7 @@ from .opticalflow_model import (  # noqa: F401
     getOutputConfidences2,
     processOutput,
 )
-from .multiscale import CascadingAddTable, MultiscaleModel, getModelMultiscale  # noqa: F401
+from .multiscale import CascadingAddTable, MultiscaleModel, MultiscalePrefilter, getModelMultiscale, getMultiscalePrefilter  # noqa: F401
 from .network import getFilter, getFilterRadial, getModel, tables_random  # noqa: F401
 from .radial import (getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth, getKOutput, getP2CMaskOF,  # noqa: F401
                      computeDepthMapFromFlow, getTesterNetwork, getTrainerNetwork, getMatcher, radialFlowDepth, radial_out_shape)

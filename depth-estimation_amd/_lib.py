@@ -13,6 +13,12 @@ c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int)
 
+class FilterLayer(C.Structure):
+    """dfe_filter_layer (include/dfe.h)"""
+    _fields_ = [("nIn", C.c_int), ("nOut", C.c_int), ("kH", C.c_int), ("kW", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("conn", C.c_void_p), ("nConn", C.c_int), ("tanh_after", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/dfe.h declares
 PROTOTYPES = {
     "dfe_version": (C.c_int, []),
@@ -89,6 +95,8 @@ PROTOTYPES = {
     "dfe_radial_matching_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dfe_cascade_flow_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfe_multiscale_flow_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dfe_multiscale_flow_pair_filtered_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int,
+                                                       C.POINTER(FilterLayer), C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "dfe_multiscale_flow_pair_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "dfe_cascading_add_backward_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dfe_cascade_ring_f32": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), c_i32p] + [C.c_int] * 5 + [C.c_void_p]),

@@ -71,6 +71,11 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
                              int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale = 0.f);
 int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
+// one layer of a filter stack (filters.hip): in [nIn][H][W] -> out [nOut][H-kH+1][W-kW+1], nn.Tanh fused behind it when
+// L.tanh_after (the same tanhf as dfe_tanh_f32: bit-identical to the two separate calls)
+int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out);
+// nn.SpatialMatching on feature maps, fast kernels or the reference-order one (ssd_cost_volume.hip)
+int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 
 #define DFE_HIP(ctx, expr)                                                              \
     do {                                                                                \

@@ -45,6 +45,35 @@ __global__ void conv_map_kernel(const float *__restrict__ in, const float *__res
     }
 }
 
+// the same two kernels with nn.Tanh applied to the result (one launch per layer of a filter stack inside the one-call pipelines)
+template <bool TANH>
+__global__ void conv_layer_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias, const int *__restrict__ conn,
+                                  int nConn, int nIn, int nOut, int H, int W, int kH, int kW, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    const int Ho = H - kH + 1, Wo = W - kW + 1;
+    const long long n = (long long)nOut * Ho * Wo;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(e % Wo);
+        const long long t = e / Wo;
+        const int y = (int)(t % Ho), o = (int)(t / Ho);
+        float s = bias ? bias[o] : 0.f;
+        if (conn) {
+            for (int c = 0; c < nConn; ++c) {
+                if (conn[2 * c + 1] - 1 != o) continue;
+                const int i = conn[2 * c] - 1;
+                for (int u = 0; u < kH; ++u)
+                    for (int v = 0; v < kW; ++v) s = s + w[((long long)c * kH + u) * kW + v] * in[((long long)i * H + y + u) * W + x + v];
+            }
+        } else {
+            for (int i = 0; i < nIn; ++i)
+                for (int u = 0; u < kH; ++u)
+                    for (int v = 0; v < kW; ++v)
+                        s = s + w[(((long long)o * nIn + i) * kH + u) * kW + v] * in[((long long)i * H + y + u) * W + x + v];
+        }
+        out[e] = TANH ? tanhf(s) : s;
+    }
+}
+
 __global__ void tanh_kernel(const float *__restrict__ in, long long n, float *__restrict__ out) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) out[e] = tanhf(in[e]);
 }
@@ -57,6 +86,19 @@ int grid_n(long long n) {
 }
 
 }  // namespace
+
+int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out) {
+    DFE_REQUIRE(ctx, in && L.weight && out, DFE_E_ARG, "filter layer: NULL tensor");
+    DFE_REQUIRE(ctx, L.nIn > 0 && L.nOut > 0 && L.kH > 0 && L.kW > 0 && H >= L.kH && W >= L.kW && (!L.conn || L.nConn > 0), DFE_E_SHAPE,
+                "filter layer: %d->%d planes, %dx%d kernel on %dx%d", L.nIn, L.nOut, L.kH, L.kW, H, W);
+    const int g = grid_n((long long)L.nOut * (H - L.kH + 1) * (W - L.kW + 1));
+    if (L.tanh_after)
+        hipLaunchKernelGGL(conv_layer_kernel<true>, dim3(g), dim3(256), 0, ctx->stream, in, L.weight, L.bias, (const int *)L.conn, L.nConn, L.nIn, L.nOut, H, W, L.kH, L.kW, out);
+    else
+        hipLaunchKernelGGL(conv_layer_kernel<false>, dim3(g), dim3(256), 0, ctx->stream, in, L.weight, L.bias, (const int *)L.conn, L.nConn, L.nIn, L.nOut, H, W, L.kH, L.kW, out);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
 
 extern "C" {
 

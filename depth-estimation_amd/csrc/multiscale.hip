@@ -115,6 +115,45 @@ __global__ void prep_scales_kernel(const float *__restrict__ I0, const float *__
     prep_scale_body(I0, I1, C, H, W, ps.r[s], pl, pt, ps.Hp[s], ps.Wp[s], ps.p0[s], ps.p1[s]);
 }
 
+// the same per FRAME, each entry with its own padding (the learned-filter matcher crops frame 0 by the search window before
+// it filters: its padded frame is smaller than frame 1's): blockIdx.y = entry
+struct PrepFrames {
+    const float *img[2 * DFE_MAX_RATIOS];
+    float *out[2 * DFE_MAX_RATIOS];
+    int r[2 * DFE_MAX_RATIOS], pl[2 * DFE_MAX_RATIOS], pt[2 * DFE_MAX_RATIOS], Hp[2 * DFE_MAX_RATIOS], Wp[2 * DFE_MAX_RATIOS];
+};
+__global__ void prep_frames_kernel(int C, int H, int W, PrepFrames pf) {
+#pragma clang fp contract(off)
+    const int z = blockIdx.y;
+    const int r = pf.r[z], pl = pf.pl[z], pt = pf.pt[z], Hp = pf.Hp[z], Wp = pf.Wp[z];
+    const float *__restrict__ img = pf.img[z];
+    float *__restrict__ out = pf.out[z];
+    const int Hs = H / r, Ws = W / r;
+    const unsigned total = (unsigned)C * Hp * Wp;
+    const float inv = 1.0f / (float)(r * r);
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned t = e / (unsigned)Wp;
+        const int x = (int)(e - t * (unsigned)Wp);
+        const int c = (int)(t / (unsigned)Hp), y = (int)(t - (unsigned)c * Hp);
+        const int sy = y - pt, sx = x - pl;
+        float v = 0.f;
+        if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
+            const float *src = img + ((long long)c * H + sy * r) * W + sx * r;
+            float s = 0.f;
+            if (r == 1) s = 0.f + src[0];
+            else if (r == 2) s = box_sum<2>(src, W);
+            else if (r == 4) s = box_sum<4>(src, W);
+            else if (r == 8) s = box_sum<8>(src, W);
+            else {
+                for (int i = 0; i < r; ++i)
+                    for (int j = 0; j < r; ++j) s = s + src[(long long)i * W + j];
+            }
+            v = r > 1 ? s * inv : s;
+        }
+        out[e] = v;
+    }
+}
+
 // ---- A3: p = softmax(-cost) over the N cells of each pixel (one wave per pixel) --------------------
 __device__ __forceinline__ void softmin_body(const float *__restrict__ cost, long long P, int N, float *__restrict__ prob) {
     const int lane = threadIdx.x & 63;
@@ -878,22 +917,43 @@ int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1,
 }
 
 // f16_scale != 0: every scale's volume is stored as half(cost * f16_scale) (dfe_multiscale_flow_pair_f16)
+// the learned patch filters of the matcher (NULL = raw patches, the identity filter): layers [share ? 1 : nratios][nlayers]
+struct MsFilter { const dfe_filter_layer *layers; int nlayers, share; };
 static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
-                                const int *ratios, int nratios, float *flow, int64_t *idx, float f16_scale) {
+                                const int *ratios, int nratios, float *flow, int64_t *idx, float f16_scale, const MsFilter *filt = nullptr) {
     DFE_REQUIRE(ctx, I0 && I1 && (flow || idx), DFE_E_ARG, "dfe_multiscale_flow_pair_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && k > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_f32: bad size");
     CascadeGeom g;
     int rc = fill_cascade(ctx, g, ratios, nratios, maxh, maxw);
     if (rc) return rc;
     const int N = maxh * maxw;
-    const int hp = maxh - 1 + k - 1, wp = maxw - 1 + k - 1;   // hPatch2-1 (opticalflow_model_multiscale.lua:136-141)
+    // receptive field of the patch filter: k x k raw patches, or hKernel = sum kH - (nlayers - 1) of the learned stack (opticalflow.lua:154-171)
+    int hk = k, wk = k, maxplanes = C;
+    if (filt) {
+        for (int v = 0; v < (filt->share ? 1 : nratios); ++v) {
+            int h = 1, w = 1, nin = C;
+            for (int l = 0; l < filt->nlayers; ++l) {
+                const dfe_filter_layer &L = filt->layers[v * filt->nlayers + l];
+                DFE_REQUIRE(ctx, L.weight && L.nIn > 0 && L.nOut > 0 && L.kH > 0 && L.kW > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_filtered_f32: layer %d: bad description", l);
+                DFE_REQUIRE(ctx, L.conn ? L.nIn <= nin : L.nIn == nin, DFE_E_SHAPE, "dfe_multiscale_flow_pair_filtered_f32: layer %d reads %d planes, the layer before it makes %d", l, L.nIn, nin);
+                h += L.kH - 1; w += L.kW - 1; nin = L.nOut;
+                if (L.nOut > maxplanes) maxplanes = L.nOut;
+            }
+            DFE_REQUIRE(ctx, v == 0 || (h == hk && w == wk), DFE_E_SHAPE, "dfe_multiscale_flow_pair_filtered_f32: the scales' filter stacks have different receptive fields");
+            hk = h; wk = w;
+        }
+    }
+    const int hp = maxh - 1 + hk - 1, wp = maxw - 1 + wk - 1;   // hPatch2-1 (opticalflow_model_multiscale.lua:136-141)
     const int pt = hp / 2, pl = wp / 2;
-    size_t off_p[DFE_MAX_RATIOS], off_v[DFE_MAX_RATIOS], off_q[DFE_MAX_RATIOS], off_b[DFE_MAX_RATIOS], total = 0;
+    size_t off_p[DFE_MAX_RATIOS], off_v[DFE_MAX_RATIOS], off_q[DFE_MAX_RATIOS], off_b[DFE_MAX_RATIOS], off_f[DFE_MAX_RATIOS], fbuf[DFE_MAX_RATIOS], total = 0;
     for (int s = 0; s < nratios; ++s) {
         const int r = ratios[s];
         DFE_REQUIRE(ctx, H % r == 0 && W % r == 0, DFE_E_SHAPE,
                     "dfe_multiscale_flow_pair_f32: frame %dx%d is not a multiple of ratio %d (opticalflow_model_multiscale.lua:238-243)", H, W, r);
         const size_t np = (size_t)C * (H / r + hp) * (W / r + wp), nv = (size_t)(H / r) * (W / r) * N;
+        // learned filters: four feature buffers per scale (ping-pong per frame), each the largest layer output
+        fbuf[s] = filt ? ((size_t)maxplanes * (H / r + hp) * (W / r + wp) * sizeof(float) + 255) / 256 * 256 : 0;
+        off_f[s] = total; total += 4 * fbuf[s];
         off_p[s] = total; total += (2 * np * sizeof(float) + 255) / 256 * 256;
         off_v[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
         off_q[s] = total; total += (nv * sizeof(float) + 255) / 256 * 256;
@@ -910,7 +970,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     gkey.I0 = I0; gkey.I1 = I1; gkey.flow = flow; gkey.idx = idx; gkey.scr = scr;
     gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios; gkey.f16 = f16_scale;
     for (int s = 0; s < nratios; ++s) gkey.ratios[s] = ratios[s];
-    const int gmode = dfe_graph_lookup(ctx, ctx->ms_graph, &gkey, sizeof gkey);
+    const int gmode = filt ? 0 : dfe_graph_lookup(ctx, ctx->ms_graph, &gkey, sizeof gkey);
     if (gmode == 2) {
         DFE_HIP(ctx, hipGraphLaunch(ctx->ms_graph.exec, ctx->stream));
         ctx->last_kernel = "multiscale graph";
@@ -940,8 +1000,10 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         mg.ratios[s] = r;
         mg.d[s] = g.d[s];
     }
-    hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
-    DFE_LAUNCH_CHECK(ctx);
+    if (!filt) {
+        hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
+        DFE_LAUNCH_CHECK(ctx);
+    }
     bool merged = false, soft_done = false, half_vol = false;
     const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
     // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
@@ -949,7 +1011,43 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     for (int s = 0; s < nratios; ++s)
         if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
     if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
-    {
+    if (filt) {
+        // learned filters (getModelMultiscale's filter1 / filter2, opticalflow_model_multiscale.lua:196-211): frame 0 is cropped by
+        // the search window BEFORE the filter (its zero padding shrinks by floor / ceil((maxh-1)/2)), both padded frames go
+        // through the stack, nn.SpatialMatching(maxh, maxw) runs on the K-plane features
+        const int ct = (maxh - 1) / 2, cl = (maxw - 1) / 2;
+        PrepFrames pf;
+        long long pmax = 0;
+        for (int s = 0; s < nratios; ++s) {
+            const int r = ratios[s], Hs = H / r, Ws = W / r;
+            pf.img[2 * s] = I0; pf.out[2 * s] = ps.p0[s]; pf.r[2 * s] = r;
+            pf.pl[2 * s] = pl - cl; pf.pt[2 * s] = pt - ct; pf.Hp[2 * s] = Hs + hk - 1; pf.Wp[2 * s] = Ws + wk - 1;
+            pf.img[2 * s + 1] = I1; pf.out[2 * s + 1] = ps.p1[s]; pf.r[2 * s + 1] = r;
+            pf.pl[2 * s + 1] = pl; pf.pt[2 * s + 1] = pt; pf.Hp[2 * s + 1] = Hs + hp; pf.Wp[2 * s + 1] = Ws + wp;
+            if ((long long)C * (Hs + hp) * (Ws + wp) > pmax) pmax = (long long)C * (Hs + hp) * (Ws + wp);
+        }
+        hipLaunchKernelGGL(prep_frames_kernel, dim3(grid1d(pmax, 256 * 8), 2 * nratios), dim3(256), 0, ctx->stream, C, H, W, pf);
+        DFE_LAUNCH_CHECK(ctx);
+        for (int s = 0; s < nratios; ++s) {
+            const dfe_filter_layer *Ls = filt->layers + (filt->share ? 0 : s) * filt->nlayers;
+            const float *feat[2];
+            for (int f = 0; f < 2; ++f) {
+                const float *cur = pf.out[2 * s + f];
+                int h = pf.Hp[2 * s + f], w = pf.Wp[2 * s + f];
+                for (int l = 0; l < filt->nlayers; ++l) {
+                    float *dst = (float *)((char *)scr + off_f[s] + (size_t)(2 * f + (l & 1)) * fbuf[s]);
+                    rc = dfe_filter_layer_forward(ctx, cur, Ls[l], h, w, dst);
+                    if (rc) return rc;
+                    cur = dst; h -= Ls[l].kH - 1; w -= Ls[l].kW - 1;
+                }
+                feat[f] = cur;
+            }
+            const int K = filt->nlayers ? Ls[filt->nlayers - 1].nOut : C;
+            rc = dfe_spatial_matching_dispatch(ctx, feat[0], feat[1], K, H / ratios[s], W / ratios[s], maxh, maxw, (float *)ss.cost[s]);
+            if (rc) return rc;
+        }
+        merged = true;
+    } else {
         // one launch for every scale's volume; on the fast path the coarser scales leave it as soft-min probabilities already
         // (their blocks run next to the scale-1 blocks that dominate the launch), scale 1 as costs for the cascade's SOFT0
         const float *f0[DFE_MAX_RATIOS], *f1[DFE_MAX_RATIOS];
@@ -1075,6 +1173,18 @@ int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1,
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, scale > 0.f && scale < INFINITY, DFE_E_ARG, "dfe_multiscale_flow_pair_f16: scale=%g must be positive", (double)scale);
     return multiscale_flow_pair(ctx, I0, I1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx, scale);
+}
+
+int dfe_multiscale_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int maxh, int maxw,
+                                          const int *ratios, int nratios, const dfe_filter_layer *layers, int nlayers, int share_filters,
+                                          float f16_scale, float *flow, int64_t *idx) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, layers && nlayers >= 1 && nlayers <= 16, DFE_E_ARG, "dfe_multiscale_flow_pair_filtered_f32: nlayers=%d", nlayers);
+    DFE_REQUIRE(ctx, f16_scale >= 0.f && f16_scale < INFINITY, DFE_E_ARG, "dfe_multiscale_flow_pair_filtered_f32: f16_scale=%g", (double)f16_scale);
+    DFE_REQUIRE(ctx, layers[0].nIn == C || layers[0].conn, DFE_E_SHAPE, "dfe_multiscale_flow_pair_filtered_f32: frames have %d channels, the first layer reads %d", C,
+                layers[0].nIn);
+    const MsFilter filt{layers, nlayers, share_filters};
+    return multiscale_flow_pair(ctx, I0, I1, C, H, W, 1, maxh, maxw, ratios, nratios, flow, idx, f16_scale, &filt);
 }
 
 int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *prob) {

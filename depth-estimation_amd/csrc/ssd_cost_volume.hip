@@ -2008,6 +2008,11 @@ int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int 
 int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh,
                              int maxw, float *out) {
     DFE_ENTER(ctx);
+    return dfe_spatial_matching_dispatch(ctx, in1, in2, K, H1, W1, maxh, maxw, out);
+}
+}  // extern "C"
+
+int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out) {
     DFE_REQUIRE(ctx, in1 && in2 && out, DFE_E_ARG, "dfe_spatial_matching_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE,
                 "dfe_spatial_matching_f32: K=%d H1=%d W1=%d maxh=%d maxw=%d must be positive", K, H1, W1, maxh, maxw);
@@ -2025,6 +2030,7 @@ int dfe_spatial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, i
     return launch_cv_ref(ctx, a);
 }
 
+extern "C" {
 int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W, int hWin,
                             float *out) {
     DFE_ENTER(ctx);

@@ -6,6 +6,8 @@ local ffi = require 'ffi'
 
 ffi.cdef[[
 typedef struct dfe_ctx dfe_ctx;
+typedef struct dfe_radial_params { int C, hImg, wImg; int hInput, wInput; int hWin; int n1, kW1; int n2, kH2; int tanh_between; float alpha_polar; double kinfty; } dfe_radial_params;
+typedef struct dfe_filter_layer { int nIn, nOut, kH, kW; const float *weight; const float *bias; const int32_t *conn; int nConn; int tanh_after; } dfe_filter_layer;
 int dfe_version(void);
 const char *dfe_kernel_revision(void);
 int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out);
@@ -54,6 +56,7 @@ int dfe_cascading_add_f32(dfe_ctx *ctx, const float *const *in, const int *ratio
 int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, int64_t *idx, float *best, float *flow_y, float *flow_x);
 int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
 int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float scale, float *flow, int64_t *idx);
+int dfe_multiscale_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int maxh, int maxw, const int *ratios, int nratios, const dfe_filter_layer *layers, int nlayers, int share_filters, float f16_scale, float *flow, int64_t *idx);
 int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *gradIn);
 int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, float *out);
 int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, int lpadding, int rpadding, float rmax, float alpha, float *mask);

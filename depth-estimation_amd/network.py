@@ -293,6 +293,7 @@ def getFilter(geometry, device="cuda", generator=None):
             filt.add(SpatialConvolutionMap(tables_random(layers[i - 1][3], nout, nin, generator=generator), kw, kh, device=device, generator=generator))
         if i != len(layers) - 1:
             filt.add(Tanh())
+    filt.getWeights = lambda: filter_weights(filt)
     return filt
 
 
@@ -315,6 +316,26 @@ def getFilterRadial(networkp, device="cuda", generator=None):
     return filt
 
 
+_SHARED_ATTRS = ("weight", "bias", "gradWeight", "gradBias", "kernel", "connTable", "_conn_dev")
+
+
+def shared_clone(src):
+    """module:clone('weight', 'bias', 'gradWeight', 'gradBias') of ONE convolution: a second module of the same class whose
+    parameters, gradient buffers and kernel choice ARE the source's -- read through the source at call time, so rebinding
+    `src.weight = ...` (how trained weights get loaded), `src.kernel = "mfma"` or a device move shows in the clone, and
+    assignments to the clone's parameters land in the source -- while outputs / gradInputs stay its own."""
+    cls = type(src)
+    ns = {"__getattr__": lambda self, name: getattr(object.__getattribute__(self, "_src"), name)}
+    for n in _SHARED_ATTRS:
+        ns[n] = property(lambda self, n=n: getattr(object.__getattribute__(self, "_src"), n),
+                         lambda self, v, n=n: setattr(object.__getattribute__(self, "_src"), n, v))
+    proxy_cls = type("Shared" + cls.__name__, (cls,), ns)
+    p = proxy_cls.__new__(proxy_cls)
+    object.__setattr__(p, "_src", src)
+    p.output = p.gradInput = None
+    return p
+
+
 class _SharedFilter(Module):
     """filter:clone('weight','bias','gradWeight','gradBias') -- the second branch shares the first one's parameters AND
     gradient buffers (accGradParameters of both branches accumulates into the same tensors), but keeps its own outputs."""
@@ -322,15 +343,7 @@ class _SharedFilter(Module):
     def __init__(self, filt):
         super().__init__()
         self.filt = filt
-        self.modules = []
-        for m in filt.modules:
-            if isinstance(m, (SpatialConvolution, SpatialConvolutionMap)):
-                mm = type(m).__new__(type(m))
-                mm.__dict__.update(m.__dict__)     # same weight / bias / gradWeight / gradBias tensors
-                mm.output = mm.gradInput = None
-            else:
-                mm = type(m)()
-            self.modules.append(mm)
+        self.modules = [shared_clone(m) if isinstance(m, (SpatialConvolution, SpatialConvolutionMap)) else type(m)() for m in filt.modules]
 
     def updateOutput(self, input):
         self._inputs = []
@@ -349,6 +362,19 @@ class _SharedFilter(Module):
         return g
 
     updateGradInput = Sequential.updateGradInput
+
+    def getWeights(self):
+        return filter_weights(self)
+
+
+def filter_weights(filt):
+    """filter:getWeights() of getFilter (opticalflow_model.lua:66-76): {'layer<i>': weight} over the modules that have one."""
+    out, i = {}, 1
+    for m in filt.modules:
+        if isinstance(m, (SpatialConvolution, SpatialConvolutionMap)):
+            out["layer%d" % i] = m.weight
+            i += 1
+    return out
 
 
 def getModel(geometry, full_image=True, prefiltered=False, device="cuda", generator=None):

@@ -297,6 +297,32 @@ int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1,
 int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k,
                                  int maxh, int maxw, const int *ratios, int nratios, float scale, float *flow, int64_t *idx);
 
+/* ---- A2..A6 + A10 + A15 in one call: the multiscale matcher with its LEARNED patch filters ------------------------------- */
+/* One layer of getFilter(geometry) (opticalflow_model.lua:45-79): nn.SpatialConvolution(nIn, nOut, kW, kH), or
+ * nn.SpatialConvolutionMap over a connection table when conn != NULL, followed by nn.Tanh when tanh_after (getFilter puts
+ * one behind every layer but the last).  All pointers are DEVICE pointers. */
+typedef struct dfe_filter_layer {
+    int nIn, nOut, kH, kW;
+    const float *weight;   /* [nOut][nIn][kH][kW]; with conn: [nConn][kH][kW] */
+    const float *bias;     /* [nOut] or NULL */
+    const int32_t *conn;   /* SpatialConvolutionMap: [nConn][2] = (from, to), 1-based int32; NULL = full connection */
+    int nConn;
+    int tanh_after;
+} dfe_filter_layer;
+/* replaces: getModelMultiscale(geometry, true, false):forward({I0, I1}) + processOutput ('max', no threshold) with
+ *   getFilter(geometry) in front of every scale's nn.SpatialMatching -- opticalflow_model_multiscale.lua:175-333 (the filter
+ *   branches :196-211, shared or cloned per scale :219-226), equivalently getMultiscalePrefilter (:134-173) followed by the
+ *   prefiltered model: the per-scale computation is the same.  Per scale r: box down-sample by r, zero-pad by hPatch2-1 =
+ *   (maxh-1)+(hKernel-1) split floor/ceil (hKernel = sum kH - (nlayers-1), the stack's receptive field: opticalflow.lua:154-189),
+ *   frame 0 cropped by maxh-1 / maxw-1 (:198-202), the filter stack on both, SpatialMatching(maxh, maxw) on the K-plane
+ *   features, soft-min; then cascade / ring / arg-max / decode as in dfe_multiscale_flow_pair_f32.
+ *   layers: HOST array [share_filters ? 1 : nratios][nlayers] (scale-major); share_filters != 0: one stack for every scale
+ *   (geometry.share_filters).  I0, I1 [C][H][W], C = layers[0].nIn, H and W multiples of every ratio.
+ *   f16_scale != 0: volumes rounded to half precision where they are stored (see dfe_multiscale_flow_pair_f16). */
+int dfe_multiscale_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int maxh, int maxw,
+                                          const int *ratios, int nratios, const dfe_filter_layer *layers, int nlayers,
+                                          int share_filters, float f16_scale, float *flow, int64_t *idx);
+
 /* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
 /* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
  *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];

@@ -199,6 +199,22 @@ def multi_nclasses(maxh, maxw, ratios):
     return int(lib().orc_multi_nclasses(maxh, maxw, r, len(r)))
 
 
+def downsample_box(img, r):
+    img = _f(img)
+    Cc, H, W = img.shape
+    out = np.empty((Cc, H // r, W // r), np.float32)
+    lib().orc_downsample_box(img, Cc, H, W, r, out)
+    return out
+
+
+def zero_pad(img, pl, pr, pt, pb):
+    img = _f(img)
+    Cc, H, W = img.shape
+    out = np.empty((Cc, H + pt + pb, W + pl + pr), np.float32)
+    lib().orc_zero_pad(img, Cc, H, W, pl, pr, pt, pb, out)
+    return out
+
+
 def pyramid_scale_volume(I0, I1, r, kh, kw, maxh, maxw):
     I0, I1 = _f(I0), _f(I1)
     Cc, H, W = I0.shape

@@ -155,6 +155,57 @@ def multiscale_flow_oracle(f0, f1, k, maxh, maxw, ratios, f16_scale=None):
     return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle, vols=vols)
 
 
+def filter_stack_oracle(x, layers):
+    """getFilter(geometry):forward (opticalflow_model.lua:45-79) on the oracle.  layers: list of dicts
+    {weight, bias, conn (None or [nConn][2] int32, 1-based), nOut, tanh}."""
+    from tests import oracle as orc
+
+    for L in layers:
+        if L.get("conn") is not None:
+            x = orc.spatial_convolution_map(x, L["weight"], L["bias"], L["conn"], L["nOut"])
+        else:
+            x = orc.spatial_convolution(x, L["weight"], L["bias"])
+        if L.get("tanh"):
+            x = orc.tanh(x)
+    return x
+
+
+def multiscale_filtered_oracle(f0, f1, stacks, maxh, maxw, ratios, f16_scale=None):
+    """getModelMultiscale(geometry, true, false):forward({I0, I1}) + processOutput ('max') WITH the learned filters, on the oracle
+    (opticalflow_model_multiscale.lua:134-173,196-229): per ratio r: SpatialDownSampling(r) -> SpatialZeroPadding(hPatch2-1 /
+    wPatch2-1 split floor / ceil) of both frames; frame 0 cropped by maxh-1 / maxw-1 (filter1, :198-202); getFilter on both;
+    SpatialMatching(maxh, maxw); softmin; cascade + ring; arg-max with the centre tie-break; decode.
+    stacks: one list of layer dicts per ratio (the same list object when the filters are shared)."""
+    from tests import oracle as orc
+
+    H, W = f0.shape[1:]
+    hk = 1 + sum(L["weight"].shape[-2] - 1 for L in stacks[0])
+    wk = 1 + sum(L["weight"].shape[-1] - 1 for L in stacks[0])
+    hp, wp = maxh - 1 + hk - 1, maxw - 1 + wk - 1
+    ct, cl = (maxh - 1) // 2, (maxw - 1) // 2
+    vols, feats = [], []
+    for r, st in zip(ratios, stacks):
+        d0, d1 = (orc.downsample_box(f, r) if r > 1 else np.ascontiguousarray(f, np.float32) for f in (f0, f1))
+        p0 = orc.zero_pad(d0, wp // 2, wp - wp // 2, hp // 2, hp - hp // 2)
+        p1 = orc.zero_pad(d1, wp // 2, wp - wp // 2, hp // 2, hp - hp // 2)
+        p0c = np.ascontiguousarray(p0[:, ct : p0.shape[1] - (maxh - 1 - ct), cl : p0.shape[2] - (maxw - 1 - cl)])
+        a, b = filter_stack_oracle(p0c, st), filter_stack_oracle(p1, st)
+        assert a.shape[1:] == (H // r, W // r) and b.shape[1:] == (H // r + maxh - 1, W // r + maxw - 1)
+        feats.append((a, b))
+        vols.append(orc.spatial_matching(a, b, maxh, maxw))
+    if f16_scale:
+        sc, inv = np.float32(f16_scale), np.float32(1.0) / np.float32(f16_scale)
+        vols = [(v * sc).astype(np.float16).astype(np.float32) * inv for v in vols]
+    probs = [orc.softmin(v.reshape(-1, maxh * maxw)).reshape(v.shape) for v in vols]
+    rc, joined = orc.cascade_ring(probs, ratios, H, W, maxh, maxw)
+    assert rc == 0
+    middle = orc.yx2x_multi(maxh, maxw, ratios, 0, 0)
+    idx, best = orc.argbest_center(joined, middle, True)
+    rc, y, x = orc.x2yx_multi(maxh, maxw, ratios, idx)
+    assert rc == 0
+    return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle, vols=vols, feats=feats)
+
+
 def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between=False, kinfty=0.65, alpha=1.0):
     """radial/test_radial_opticalflow.lua:186-225 on the oracle, for the separable filter stack conv(1 x kW) [tanh] conv(kH x 1):
     getC2PMask(+ wrap columns) -> cartesian2polar of both frames -> getTesterNetwork (crop hWin-1 rows of the previous frame,

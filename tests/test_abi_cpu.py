@@ -44,6 +44,57 @@ def test_lua_ffi_binding_declares_the_whole_abi():
     assert rc == 0, "dfe_ffi.lua is out of date: run tools/gen_lua_cdef.py"
 
 
+def test_lua_cdef_block_is_valid_c(tmp_path):
+    """LuaJIT parses the ffi.cdef block as C declarations and rejects ALL of it on the first unknown type (round 2 shipped a block
+    that used dfe_radial_params without declaring it: every Lua drop-in failed at require).  A C compiler must accept the
+    block as it stands, with only the two headers whose types LuaJIT predeclares (stddef / stdint), and every struct of
+    include/dfe.h must be declared in it with the header's layout."""
+    lua = open(os.path.join(PKG, "lua", "dfe_ffi.lua")).read()
+    cdef = lua[lua.index("ffi.cdef[[") + len("ffi.cdef[[") : lua.index("]]")]
+    src = tmp_path / "cdef.c"
+    src.write_text("#include <stddef.h>\n#include <stdint.h>\n" + cdef + "\n")
+    r = subprocess.run(["gcc", "-fsyntax-only", "-std=c99", "-Wall", "-Werror", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    hdr = re.sub(r"/\*.*?\*/", "", open(HDR).read(), flags=re.S)
+    structs = re.findall(r"typedef\s+struct\s+(\w+)\s*\{", hdr)
+    assert "dfe_radial_params" in structs and "dfe_filter_layer" in structs
+    for name in structs:
+        assert re.search(r"typedef struct %s \{" % name, cdef), "dfe_ffi.lua does not declare struct %s" % name
+    # same layout as the header: sizeof / offsetof through a C program that includes both (the cdef's copy under other names)
+    prog = tmp_path / "layout.c"
+    renamed = re.sub(r"\bdfe_", "lua_dfe_", cdef)
+    checks = "".join("_Static_assert(sizeof(%s) == sizeof(lua_%s), \"%s\");\n" % (n, n, n) for n in structs)
+    prog.write_text('#include "%s"\n%s\n%s' % (HDR, renamed, checks))
+    r = subprocess.run(["gcc", "-fsyntax-only", "-std=c11", str(prog)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_shared_filter_clone_follows_rebound_parameters():
+    """filter:clone('weight','bias','gradWeight','gradBias'): the second branch reads the first one's parameters at call time --
+    rebinding them on the source (how trained weights are loaded), switching its kernel, or assigning through the clone all
+    act on ONE set of tensors (the clone used to snapshot the tensors at construction)."""
+    import torch
+
+    from depth_estimation_amd import network
+
+    gen = torch.Generator().manual_seed(1)
+    filt = network.getFilter(dict(layers=[(3, 5, 5, 4), (4, 3, 3, 6)]), device="cpu", generator=gen)
+    shared = network._SharedFilter(filt)
+    src, cl = filt.modules[0], shared.modules[0]
+    assert type(cl).__name__ == "SharedSpatialConvolution" and isinstance(cl, network.SpatialConvolution)
+    assert cl.weight is src.weight and cl.gradBias is src.gradBias and cl.nOutputPlane == 4
+    w2 = torch.randn_like(src.weight)
+    src.weight = w2                                    # rebinding on branch 1 ...
+    assert cl.weight is w2                             # ... is what branch 2 computes with
+    src.kernel = "mfma"
+    assert cl.kernel == "mfma"
+    cl.bias = torch.zeros(4)                           # and assignment through the clone lands in the source
+    assert src.bias is cl.bias and float(src.bias.abs().sum()) == 0
+    cl.output = torch.ones(1)                          # outputs stay the clone's own
+    assert src.output is None
+    assert set(shared.getWeights()) == {"layer1", "layer2"} and shared.getWeights()["layer1"] is w2
+
+
 def test_library_is_gfx950_only():
     from depth_estimation_amd import _lib
 

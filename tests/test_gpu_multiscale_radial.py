@@ -649,6 +649,127 @@ def test_4k_five_level_f16_pyramid_properties(dfe, cuda):
         assert ok[inner].mean() > 0.9
 
 
+# ------------------------------------------------------------------ the multiscale matcher with LEARNED filters
+def _stack_dicts(filt):
+    """numpy layer descriptions of a getFilter stack, for the oracle"""
+    out = []
+    for m in filt.modules:
+        name = type(m).__name__
+        if name.endswith("Tanh"):
+            out[-1]["tanh"] = True
+            continue
+        out.append(dict(weight=m.weight.cpu().numpy(), bias=m.bias.cpu().numpy(), nOut=m.nOutputPlane, tanh=False,
+                        conn=(m.connTable.cpu().numpy() if "Map" in name else None)))
+    return out
+
+
+LEARNED_LAYERS = [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)]       # tests/time_matching.lua:13 (13 x 13 receptive field, K = 10)
+
+
+@pytest.mark.parametrize("share", [True, False])
+@pytest.mark.parametrize("ratios,mh,H,W,layers", [
+    ([1, 2, 4], 8, 96, 128, LEARNED_LAYERS),
+    ([1, 2, 4, 8], 8, 96, 136, LEARNED_LAYERS),
+    ([1, 2, 4], 4, 64, 88, [(3, 5, 5, 6), (2, 3, 3, 6)]),      # second layer's fan-in differs: nn.SpatialConvolutionMap over a random table
+    ([1, 2], 4, 48, 70, [(3, 3, 7, 5)]),                        # one layer (no tanh), non-square kernel (kW = 3, kH = 7)
+])
+def test_learned_multiscale_one_call_equals_staged_and_oracle(dfe, cuda, share, ratios, mh, H, W, layers):
+    """getModelMultiscale with getFilter(geometry) per scale (shared / per-scale parameters): the one-call entry
+    dfe_multiscale_flow_pair_filtered_f32 == the staged module path (down-sample, pad, crop, filter modules, nn.SpatialMatching,
+    softmin, fused cascade) bit for bit, and both against the ORACLE composition: cost volumes bit-exact for a tanh-free stack (the direct
+    convolution and the feature matcher sum in the oracle's order), within 1e-5 relative behind nn.Tanh (device tanhf vs glibc),
+    indices tie-aware (device expf), decode exact."""
+    gen = torch.Generator().manual_seed(7 + len(ratios))
+    geo = dict(maxh=mh, maxw=mh, ratios=ratios, multiscale=True, layers=layers, share_filters=share, hImg=H, wImg=W, output_extraction_method="max")
+    model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
+    assert geo["hKernel"] == 1 + sum(l[2] - 1 for l in layers) and geo["wKernel"] == 1 + sum(l[1] - 1 for l in layers)
+    if not share:       # independent copies start equal (:clone()); make them differ so that a mix-up of scales would show
+        for i, f in enumerate(model.filters[1:], 1):
+            for m in f.modules:
+                if hasattr(m, "weight") and m.weight is not None:
+                    m.weight.mul_(1.0 + 0.25 * i)
+        assert set(model.getWeights()) == {"scale%d_layer%d" % (r, i + 1) for r in ratios for i in range(len(layers))}
+    else:
+        assert set(model.getWeights()) == {"layer%d" % (i + 1) for i in range(len(layers))}
+        assert model.filters[1].modules[0].weight is model.filters[0].modules[0].weight
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + mh, max_flow=min(10, 2 * ratios[-1]), noise_sigma=0)
+    f0, f1 = f0 / np.float32(255), f1 / np.float32(255)
+    one = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=True)
+    stg = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False)
+    assert torch.equal(one["index"], stg["index"]) and torch.equal(one["y"], stg["y"]) and torch.equal(one["x"], stg["x"])
+    ref = rp.multiscale_filtered_oracle(f0, f1, [_stack_dicts(f) for f in model.filters], mh, mh, ratios)
+    # (bit-exact only up to nn.Tanh: the device's tanhf and glibc's differ in the last place, which the next layers carry on --
+    #  with a single layer, i.e. no tanh, the volumes ARE bit-identical)
+    for v, rv in zip(model.volumes, ref["vols"]):
+        if len(layers) == 1:
+            assert np.array_equal(v.cpu().numpy(), rv)
+        else:
+            assert (np.abs(v.cpu().numpy() - rv) <= 1e-5 * np.abs(rv) + 1e-6 * np.abs(rv).max()).all()
+    gi = one["index"].cpu().numpy()
+    gflow = np.stack([one["y"].cpu().numpy(), one["x"].cpu().numpy()]).astype(np.float32)
+    _assert_matches_oracle(gi, gflow, ref, mh, mh, ratios)
+    # the full class tensor of model:forward, against the oracle's joined tensor
+    out = model.forward([T(f0, cuda), T(f1, cuda)])
+    assert np.abs(out.cpu().numpy() - ref["joined"]).max() <= len(ratios) * SOFT_ATOL
+
+
+def test_learned_multiscale_prefiltered_and_focus(dfe, cuda):
+    """getMultiscalePrefilter + the prefiltered model == the model with the filters inside (same volumes bit for bit), and
+    model:focus(x, y) (training mode) == log of that pixel's class vector of the full output."""
+    ratios, mh, H, W = [1, 2, 4], 8, 64, 96
+    gen = torch.Generator().manual_seed(3)
+    geo = dict(maxh=mh, maxw=mh, ratios=ratios, multiscale=True, layers=LEARNED_LAYERS, share_filters=True, hImg=H, wImg=W, output_extraction_method="max")
+    model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
+    geo["hPatch2"], geo["wPatch2"] = mh + geo["hKernel"] - 1, mh + geo["wKernel"] - 1          # opticalflow.lua:188-189
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=12, max_flow=8, noise_sigma=0)
+    f0, f1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
+    full = model.forward([f0, f1]).clone()
+    vols = [v.clone() for v in model.volumes]
+    pre = dfe.getMultiscalePrefilter(geo, model.filters[0])
+    assert set(pre.getWeights()) == {"layer1", "layer2", "layer3"}
+    a = [t.clone() for t in pre.forward(f0)]
+    b = [t.clone() for t in pre.forward(f1)]
+    assert tuple(a[1].shape) == (10, H // 2 + mh - 1, W // 2 + mh - 1)
+    pm = dfe.getModelMultiscale(geo, True, True)
+    out = pm.forward([[a[s], b[s]] for s in range(len(ratios))])
+    for v, w in zip(pm.volumes, vols):
+        assert torch.equal(v, w)
+    assert torch.equal(out, full)
+    # focus: 1-based (x, y) like the Lua caller; training mode appends nn.Log2(1e-10)
+    geo_t = dict(geo, training_mode=True)
+    tm = dfe.MultiscaleModel(geo_t, model.filters, False)
+    for (x, y) in [(1, 1), (37, 22), (W, H), (5, H - 3)]:
+        tm.focus(x, y)
+        o = tm.forward([f0, f1])
+        assert tuple(o.shape) == (1, 1, full.shape[2])
+        want = torch.log(torch.clamp(full[y - 1, x - 1], min=1e-10))
+        assert torch.allclose(o.reshape(-1), want, rtol=0, atol=0) or float((o.reshape(-1) - want).abs().max()) <= 1e-6
+    tm.focus()
+    assert tuple(tm.forward([f0, f1]).shape) == tuple(full.shape)
+    # the raw-patch model focuses too
+    geo_r = dict(maxh=mh, maxw=mh, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
+    rm = dfe.getModelMultiscale(geo_r)
+    fullr = rm.forward([f0, f1]).clone()
+    rm.focus(30, 17)
+    o = rm.forward([f0, f1])
+    assert float((o.reshape(-1) - fullr[16, 29]).abs().max()) <= 1e-6
+
+
+def test_learned_multiscale_f16_and_full_vga(dfe, cuda):
+    """the bench workload `vga-pyramid-learned` (640x480, {1,2,4}, layers of tests/time_matching.lua): one call == staged bit for
+    bit, with fp32 and with half-rounded volumes; the planted flow is found."""
+    H, W, ratios = 480, 640, [1, 2, 4]
+    gen = torch.Generator().manual_seed(1)
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, layers=LEARNED_LAYERS, share_filters=True, hImg=H, wImg=W, output_extraction_method="max")
+    model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
+    f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=2, max_flow=12, noise_sigma=0)
+    t0, t1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
+    for sc in (None, 1.0):
+        one = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+        stg = model.forwardFlow([t0, t1], False, one_call=False, f16_scale=sc)
+        assert torch.equal(one["index"], stg["index"]) and torch.equal(one["y"], stg["y"]) and torch.equal(one["x"], stg["x"])
+
+
 # ------------------------------------------------------------------ the radial path as a path (BASELINE configs[2])
 def _radial_setup(dfe, cuda, hImg, wImg, hIn, wIn, layers, hWin=15, seed=0):
     networkp = dict(hImg=hImg, wImg=wImg, hInput=hIn, wInput=wIn, hWin=hWin, layers=layers)
