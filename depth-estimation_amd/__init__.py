@@ -15,6 +15,7 @@ no CPU fallback -- a missing library or device raises.
     nn.CascadingAddTable, getModelMultiscale            (CascadingAddTable.lua, opticalflow_model_multiscale.lua)
     getC2PMask, getP2CMask, cartesian2polar, flow2depth (radial/cartesian2polar.lua, radial_opticalflow_display.lua)
     torch7_io.load / save, load_calibration             (Torch7 binary files: *.cal, saveModel / saveNetwork weights)
+    saveModel, loadModel, loadWeightsFrom, saveNetwork, loadTesterNetwork, loadTrainerNetwork   (opticalflow_model_io.lua, radial_opticalflow_network.lua)
 """
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
@@ -40,7 +41,8 @@ from .network import getFilter, getFilterRadial, getModel, tables_random  # noqa
 from .radial import (getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth, getKOutput, getP2CMaskOF,  # noqa: F401
                      computeDepthMapFromFlow, getTesterNetwork, getTrainerNetwork, getMatcher, radialFlowDepth, radial_out_shape)
 from .glue import SmartReshape, FunctionWrapper, Mul2, Log2, OutputExtractor, postProcessImage, enlargeMask  # noqa: F401
-from . import torch7_io  # noqa: F401
+from . import torch7_io, model_io  # noqa: F401
+from .model_io import (saveModel, loadModel, loadWeightsFrom, saveNetwork, loadTesterNetwork, loadTrainerNetwork, copyWeights)  # noqa: F401
 from .torch7_io import load_calibration  # noqa: F401
 from .groundtruth import (  # noqa: F401
     unfold,

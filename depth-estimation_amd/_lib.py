@@ -123,7 +123,7 @@ class RadialParams(C.Structure):
     """dfe_radial_params (include/dfe.h)"""
     _fields_ = [("C", C.c_int), ("hImg", C.c_int), ("wImg", C.c_int), ("hInput", C.c_int), ("wInput", C.c_int), ("hWin", C.c_int),
                 ("n1", C.c_int), ("kW1", C.c_int), ("n2", C.c_int), ("kH2", C.c_int), ("tanh_between", C.c_int),
-                ("alpha_polar", C.c_float), ("kinfty", C.c_double)]
+                ("alpha_polar", C.c_float), ("kinfty", C.c_double), ("zero_last_row", C.c_int)]
 
 _lib = None
 

@@ -430,8 +430,9 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     if (rc) return rc;
     rc = radial_filter(ctx, p, pol1, H, Wp, w1, b1, w2, b2, tmp, feat2);
     if (rc) return rc;
-    // 3. matcher + arg-min (+ the volume when asked for); last flow row zeroed (train_radial:178-180)
-    rc = dfe_radial_match_argmin_f32(ctx, feat1, Hf2, feat2, p->n2, hm, W, p->hWin, volume, pflow, 1);
+    // 3. matcher + arg-min (+ the volume when asked for); the last flow row zeroed only on request (train_radial:178-180 does
+    //    it for its display; test_radial:204-207, the path this call replaces, does not)
+    rc = dfe_radial_match_argmin_f32(ctx, feat1, Hf2, feat2, p->n2, hm, W, p->hWin, volume, pflow, p->zero_last_row != 0);
     if (rc) return rc;
     {   // 4. polar flow -> cartesian -> depth (getP2CMaskOF + flow2depth with center2 = e2 * getKOutput)
         const double kOut = (double)hm / (double)H;

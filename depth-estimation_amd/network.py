@@ -397,4 +397,6 @@ def getModel(geometry, full_image=True, prefiltered=False, device="cuda", genera
         model.add(glue.OutputExtractor(get("maxh"), get("maxw")))
     elif get("training_mode", False):
         model.add(glue.Log2(1e-10))
+    # model:getWeights() (:119-125): the first filter branch's, nothing when prefiltered
+    model.getWeights = (lambda: {}) if prefiltered else (lambda: filter_weights(model.modules[0].modules[0]))
     return model

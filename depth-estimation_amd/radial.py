@@ -243,13 +243,15 @@ def radial_out_shape(networkp):
     return hPolar, int(networkp["hImg"] * k), int(networkp["wImg"] * k)
 
 
-def radialFlowDepth(networkp, network, prev_img, img, e2, kinfty=0.65, alpha_polar=1.0, one_call=True, want_volume=False):
+def radialFlowDepth(networkp, network, prev_img, img, e2, kinfty=0.65, alpha_polar=1.0, one_call=True, want_volume=False, zero_last_row=False):
     """radial/test_radial_opticalflow.lua:186-225 for one frame pair: polar warps of both frames around the epipole e2,
     getTesterNetwork:forward, min(3) - 1, back to cartesian through getP2CMaskOF, flow2depth.  prev_img is the previous
     frame after the caller's ego-motion correction (sfm2.removeEgoMotion: `sfm2.removeEgoMotion` of this package, or the caller's own).  Returns a dict
     polar_flow, flow (cartesian), depth, confs [, output = the matcher volume].
     one_call: everything inside dfe_radial_flow_depth_pair_f32 (default separable filter stacks); else the staged module
-    calls -- same numbers bit for bit."""
+    calls -- same numbers bit for bit.
+    zero_last_row: also zero the last polar flow row, as the trainer's display path does (train_radial:178-180:
+    `test:sub(h,h,1,w):zero()`); test_radial:204-207 -- the default here -- does not."""
     hK, wK = networkp_kernel_size(networkp)
     prev_img, img = prev_img.contiguous(), img.contiguous()
     Cc, hImg, wImg = img.shape
@@ -264,7 +266,7 @@ def radialFlowDepth(networkp, network, prev_img, img, e2, kinfty=0.65, alpha_pol
     if sep is not None and networkp["hWin"] in (8, 12, 15, 16):
         w1, b1, w2, b2, th = sep
         prm = RadialParams(Cc, hImg, wImg, networkp["hInput"], networkp["wInput"], networkp["hWin"], w1.shape[0], w1.shape[3], w2.shape[0], w2.shape[2],
-                           int(th), float(alpha_polar), float(kinfty))
+                           int(th), float(alpha_polar), float(kinfty), 1 if zero_last_row else 0)
         vol = torch.empty((hm, networkp["wInput"], networkp["hWin"]), dtype=torch.float32, device=dev) if want_volume else None
         pf = torch.empty((hm, networkp["wInput"]), dtype=torch.float32, device=dev)
         cart, depth, conf = (torch.empty((hOut, wOut), dtype=torch.float32, device=dev) for _ in range(3))
@@ -284,7 +286,8 @@ def radialFlowDepth(networkp, network, prev_img, img, e2, kinfty=0.65, alpha_pol
     ctx = get_ctx(output)
     ctx.check(lib().dfe_argbest_center(ctx.handle, ptr(output), H1 * Wi, hW, 0, 0, ptr(imin), None))   # output:min(3): first minimum, no centre rule
     idx = (imin - 1).to(torch.float32)                   # idx:add(-1), test_radial:207
-    idx[-1].zero_()                                      # train_radial:178-180
+    if zero_last_row:
+        idx[-1].zero_()                                  # train_radial:178-180 (the trainer's display path only)
     np2 = dict(networkp, hKernel=hK, wKernel=wK)
     p2c = getP2CMaskOF(np2, e2, alpha_polar, device=dev)
     cart = cartesian2polar(idx, p2c)

@@ -12,7 +12,7 @@ depth_estimation_api.lua:33-38) and the trained filter weights written by `saveM
     tag 4 torch:  int32 index; first occurrence: string "V 1" (newer files; absent in the oldest), string class name, then
                   torch.XTensor:  int32 ndim, ndim x int64 size, ndim x int64 stride, int64 storage offset (1-based), object storage
                   torch.XStorage: int64 n, n raw elements
-    tag 6 / 7 function (recursive function): int32 index; first occurrence: string dumped chunk, object upvalues (kept opaque)
+    tag 6 / 7 / 8 function (7 = legacy, 8 = current TYPE_RECUR_FUNCTION): int32 index; first occurrence: string dumped chunk, object upvalues (kept opaque)
 
 Tables whose keys are exactly 1..n come back as lists, other tables as dicts; tensors as numpy arrays (a copy with the
 file's sizes and strides applied); closures as Torch7Function(bytecode) placeholders.  `save` writes numbers, strings,
@@ -114,6 +114,8 @@ class _Reader:
                 return a
             if name in _TENSOR_STORAGE:
                 nd = self.take("i")
+                if nd < 0 or nd > 64:
+                    raise ValueError("torch7_io: tensor with %d dimensions" % nd)
                 size = [self.take("q") for _ in range(nd)]
                 stride = [self.take("q") for _ in range(nd)]
                 off = self.take("q") - 1
@@ -121,14 +123,25 @@ class _Reader:
                 if st is None or nd == 0:
                     t = np.zeros([0] * max(nd, 1), _STORAGE_DTYPES[_TENSOR_STORAGE[name]])
                 else:
-                    t = np.lib.stride_tricks.as_strided(st[off:], shape=size, strides=[s * st.itemsize for s in stride]).copy()
+                    # the file's geometry is untrusted: every size / stride non-negative and the last element inside the storage
+                    if not isinstance(st, np.ndarray) or st.dtype != np.dtype(_STORAGE_DTYPES[_TENSOR_STORAGE[name]]):
+                        raise ValueError("torch7_io: %s over a %s" % (name, type(st).__name__))
+                    if off < 0 or any(x < 0 for x in size) or any(x < 0 for x in stride):
+                        raise ValueError("torch7_io: tensor with negative offset / size / stride (%d, %s, %s)" % (off, size, stride))
+                    if all(x > 0 for x in size):
+                        last = off + sum((n - 1) * x for n, x in zip(size, stride))
+                        if last >= len(st):
+                            raise ValueError("torch7_io: tensor reaches element %d of a storage of %d" % (last, len(st)))
+                        t = np.lib.stride_tricks.as_strided(st[off:], shape=size, strides=[x * st.itemsize for x in stride]).copy()
+                    else:
+                        t = np.zeros(size, st.dtype)
                 self.memo[idx] = t
                 return t
             o = Torch7Object(name, None)                  # any other torch class serialises as its table of fields
             self.memo[idx] = o
             o.fields = self.obj()
             return o
-        if tag in (6, 7):
+        if tag in (6, 7, 8):     # legacy function / recursive function (old and current Torch7 File.lua numbering)
             idx = self.take("i")
             if idx in self.memo:
                 return self.memo[idx]

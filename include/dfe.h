@@ -126,7 +126,8 @@ int dfe_radial_matching_f32(dfe_ctx *ctx, const float *in1, const float *in2, in
  *   (radial/train_radial_opticalflow.lua:161-168, radial/test_radial_opticalflow.lua:204-207).  in1 [K][in1_plane_rows][W]
  *   (only the first H1 rows of a plane are read: the previous frame cropped by hWin-1 rows, network.lua:59;
  *   0 = H1), in2 [K][H1+hWin-1][W]; volume [H1][W][hWin] or NULL; flow [H1][W] = first-minimum index - 1 as float
- *   (TH min keeps the first minimum), its last row zeroed when zero_last_row (train_radial:178-180).
+ *   (TH min keeps the first minimum), its last row zeroed when zero_last_row (train_radial:178-180: the trainer's display
+ *   code does that; the inference script test_radial:204-207 does not).
  *   hWin in {8, 12, 15, 16}. */
 int dfe_radial_match_argmin_f32(dfe_ctx *ctx, const float *in1, int in1_plane_rows, const float *in2, int K, int H1, int W,
                                 int hWin, float *volume, float *flow, int zero_last_row);
@@ -142,6 +143,8 @@ typedef struct dfe_radial_params {
     int tanh_between;      /* non-zero: nn.Tanh between the layers */
     float alpha_polar;     /* radial exponent of the polar grid (1 = linear) */
     double kinfty;         /* flow2depth's infinity factor (0.65 in test_radial:225; a Lua number, i.e. a double) */
+    int zero_last_row;     /* 0 = radial/test_radial_opticalflow.lua:204-207 as shipped (idx = min(3) - 1, nothing else);
+                              non-zero = also `test:sub(h,h,1,w):zero()` of the trainer's display path (train_radial:178-180) */
 } dfe_radial_params;
 /* rows of the matcher output (hInput - hKernel - hWin + 2) and size of the cartesian flow / depth images
  * (floor(hImg * kOutput) x floor(wImg * kOutput), getP2CMaskOF radial/radial_opticalflow_polar.lua:18-30). */

@@ -206,10 +206,11 @@ def multiscale_filtered_oracle(f0, f1, stacks, maxh, maxw, ratios, f16_scale=Non
     return dict(joined=joined, idx=idx, best=best, y=y, x=x, middle=middle, vols=vols, feats=feats)
 
 
-def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between=False, kinfty=0.65, alpha=1.0):
+def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between=False, kinfty=0.65, alpha=1.0, zero_last_row=False):
     """radial/test_radial_opticalflow.lua:186-225 on the oracle, for the separable filter stack conv(1 x kW) [tanh] conv(kH x 1):
     getC2PMask(+ wrap columns) -> cartesian2polar of both frames -> getTesterNetwork (crop hWin-1 rows of the previous frame,
-    shared filter, SpatialRadialMatching) -> min(3) - 1 (last row zeroed, train_radial:178-180) -> getP2CMaskOF ->
+    shared filter, SpatialRadialMatching) -> min(3) - 1 (test_radial:204-207; the last row zeroed only with zero_last_row, which is
+    what the trainer's display code does, train_radial:178-180) -> getP2CMaskOF ->
     cartesian2polar of the flow -> flow2depth(center = e2 * getKOutput).  Returns dict(polar_prev, polar_img, feat1, feat2,
     output, polar_flow, flow, depth, confs)."""
     import math
@@ -235,7 +236,8 @@ def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between
     f1, f2 = filt(np.ascontiguousarray(pp[:, : hIn - hWin + 1])), filt(pi)      # SpatialPadding(0,0,0,-hWin+1) on the previous frame
     out = orc.radial_matching(f1, f2, hWin)
     pf = out.argmin(2).astype(np.float32)                                       # numpy argmin: first minimum
-    pf[-1] = 0
+    if zero_last_row:
+        pf[-1] = 0
     hPolar = hIn - kH - hWin + 2
     assert hPolar == out.shape[0]
     kOut = hPolar / hIn

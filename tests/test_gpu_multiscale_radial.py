@@ -827,8 +827,16 @@ def test_radial_path_one_call_equals_staged_and_oracle(dfe, cuda, layers, hIn, w
     pf, rf = one["polar_flow"].cpu().numpy(), ref["polar_flow"]
     srt = np.sort(ref["output"], -1)
     tie = (srt[..., 1] - srt[..., 0]) <= 1e-4 * srt[..., 1] + 1e-7
-    tie[-1] = True                                                                       # (zeroed row)
-    assert ((pf == rf) | tie).all() and (pf != rf).mean() < 0.02
+    assert ((pf == rf) | tie).all() and (pf != rf).mean() < 0.02                         # the LAST row too: test_radial does not zero it
+    assert float(np.abs(pf[-1]).max()) > 0
+    # the trainer's display variant (train_radial:178-180) zeroes the last row: everything else unchanged
+    z1 = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=True, zero_last_row=True)
+    z2 = dfe.radialFlowDepth(networkp, net, T(f0, cuda), T(f1, cuda), e2, one_call=False, zero_last_row=True)
+    assert float(z1["polar_flow"][-1].abs().max()) == 0 and torch.equal(z1["polar_flow"][:-1], one["polar_flow"][:-1])
+    for k in ("polar_flow", "flow", "depth", "confs"):
+        assert torch.equal(z1[k], z2[k]), k
+    refz = rp.radial_path_oracle(f0, f1, e2, networkp, w1, b1, w2, b2, tanh_between="tanh" in layers, zero_last_row=True)
+    assert (np.abs(z1["flow"].cpu().numpy() - refz["flow"]) <= 1e-4).mean() > 0.97
     same = np.abs(one["flow"].cpu().numpy() - ref["flow"]) <= 1e-4
     assert same.mean() > 0.97
     assert np.array_equal(one["confs"].cpu().numpy(), ref["confs"])
