@@ -162,6 +162,8 @@ def launch_ranks(gpus, argv):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
+    # the pool's host driver supports dmabuf IPC only: without this RCCL's (and torch's) cross-process buffer sharing fails with
+    # `hipIpcGetMemHandle: invalid argument` at init_process_group.  Already exported on the driver's boxes; kept for a bare shell.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
 
@@ -458,7 +460,11 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md)
             try:
                 tj = json.load(open(tpath))
-                if tj.get("kernel_rev") == lib.dfe_kernel_revision().decode():   # counters of another kernel revision say nothing
+                import hashlib
+
+                src = os.path.join(ROOT, "depth-estimation_amd", "csrc", "ssd_cost_volume.hip")
+                same_src = os.path.exists(src) and tj.get("source_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest()
+                if same_src and tj.get("kernel_rev") == lib.dfe_kernel_revision().decode():   # counters of another kernel version say nothing
                     traffic = tj.get("hbm_bytes_per_launch")
                     build_traffic = tj.get("build_only", {}).get("hbm_bytes_per_launch")
             except Exception:

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "dfe_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfe_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "dfe_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dfe_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dfe_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),

@@ -177,6 +177,23 @@ int dfe_host_unregister(dfe_ctx *ctx, void *ptr) {
     return DFE_OK;
 }
 
+int dfe_host_alloc(dfe_ctx *ctx, size_t bytes, void **hptr) {
+    DFE_REQUIRE(ctx, ctx && hptr && bytes > 0, DFE_E_ARG, "dfe_host_alloc: bad argument");
+    DfeDeviceGuard guard(ctx);
+    *hptr = nullptr;
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return DFE_OK;
+}
+
+int dfe_host_free(dfe_ctx *ctx, void *hptr) {
+    DFE_REQUIRE(ctx, ctx, DFE_E_ARG, "dfe_host_free: ctx is NULL");
+    if (!hptr) return DFE_OK;
+    DfeDeviceGuard guard(ctx);
+    DFE_HIP(ctx, hipHostFree(hptr));
+    return DFE_OK;
+}
+
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode) {
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, mode >= 0 && mode <= 3, DFE_E_ARG, "cost-volume kernel mode %d not in 0..3", mode);

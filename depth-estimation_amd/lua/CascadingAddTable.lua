@@ -1,15 +1,18 @@
 -- Drop-in for the reference's nn.CascadingAddTable on the MI355X path (UNTESTED here: no Lua runtime in the build image).
 -- Same constructor (ratios, trainable, single_beta), same updateOutput(table of (H*W) x Kh x Kw tensors) -> table of the
 -- same shapes, same error texts for the shape checks (CascadingAddTable.lua:108-135); updateGradInput follows :137-154.
--- HEAD's graph has no trainable parameter, so accGradParameters stays a no-op and `trainable` must be false.
+-- HEAD's graph has no trainable parameter (the Mul2 gains and the Power normaliser are commented out, :29,46,57,61), so
+-- `trainable` / `single_beta` are accepted and kept, like the reference's constructor and the Python mirror do
+-- (tests/test_cascad.lua:14 constructs the module with trainable = true), and accGradParameters stays a no-op.
 local dfe = require 'dfe_ffi'
 local ffi = require 'ffi'
 local CascadingAddTable, parent = torch.class('nn.CascadingAddTable', 'nn.Module')
 
 function CascadingAddTable:__init(ratios, trainable, single_beta)
    parent.__init(self)
-   assert(not trainable, 'nn.CascadingAddTable (dfe): the trainable variant is not part of the accelerated path')
    self.ratios = ratios
+   self.trainable = trainable or false
+   self.single_beta = single_beta or false
    self.output = {}
    self.gradInput = {}
    for i = 1, #ratios do

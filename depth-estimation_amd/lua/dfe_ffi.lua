@@ -6,7 +6,7 @@ local ffi = require 'ffi'
 
 ffi.cdef[[
 typedef struct dfe_ctx dfe_ctx;
-typedef struct dfe_radial_params { int C, hImg, wImg; int hInput, wInput; int hWin; int n1, kW1; int n2, kH2; int tanh_between; float alpha_polar; double kinfty; } dfe_radial_params;
+typedef struct dfe_radial_params { int C, hImg, wImg; int hInput, wInput; int hWin; int n1, kW1; int n2, kH2; int tanh_between; float alpha_polar; double kinfty; int zero_last_row; } dfe_radial_params;
 typedef struct dfe_filter_layer { int nIn, nOut, kH, kW; const float *weight; const float *bias; const int32_t *conn; int nConn; int tanh_after; } dfe_filter_layer;
 int dfe_version(void);
 const char *dfe_kernel_revision(void);
@@ -21,6 +21,8 @@ int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dfe_host_register(dfe_ctx *ctx, void *ptr, size_t bytes);
 int dfe_host_unregister(dfe_ctx *ctx, void *ptr);
+int dfe_host_alloc(dfe_ctx *ctx, size_t bytes, void **hptr);
+int dfe_host_free(dfe_ctx *ctx, void *hptr);
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 const char *dfe_last_kernel(const dfe_ctx *ctx);
@@ -103,9 +105,7 @@ function M.check(rc)
 end
 
 -- Device buffers are PERSISTENT: one per (module instance, role), grown when the tensor it mirrors grows, never freed per
--- call (a VGA SpatialMatching would otherwise spend far longer in hipMalloc / hipFree than in its kernel).  Host tensors
--- that are handed over again and again (a module's output, the frames of a video loop) are pinned in place on first
--- sight (dfe_host_register), so the copies are direct DMA; a tensor whose storage moved is re-pinned.
+-- call (a VGA SpatialMatching would otherwise spend far longer in hipMalloc / hipFree than in its kernel).
 local Buffer = {}
 Buffer.__index = Buffer
 function M.newBuffer() return setmetatable({ptr = nil, bytes = 0}, Buffer) end
@@ -123,19 +123,23 @@ function Buffer:free()
    self.ptr, self.bytes = nil, 0
 end
 
-local pinned = {}   -- storage address (number) -> bytes
-local function pin(t)
-   local p, bytes = t:data(), t:nElement() * t:elementSize()
-   local key = tonumber(ffi.cast('intptr_t', p))
-   if pinned[key] == nil or pinned[key] < bytes then
-      if pinned[key] ~= nil then M.check(M.lib.dfe_host_unregister(M.ctx, p)) end
-      M.check(M.lib.dfe_host_register(M.ctx, p, bytes))
-      pinned[key] = bytes
+-- Host <-> device copies go through ONE library-owned pinned bounce buffer (dfe_host_alloc = hipHostMalloc), grown on demand
+-- and reused by every module: direct DMA without ever pinning memory this binding does not own.  (The first version pinned
+-- the tensors' own storage in place through dfe_host_register -- including the temporaries of :contiguous() / :long(), which
+-- the garbage collector frees while they are still registered; a later tensor at the same address then inherited a stale
+-- registration that maps the OLD physical pages.  Torch tensor storage is never registered any more.)  dfe_memcpy_* are
+-- synchronous, so one bounce buffer serves all copies of the single Lua thread.
+local bounce = {ptr = nil, bytes = 0}
+local function bounce_reserve(bytes)
+   if bytes > bounce.bytes then
+      if bounce.ptr ~= nil then M.check(M.lib.dfe_host_free(M.ctx, bounce.ptr)) end
+      bounce.ptr, bounce.bytes = nil, 0
+      local want = math.max(bytes, 2 * bounce.bytes, 1048576)
+      local p = ffi.new('void*[1]')
+      M.check(M.lib.dfe_host_alloc(M.ctx, want, p))
+      bounce.ptr, bounce.bytes = p[0], want
    end
-end
-function M.unpin(t)
-   local key = tonumber(ffi.cast('intptr_t', t:data()))
-   if pinned[key] ~= nil then M.check(M.lib.dfe_host_unregister(M.ctx, t:data())); pinned[key] = nil end
+   return bounce.ptr
 end
 
 -- the C ABI is typed: a DoubleTensor uploaded byte for byte would be read as floats
@@ -150,15 +154,22 @@ function M.upload(t, buf)
    t = t:contiguous()
    local bytes = t:nElement() * t:elementSize()
    local d = buf:reserve(bytes)
-   pin(t)
-   M.check(M.lib.dfe_memcpy_h2d(M.ctx, d, t:data(), bytes))
+   if bytes > 0 then
+      local h = bounce_reserve(bytes)
+      ffi.copy(h, t:data(), bytes)
+      M.check(M.lib.dfe_memcpy_h2d(M.ctx, d, h, bytes))
+   end
    return d, bytes
 end
 
 function M.download(t, dptr)
    assert(t:isContiguous())
-   pin(t)
-   M.check(M.lib.dfe_memcpy_d2h(M.ctx, t:data(), dptr, t:nElement() * t:elementSize()))
+   local bytes = t:nElement() * t:elementSize()
+   if bytes > 0 then
+      local h = bounce_reserve(bytes)
+      M.check(M.lib.dfe_memcpy_d2h(M.ctx, h, dptr, bytes))
+      ffi.copy(t:data(), h, bytes)
+   end
 end
 
 return M

@@ -61,6 +61,10 @@ int dfe_memcpy_d2h(dfe_ctx *ctx, void *dst, const void *src, size_t bytes); /* s
  * Registering a range twice, or unregistering an unknown one, is not an error.  Unregister before the memory is freed. */
 int dfe_host_register(dfe_ctx *ctx, void *ptr, size_t bytes);
 int dfe_host_unregister(dfe_ctx *ctx, void *ptr);
+/* Library-owned pinned host memory (hipHostMalloc): the bounce buffer a binding stages its tensors through, so that it never
+ * has to pin memory it does not own (garbage-collected temporaries, storage that is resized or freed behind its back). */
+int dfe_host_alloc(dfe_ctx *ctx, size_t bytes, void **hptr);
+int dfe_host_free(dfe_ctx *ctx, void *hptr);
 /* cost-volume kernel selection (tuning / tests; also the DFE_CV_MODE environment variable at context creation):
  * 0 = auto (default: the row-image kernel where it applies -- C=3, 7x7 patch, 769..1096 window cells, e.g. 33x33 --
  * else the tiled kernel, else the reference-order kernel), 1 = force the reference-order kernel (bit-identical float
