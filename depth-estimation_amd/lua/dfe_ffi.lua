@@ -89,6 +89,8 @@ int dfe_epipole(const double *K9, const double *T3, double scale, double *e2_xy)
 int dfe_remove_ego_motion_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *R9, int inverse, float *out, float *mask);
 int dfe_undistort_image_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *dist5, float *out);
 int dfe_foe_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W, float min_flow, int iterations, double *foe_xy, double *n_used);
+int dfe_ego_motion_from_points_f32(dfe_ctx *ctx, const float *pts1, const float *pts2, const float *weights, int N, const double *K9, double ransac_max_dist, int iterations, unsigned seed, double *R9, double *T3, int *n_inliers, double *F9);
+int dfe_ego_motion_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W, const double *K9, int max_points, double ransac_max_dist, int iterations, unsigned seed, double *R9, double *T3, int *n_found, int *n_inliers, double *F9);
 ]]
 
 local M = {}

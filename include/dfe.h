@@ -470,11 +470,33 @@ int dfe_remove_ego_motion_f32(dfe_ctx *ctx, const float *img, int C, int H, int 
 /* sfm2.undistortImage(img, K, distP): inverse-map undistortion with the (k1, k2, p1, p2, k3) model of the .cal files. */
 int dfe_undistort_image_f32(dfe_ctx *ctx, const float *img, int C, int H, int W, const double *K9, const double *dist5,
                             float *out);
-/* Focus of expansion of a dense flow field (flow_y, flow_x [H][W]; conf [H][W] or NULL: pixels with conf <= 0 or
+/* NOT IN THE REFERENCE: an estimator of this library for the pure-translation case (the reference obtains the focus of expansion
+ * as the epipole K T of sfm2.getEgoMotion2's pose: dfe_ego_motion_from_*_f32 + dfe_epipole below are that route).
+ * Focus of expansion of a dense flow field (flow_y, flow_x [H][W]; conf [H][W] or NULL: pixels with conf <= 0 or
  * |flow| < min_flow are skipped): least-squares intersection of the flow lines, `iterations` Huber re-weightings (0..16).
  * foe_xy = (x, y) in pixels (host); n_used (may be NULL) = sum of the weights.  DFE_E_ARG when the lines are parallel. */
 int dfe_foe_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W,
                           float min_flow, int iterations, double *foe_xy, double *n_used);
+
+/* ---- N4, the core: relative pose of the two frames from correspondences ------------------------------------------------------
+ * replaces: sfm2.getEgoMotion2{im1, im2, K, maxPoints, pointsQuality, ransacMaxDist, pointsMinDistance} -> R, T, nFound, nInliers,
+ *   fundmat (radial/radial_opticalflow_data.lua:211-217, radial/test_radial_opticalflow.lua:122-126; sfm2.getEgoMotion at
+ *   depth_estimation_api.lua:141).  sfm2 (un-vendored, OpenCV) finds and tracks sparse corners itself; here the correspondences
+ *   are an INPUT: pts1 / pts2 [N][2] = (x, y) pixel positions in the previous / current frame (device floats; weights [N] or NULL:
+ *   entries <= 0 are skipped), or samples of the dense flow the matcher has produced (_from_flow: p2 = p1 + flow(p1) on a centred
+ *   regular grid of at most max_points samples, conf <= 0 skipped).  `iterations` 8-point RANSAC hypotheses are built and scored
+ *   in parallel on the device (Sampson distance <= ransac_max_dist pixels), the best is refitted over its inliers, projected onto
+ *   the essential manifold and decomposed; cheirality picks among the four (R, T).  Restated from the calling convention: parity
+ *   unpinned (3P).  Outputs (host doubles): R9 row-major, T3 (|T| = 1) with x2 ~ R x1 + T for camera coordinates of frame 1 in
+ *   frame 2 -- so K T is the epipole in the current frame (data.lua:218) and dfe_remove_ego_motion_f32(prev, K, R, inverse = 1) undoes
+ *   the rotation --, F9 = K^-T [T]x R K^-1 with unit Frobenius norm (may be NULL), n_found = usable samples, n_inliers.
+ *   Deterministic for a given seed.  Synchronises.  DFE_E_ARG when no hypothesis reaches 8 inliers. */
+int dfe_ego_motion_from_points_f32(dfe_ctx *ctx, const float *pts1, const float *pts2, const float *weights, int N, const double *K9,
+                                   double ransac_max_dist, int iterations, unsigned seed, double *R9, double *T3, int *n_inliers,
+                                   double *F9);
+int dfe_ego_motion_from_flow_f32(dfe_ctx *ctx, const float *flow_y, const float *flow_x, const float *conf, int H, int W,
+                                 const double *K9, int max_points, double ransac_max_dist, int iterations, unsigned seed, double *R9,
+                                 double *T3, int *n_found, int *n_inliers, double *F9);
 
 #ifdef __cplusplus
 }

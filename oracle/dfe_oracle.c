@@ -1042,3 +1042,318 @@ void orc_output_extractor(const float *input, int64_t P, int maxh, int maxw, flo
         x[p] = sx; y[p] = sy;
     }
 }
+
+/* ======================================================================================================================
+ * next-row N4: ego-motion rectification and relative pose.  The reference takes all of it from the un-vendored,
+ * OpenCV-backed `sfm2` package -- nothing of sfm2 is in the repository -- so these follow the CALL SITES (what goes in,
+ * what the results are used for); "parity unpinned (3P)".
+ * ====================================================================================================================== */
+static float orc_bilin_clamped(const float *p, int H, int W, float fy, float fx) {
+    fy = fy < 0 ? 0 : (fy > (float)(H - 1) ? (float)(H - 1) : fy);
+    fx = fx < 0 ? 0 : (fx > (float)(W - 1) ? (float)(W - 1) : fx);
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+    float wy = fy - (float)y0, wx = fx - (float)x0;
+    float top = (1 - wx) * p[(size_t)y0 * W + x0] + wx * p[(size_t)y0 * W + x1];
+    float bot = (1 - wx) * p[(size_t)y1 * W + x0] + wx * p[(size_t)y1 * W + x1];
+    return (1 - wy) * top + wy * bot;
+}
+
+static int orc_inv3(const double *m, double *o) {
+    double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (fabs(d) < 1e-300) return -1;
+    o[0] = (m[4] * m[8] - m[5] * m[7]) / d; o[1] = (m[2] * m[7] - m[1] * m[8]) / d; o[2] = (m[1] * m[5] - m[2] * m[4]) / d;
+    o[3] = (m[5] * m[6] - m[3] * m[8]) / d; o[4] = (m[0] * m[8] - m[2] * m[6]) / d; o[5] = (m[2] * m[3] - m[0] * m[5]) / d;
+    o[6] = (m[3] * m[7] - m[4] * m[6]) / d; o[7] = (m[1] * m[6] - m[0] * m[7]) / d; o[8] = (m[0] * m[4] - m[1] * m[3]) / d;
+    return 0;
+}
+static void orc_mul3(const double *a, const double *b, double *o) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+/* ref: `e2 = calibrationp.K * T; e2 = e2 / e2[3]; e2 = e2*networkp.wImg/calibrationp.wImg`
+ *      radial/radial_opticalflow_data.lua:218-220 (= radial/test_radial_opticalflow.lua:128-130,170) */
+int orc_epipole(const double *K9, const double *T3, double scale, double *e2) {
+    double x = K9[0] * T3[0] + K9[1] * T3[1] + K9[2] * T3[2], y = K9[3] * T3[0] + K9[4] * T3[1] + K9[5] * T3[2],
+           z = K9[6] * T3[0] + K9[7] * T3[1] + K9[8] * T3[2];
+    if (z == 0) return -1;
+    e2[0] = x / z * scale;
+    e2[1] = y / z * scale;
+    return 0;
+}
+
+/* ref: `prev_img, prev_img_mask = sfm2.removeEgoMotion(prev_img, Ksmall, R, 'bilinear')` radial/radial_opticalflow_data.lua:231,
+ *      depth_estimation_api.lua:147, test_opticalflow.lua:284.  A rotation between two views of a static scene moves pixels by the
+ *      homography K R K^-1; out(p) = bilinear(img, K R K^-1 p) (inverse: R^T), mask = 1 where the source is inside the frame (the
+ *      callers erode and polar-warp the mask, data.lua:233-240). */
+int orc_remove_ego_motion(const float *img, int C, int H, int W, const double *K9, const double *R9, int inverse, float *out, float *mask) {
+    double Ki[9], Rt[9], t[9], Hd[9];
+    if (orc_inv3(K9, Ki)) return -1;
+    const double *Ru = R9;
+    if (inverse) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Rt[i * 3 + j] = R9[j * 3 + i];
+        Ru = Rt;
+    }
+    orc_mul3(K9, Ru, t);
+    orc_mul3(t, Ki, Hd);
+    float Hm[9];
+    for (int i = 0; i < 9; ++i) Hm[i] = (float)Hd[i];
+    size_t P = (size_t)H * W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float X = Hm[0] * x + Hm[1] * y + Hm[2], Y = Hm[3] * x + Hm[4] * y + Hm[5], Z = Hm[6] * x + Hm[7] * y + Hm[8];
+            float sx = X / Z, sy = Y / Z;
+            int in = Z > 0 && sx >= 0 && sx <= (float)(W - 1) && sy >= 0 && sy <= (float)(H - 1);
+            for (int c = 0; c < C; ++c) out[c * P + (size_t)y * W + x] = in ? orc_bilin_clamped(img + c * P, H, W, sy, sx) : 0.f;
+            if (mask) mask[(size_t)y * W + x] = in ? 1.f : 0.f;
+        }
+    return 0;
+}
+
+/* ref: `img = sfm2.undistortImage(img, calibrationp.K, calibrationp.distortion)` radial/radial_opticalflow_data.lua:24,
+ *      depth_estimation_api.lua:139 with the 5-entry distortion vectors of the .cal files = (k1, k2, p1, p2, k3), the
+ *      radial-tangential model: out(p) = bilinear(img, K distort(K^-1 p)). */
+void orc_undistort_image(const float *img, int C, int H, int W, const double *K9, const double *d5, float *out) {
+    float fx = (float)K9[0], fy = (float)K9[4], cx = (float)K9[2], cy = (float)K9[5];
+    float k1 = (float)d5[0], k2 = (float)d5[1], p1 = (float)d5[2], p2 = (float)d5[3], k3 = (float)d5[4];
+    size_t P = (size_t)H * W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float xn = ((float)x - cx) / fx, yn = ((float)y - cy) / fy;
+            float r2 = xn * xn + yn * yn;
+            float rad = 1.f + r2 * (k1 + r2 * (k2 + r2 * k3));
+            float xd = xn * rad + 2.f * p1 * xn * yn + p2 * (r2 + 2.f * xn * xn);
+            float yd = yn * rad + p1 * (r2 + 2.f * yn * yn) + 2.f * p2 * xn * yn;
+            float sx = xd * fx + cx, sy = yd * fy + cy;
+            int in = sx >= 0 && sx <= (float)(W - 1) && sy >= 0 && sy <= (float)(H - 1);
+            for (int c = 0; c < C; ++c) out[c * P + (size_t)y * W + x] = in ? orc_bilin_clamped(img + c * P, H, W, sy, sx) : 0.f;
+        }
+}
+
+/* NOT IN THE REFERENCE (the library's dense-flow focus-of-expansion estimator, dfe_foe_from_flow_f32): least-squares intersection
+ * of the flow lines, Huber re-weighted.  Restated here only so that the device code has a CPU counterpart. */
+int orc_foe_from_flow(const float *fy, const float *fx, const float *conf, int H, int W, float min_flow, int iterations, double *foe, double *n_used) {
+    double cx = W / 2.0, cy = H / 2.0;
+    for (int it = 0; it <= iterations; ++it) {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t e = (size_t)y * W + x;
+                float u = fx[e], v = fy[e];
+                float mag = sqrtf(u * u + v * v);
+                if (mag < min_flow || (conf && conf[e] <= 0.f)) continue;
+                double nx = -v / mag, ny = u / mag, w = 1.0;
+                if (it > 0) {
+                    double r = fabs(nx * ((double)(float)cx - x) + ny * ((double)(float)cy - y));
+                    w = r <= 2.0 ? 1.0 : 2.0 / r;
+                }
+                double np = nx * x + ny * y;
+                s[0] += w * nx * nx; s[1] += w * nx * ny; s[2] += w * ny * ny; s[3] += w * nx * np; s[4] += w * ny * np;
+            }
+        double det = s[0] * s[2] - s[1] * s[1];
+        if (n_used) *n_used = s[0] + s[2];
+        if (!(fabs(det) > 1e-9 * (s[0] + s[2]) * (s[0] + s[2]) + 1e-300)) return -1;
+        cx = (s[2] * s[3] - s[1] * s[4]) / det;
+        cy = (s[0] * s[4] - s[1] * s[3]) / det;
+    }
+    foe[0] = cx; foe[1] = cy;
+    return 0;
+}
+
+/* ---- relative pose from correspondences --------------------------------------------------------------------------------
+ * ref: `R, T, nFound, nInliers, fundmat = sfm2.getEgoMotion2{im1, im2, K, maxPoints, pointsQuality, ransacMaxDist,
+ *      pointsMinDistance}` radial/radial_opticalflow_data.lua:211-217, radial/test_radial_opticalflow.lua:122-126;
+ *      `sfm2.getEgoMotion(last_im, im, Kf, 400)` depth_estimation_api.lua:141.  Used as: e2 = K T (data.lua:218),
+ *      removeEgoMotion(prev, K, R) (:231), nInliers / nFound < bad_image_threshold (:222).
+ * sfm2 finds its correspondences itself (OpenCV corners + LK); here they are an input.  Then the textbook pipeline: RANSAC over
+ * 8-point fundamental-matrix hypotheses (Sampson distance), least-squares refit over the consensus set, projection onto the
+ * essential manifold, the four-fold decomposition, cheirality.  Same counter-based sampling as the device code (so that both draw
+ * the same hypotheses), everything else written independently. */
+static void orc_jacobi(double *A, double *V, int n) {   /* symmetric A (n x n, row-major) -> eigenvalues on the diagonal, vectors = columns of V */
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = i == j;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0, dg = 0;
+        for (int i = 0; i < n; ++i) {
+            dg += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; ++j) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-32 * dg) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double apq = A[p * n + q];
+                if (apq == 0) continue;
+                double th = (A[q * n + q] - A[p * n + p]) / (2 * apq);
+                double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1));
+                double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < n; ++k) {
+                    double a = A[k * n + p], b = A[k * n + q];
+                    A[k * n + p] = c * a - s * b; A[k * n + q] = s * a + c * b;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double a = A[p * n + k], b = A[q * n + k];
+                    A[p * n + k] = c * a - s * b; A[q * n + k] = s * a + c * b;
+                }
+                for (int k = 0; k < n; ++k) {
+                    double a = V[k * n + p], b = V[k * n + q];
+                    V[k * n + p] = c * a - s * b; V[k * n + q] = s * a + c * b;
+                }
+            }
+    }
+}
+static unsigned orc_ego_rand(unsigned seed, unsigned h, unsigned k) {
+    unsigned x = seed * 0x9E3779B1u ^ (h + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (k + 0x165667B1u) * 0xC2B2AE35u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+static void orc_cam(const double *Ki, double u, double v, double *o) {
+    o[0] = Ki[0] * u + Ki[1] * v + Ki[2]; o[1] = Ki[3] * u + Ki[4] * v + Ki[5]; o[2] = Ki[6] * u + Ki[7] * v + Ki[8];
+}
+/* E -> U diag(1,1,0) V^T (U, V right-handed, columns); 0 on success */
+static int orc_essential_svd(const double *E, double *Ep, double *U, double *V) {
+    double M[9], Q[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[i * 3 + j] = E[i] * E[j] + E[3 + i] * E[3 + j] + E[6 + i] * E[6 + j];
+    orc_jacobi(M, Q, 3);
+    int o[3] = {0, 1, 2};
+    for (int a = 0; a < 2; ++a)
+        for (int b = a + 1; b < 3; ++b)
+            if (M[o[b] * 4] > M[o[a] * 4]) { int t = o[a]; o[a] = o[b]; o[b] = t; }
+    double s1 = sqrt(M[o[0] * 4] > 0 ? M[o[0] * 4] : 0), s2 = sqrt(M[o[1] * 4] > 0 ? M[o[1] * 4] : 0);
+    if (!(s1 > 0) || !(s2 > 1e-9 * s1)) return -1;
+    double v1[3], v2[3], v3[3], u1[3], u2[3], u3[3];
+    for (int i = 0; i < 3; ++i) { v1[i] = Q[i * 3 + o[0]]; v2[i] = Q[i * 3 + o[1]]; }
+    v3[0] = v1[1] * v2[2] - v1[2] * v2[1]; v3[1] = v1[2] * v2[0] - v1[0] * v2[2]; v3[2] = v1[0] * v2[1] - v1[1] * v2[0];
+    for (int i = 0; i < 3; ++i) {
+        u1[i] = (E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2]) / s1;
+        u2[i] = (E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2]) / s2;
+    }
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    for (int i = 0; i < 3; ++i) u1[i] /= n1;
+    double d = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+    for (int i = 0; i < 3; ++i) u2[i] -= d * u1[i];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    if (!(n2 > 1e-12)) return -1;
+    for (int i = 0; i < 3; ++i) u2[i] /= n2;
+    u3[0] = u1[1] * u2[2] - u1[2] * u2[1]; u3[1] = u1[2] * u2[0] - u1[0] * u2[2]; u3[2] = u1[0] * u2[1] - u1[1] * u2[0];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ep[i * 3 + j] = u1[i] * v1[j] + u2[i] * v2[j];
+    if (U)
+        for (int i = 0; i < 3; ++i) {
+            U[i * 3] = u1[i]; U[i * 3 + 1] = u2[i]; U[i * 3 + 2] = u3[i];
+            V[i * 3] = v1[i]; V[i * 3 + 1] = v2[i]; V[i * 3 + 2] = v3[i];
+        }
+    return 0;
+}
+static void orc_fund(const double *E, const double *Ki, double *F) {
+    double KiT[9], t[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KiT[i * 3 + j] = Ki[j * 3 + i];
+    orc_mul3(KiT, E, t);
+    orc_mul3(t, Ki, F);
+}
+static double orc_sampson2(const double *F, double x1, double y1, double x2, double y2) {
+    double a0 = F[0] * x1 + F[1] * y1 + F[2], a1 = F[3] * x1 + F[4] * y1 + F[5], a2 = F[6] * x1 + F[7] * y1 + F[8];
+    double b0 = F[0] * x2 + F[3] * y2 + F[6], b1 = F[1] * x2 + F[4] * y2 + F[7];
+    double r = x2 * a0 + y2 * a1 + a2, den = a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1;
+    return den > 0 ? r * r / den : 1e300;
+}
+static void orc_normal_rows(const double *Ki, const float *p1, const float *p2, int n, double *A /* 81, accumulated */) {
+    double a[3], b[3], r[9];
+    orc_cam(Ki, p1[2 * n], p1[2 * n + 1], a);
+    orc_cam(Ki, p2[2 * n], p2[2 * n + 1], b);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) r[3 * i + j] = b[i] * a[j];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) A[i * 9 + j] += r[i] * r[j];
+}
+static int orc_null_essential(double *A, double *Ep, double *U, double *V) {
+    double Q[81], E[9];
+    orc_jacobi(A, Q, 9);
+    int mn = 0;
+    for (int i = 1; i < 9; ++i)
+        if (A[i * 10] < A[mn * 10]) mn = i;
+    for (int i = 0; i < 9; ++i) E[i] = Q[i * 9 + mn];
+    return orc_essential_svd(E, Ep, U, V);
+}
+
+int orc_ego_motion_from_points(const float *p1, const float *p2, const float *w, int N, const double *K9, double max_dist, int iterations, unsigned seed,
+                               double *R9, double *T3, int *n_inliers, double *F9) {
+    double Ki[9];
+    if (N < 8 || orc_inv3(K9, Ki)) return -1;
+    double bestF[9];
+    int bestc = -1;
+    const double md2 = max_dist * max_dist;
+    for (int h = 0; h < iterations; ++h) {
+        int pick[8], ok = 1;
+        unsigned k = 0;
+        for (int n = 0; n < 8 && ok; ++n)
+            for (int tries = 0;; ++tries) {
+                if (tries > 64) { ok = 0; break; }
+                int c = (int)(orc_ego_rand(seed, (unsigned)h, k++) % (unsigned)N);
+                if (w && !(w[c] > 0.f)) continue;
+                int dup = 0;
+                for (int m = 0; m < n; ++m) dup |= pick[m] == c;
+                if (!dup) { pick[n] = c; break; }
+            }
+        if (!ok) continue;
+        double A[81] = {0}, Ep[9], F[9];
+        for (int n = 0; n < 8; ++n) orc_normal_rows(Ki, p1, p2, pick[n], A);
+        if (orc_null_essential(A, Ep, NULL, NULL)) continue;
+        orc_fund(Ep, Ki, F);
+        int c = 0;
+        for (int n = 0; n < N; ++n)
+            if (!w || w[n] > 0.f) c += orc_sampson2(F, p1[2 * n], p1[2 * n + 1], p2[2 * n], p2[2 * n + 1]) <= md2;
+        if (c > bestc) { bestc = c; memcpy(bestF, F, sizeof F); }
+    }
+    if (bestc < 8) return -2;
+    double A[81] = {0}, Ep[9], U[9], V[9];
+    unsigned char *mask = (unsigned char *)calloc((size_t)N, 1);
+    for (int n = 0; n < N; ++n)
+        if ((!w || w[n] > 0.f) && orc_sampson2(bestF, p1[2 * n], p1[2 * n + 1], p2[2 * n], p2[2 * n + 1]) <= md2) { mask[n] = 1; orc_normal_rows(Ki, p1, p2, n, A); }
+    if (orc_null_essential(A, Ep, U, V)) { free(mask); return -3; }
+    const double Wm[9] = {0, -1, 0, 1, 0, 0, 0, 0, 1}, Wt[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+    double VT[9], t[9], Ra[9], Rb[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) VT[i * 3 + j] = V[j * 3 + i];
+    orc_mul3(U, Wm, t); orc_mul3(t, VT, Ra);
+    orc_mul3(U, Wt, t); orc_mul3(t, VT, Rb);
+    double u3[3] = {U[2], U[5], U[8]};
+    int bc = -1, bg = -1;
+    for (int c = 0; c < 4; ++c) {
+        const double *R = c < 2 ? Ra : Rb;
+        double tt[3] = {(c & 1) ? -u3[0] : u3[0], (c & 1) ? -u3[1] : u3[1], (c & 1) ? -u3[2] : u3[2]};
+        int good = 0;
+        for (int n = 0; n < N; ++n) {
+            if (!mask[n]) continue;
+            double a[3], b[3], ra[3];
+            orc_cam(Ki, p1[2 * n], p1[2 * n + 1], a);
+            orc_cam(Ki, p2[2 * n], p2[2 * n + 1], b);
+            for (int i = 0; i < 3; ++i) ra[i] = R[i * 3] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2];
+            double m00 = ra[0] * ra[0] + ra[1] * ra[1] + ra[2] * ra[2], m01 = -(ra[0] * b[0] + ra[1] * b[1] + ra[2] * b[2]);
+            double m11 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+            double r0 = -(ra[0] * tt[0] + ra[1] * tt[1] + ra[2] * tt[2]), r1 = b[0] * tt[0] + b[1] * tt[1] + b[2] * tt[2];
+            double det = m00 * m11 - m01 * m01;
+            if (fabs(det) < 1e-18) continue;
+            double z1 = (r0 * m11 - m01 * r1) / det, z2 = (m00 * r1 - m01 * r0) / det;
+            good += z1 > 0 && z2 > 0;
+        }
+        if (good > bg) { bg = good; bc = c; }
+    }
+    memcpy(R9, bc < 2 ? Ra : Rb, sizeof Ra);
+    for (int i = 0; i < 3; ++i) T3[i] = (bc & 1) ? -u3[i] : u3[i];
+    double F[9], fn = 0;
+    orc_fund(Ep, Ki, F);
+    for (int i = 0; i < 9; ++i) fn += F[i] * F[i];
+    fn = sqrt(fn);
+    int cnt = 0;
+    for (int n = 0; n < N; ++n)
+        if (mask[n]) cnt += orc_sampson2(F, p1[2 * n], p1[2 * n + 1], p2[2 * n], p2[2 * n + 1]) <= md2;
+    if (n_inliers) *n_inliers = cnt;
+    if (F9)
+        for (int i = 0; i < 9; ++i) F9[i] = F[i] / (fn > 0 ? fn : 1);
+    free(mask);
+    return 0;
+}

@@ -187,6 +187,18 @@ void orc_enlarge_mask(float *mask, int H, int W, int ix, int iy);
  * input [P][maxh*maxw] -> x[P] = sum_k input*j(k), y[P] = sum_k input*i(k), 1-based cell coordinates */
 void orc_output_extractor(const float *input, int64_t P, int maxh, int maxw, float *x, float *y);
 
+/* ---- next-row N4 (call sites only: `sfm2` is un-vendored; parity unpinned) ------------------------------------------ */
+int orc_epipole(const double *K9, const double *T3, double scale, double *e2_xy);   /* ref: radial/radial_opticalflow_data.lua:218-220 */
+int orc_remove_ego_motion(const float *img, int C, int H, int W, const double *K9, const double *R9, int inverse, float *out,
+                          float *mask); /* ref: radial/radial_opticalflow_data.lua:231, depth_estimation_api.lua:147 */
+void orc_undistort_image(const float *img, int C, int H, int W, const double *K9, const double *dist5,
+                         float *out);   /* ref: radial/radial_opticalflow_data.lua:24, depth_estimation_api.lua:139 */
+int orc_foe_from_flow(const float *fy, const float *fx, const float *conf, int H, int W, float min_flow, int iterations, double *foe_xy,
+                      double *n_used);  /* not in the reference: counterpart of dfe_foe_from_flow_f32 */
+int orc_ego_motion_from_points(const float *pts1, const float *pts2, const float *weights, int N, const double *K9, double ransac_max_dist,
+                               int iterations, unsigned seed, double *R9, double *T3, int *n_inliers,
+                               double *F9); /* ref: radial/radial_opticalflow_data.lua:211-217, depth_estimation_api.lua:141 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,12 @@ def lib():
             "orc_postprocess_image": (C.c_int, [f32p, f32p] + [C.c_int] * 4 + [f32p]),
             "orc_enlarge_mask": (None, [f32p] + [C.c_int] * 4),
             "orc_output_extractor": (None, [f32p, C.c_int64, C.c_int, C.c_int, f32p, f32p]),
+            "orc_epipole": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]),
+            "orc_remove_ego_motion": (C.c_int, [f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, f32p, C.c_void_p]),
+            "orc_undistort_image": (None, [f32p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), f32p]),
+            "orc_foe_from_flow": (C.c_int, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+            "orc_ego_motion_from_points": (C.c_int, [f32p, f32p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int, C.c_uint, C.POINTER(C.c_double),
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
         }
         for n, (r, a) in sig.items():
             f = getattr(l, n)
@@ -456,3 +462,52 @@ def output_extractor(inp, maxh, maxw):
     x, y = np.empty(inp.shape[:-1], np.float32), np.empty(inp.shape[:-1], np.float32)
     lib().orc_output_extractor(inp.reshape(P, maxh * maxw), P, maxh, maxw, x.reshape(-1), y.reshape(-1))
     return x, y
+
+
+# ---- next-row N4 (sfm2 call sites; parity unpinned) ------------------------------------------------------------------
+def _dv(a, n):
+    v = np.asarray(a, np.float64).reshape(-1)
+    assert v.size == n
+    return (C.c_double * n)(*v.tolist())
+
+
+def epipole(K, T, scale=1.0):
+    e = (C.c_double * 2)()
+    rc = lib().orc_epipole(_dv(K, 9), _dv(T, 3), float(scale), e)
+    return rc, (e[0], e[1])
+
+
+def remove_ego_motion(img, K, R, inverse=False):
+    img = _f(img)
+    Cc, H, W = img.shape
+    out, mask = np.empty_like(img), np.empty((H, W), np.float32)
+    rc = lib().orc_remove_ego_motion(img, Cc, H, W, _dv(K, 9), _dv(R, 9), int(inverse), out, mask.ctypes.data)
+    assert rc == 0
+    return out, mask
+
+
+def undistort_image(img, K, dist):
+    img = _f(img)
+    Cc, H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_undistort_image(img, Cc, H, W, _dv(K, 9), _dv(dist, 5), out)
+    return out
+
+
+def foe_from_flow(flow, conf=None, min_flow=0.5, iterations=2):
+    fy, fx = _f(flow[0]), _f(flow[1])
+    H, W = fy.shape
+    c = _f(conf) if conf is not None else None
+    out, n = (C.c_double * 2)(), C.c_double()
+    rc = lib().orc_foe_from_flow(fy, fx, c.ctypes.data if c is not None else None, H, W, float(min_flow), int(iterations), out, C.byref(n))
+    return rc, (out[0], out[1]), n.value
+
+
+def ego_motion_from_points(p1, p2, K, max_dist, iterations, seed, weights=None):
+    p1, p2 = _f(p1), _f(p2)
+    N = p1.shape[0]
+    w = _f(weights) if weights is not None else None
+    R, T, F, ni = (C.c_double * 9)(), (C.c_double * 3)(), (C.c_double * 9)(), C.c_int()
+    rc = lib().orc_ego_motion_from_points(p1, p2, w.ctypes.data if w is not None else None, N, _dv(K, 9), float(max_dist), int(iterations), int(seed), R, T,
+                                          C.byref(ni), F)
+    return rc, np.array(R[:]).reshape(3, 3), np.array(T[:]), ni.value, np.array(F[:]).reshape(3, 3)

@@ -1057,9 +1057,68 @@ def _np_bilinear(img, sy, sx):
     return (1 - wy) * top + wy * bot
 
 
+def test_ego_motion_pose_device_equals_oracle_and_planted(dfe, cuda):
+    """sfm2.getEgoMotion2's role (radial/radial_opticalflow_data.lua:211-231): relative pose from correspondences by parallel RANSAC on the
+    device == the oracle's restatement (same counter-based sampling: the same hypotheses, so R, T, F agree to rounding and the inlier
+    counts to a borderline point or two), and both recover the planted motion; then the route the reference's callers take with
+    it -- epipole K T, removeEgoMotion -- and the dense-flow entry on a synthetic flow field of the same motion."""
+    from tests.test_egomotion_cpu import two_views, rot_angle
+
+    p1, p2, K, R, Tt, nout = two_views(n=900, seed=3)
+    Rg, Tg, nf, ni, Fg = dfe.sfm2.getEgoMotion2(K, pts1=T(p1, cuda), pts2=T(p2, cuda), ransacMaxDist=1.0, iterations=512, seed=11)
+    rc, Ro, To, nio, Fo = orc.ego_motion_from_points(p1, p2, K, 1.0, 512, 11)
+    assert rc == 0 and nf == len(p1)
+    Rg, Tg, Fg = Rg.numpy(), Tg.numpy(), Fg.numpy()
+    assert np.abs(Rg - Ro).max() < 1e-6 and np.abs(Tg - To).max() < 1e-6 and np.abs(Fg - Fo).max() < 1e-6 and abs(ni - nio) <= 2
+    assert rot_angle(R, Rg) < 0.15 and np.degrees(np.arccos(np.clip(Tg @ Tt, -1, 1))) < 2.0
+    assert abs(np.linalg.det(Rg) - 1) < 1e-9 and len(p1) - nout - 25 <= ni <= len(p1) - nout + 12
+    # weights: the planted outliers switched off
+    w = np.ones(len(p1), np.float32)
+    w[:nout] = 0
+    R2, T2, nf2, ni2, _ = dfe.sfm2.getEgoMotion2(K, pts1=T(p1, cuda), pts2=T(p2, cuda), weights=T(w, cuda), iterations=256, seed=5)
+    rc, Ro2, To2, nio2, _ = orc.ego_motion_from_points(p1, p2, K, 1.0, 256, 5, weights=w)
+    assert nf2 == len(p1) - nout and np.abs(R2.numpy() - Ro2).max() < 1e-6 and abs(ni2 - nio2) <= 2 and rot_angle(R, R2.numpy()) < 0.15
+    # the callers' route: e2 = K T (data.lua:218), device vs oracle
+    ex, ey = dfe.sfm2.getEpipole(K, Tg)
+    assert np.hypot(ex - orc.epipole(K, To)[1][0], ey - orc.epipole(K, To)[1][1]) < 1e-3
+    # dense-flow entry: the flow field this motion induces on a fronto-parallel-ish scene, with a block of garbage
+    H, W = 240, 320
+    Ks = K.copy()
+    Ks[0] *= W / 640
+    Ks[1] *= H / 480
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    depth = 4.0 + 2.0 * np.sin(xs / 40) * np.cos(ys / 33) + 0.01 * ys
+    rays = np.stack([(xs - Ks[0, 2]) / Ks[0, 0], (ys - Ks[1, 2]) / Ks[1, 1], np.ones_like(xs)], -1) * depth[..., None]
+    X2 = rays @ R.T + Tt * 0.35
+    q = X2 @ Ks.T
+    flow = np.stack([q[..., 1] / q[..., 2] - ys, q[..., 0] / q[..., 2] - xs]).astype(np.float32)
+    flow[:, 30:70, 40:110] = np.random.default_rng(2).uniform(-6, 6, (2, 40, 70)).astype(np.float32)
+    conf = np.ones((H, W), np.float32)
+    conf[200:, :] = 0
+    Rf, Tf, nff, nif, Ff = dfe.sfm2.getEgoMotion2(Ks, flow=T(flow, cuda), confidences=T(conf, cuda), maxPoints=1500, ransacMaxDist=0.5, iterations=512, seed=2)
+    assert 800 < nff <= 1500 and nif > 0.8 * nff * (1 - 40 * 70 / (200.0 * W)) - 40
+    assert rot_angle(R, Rf.numpy()) < 0.5 and np.degrees(np.arccos(np.clip(Tf.numpy() @ Tt, -1, 1))) < 5.0     # (half-resolution frame, smooth scene: a weaker geometry than the 3-D point cloud above)
+    # same samples through the oracle: the grid the entry documents (centred, step = ceil(sqrt(H W / maxPoints)))
+    step = int(np.ceil(np.sqrt(H * W / 1500.0)))
+    gh, gw = (H - 1) // step + 1, (W - 1) // step + 1
+    y0, x0 = ((H - 1) - (gh - 1) * step) // 2, ((W - 1) - (gw - 1) * step) // 2
+    gy, gx = np.mgrid[0:gh, 0:gw]
+    sy, sx = (y0 + gy * step).reshape(-1), (x0 + gx * step).reshape(-1)
+    s1 = np.stack([sx, sy], 1).astype(np.float32)
+    s2 = s1 + np.stack([flow[1][sy, sx], flow[0][sy, sx]], 1)
+    sw = ((conf[sy, sx] > 0) & (s2[:, 0] >= 0) & (s2[:, 0] <= W - 1) & (s2[:, 1] >= 0) & (s2[:, 1] <= H - 1)).astype(np.float32)
+    rc, Rfo, Tfo, nifo, _ = orc.ego_motion_from_points(s1, s2, Ks, 0.5, 512, 2, weights=sw)
+    assert rc == 0 and nff == int(sw.sum()) and np.abs(Rf.numpy() - Rfo).max() < 1e-6 and abs(nif - nifo) <= 2
+    # removeEgoMotion(prev, K, R, inverse): after it, the residual flow of far points points away from / towards the epipole only
+    with pytest.raises(dfe.DfeError):
+        junk = np.random.default_rng(1).uniform(0, 300, (50, 2)).astype(np.float32)
+        dfe.sfm2.getEgoMotion2(K, pts1=T(junk, cuda), pts2=T(junk[::-1].copy(), cuda), ransacMaxDist=0.02, iterations=32)
+
+
 def test_remove_ego_motion_and_undistort(dfe, cuda):
-    """sfm2.removeEgoMotion / undistortImage restated: against a numpy evaluation of the same maps, and by the property that a
-    rotation homography followed by its inverse returns the frame wherever the mask says the pixel survived."""
+    """sfm2.removeEgoMotion / undistortImage restated: against the ORACLE's restatement of the same call sites (oracle/dfe_oracle.c,
+    next-row N4), against a numpy evaluation of the same maps, and by the property that a rotation homography followed by its
+    inverse returns the frame wherever the mask says the pixel survived."""
     rng = np.random.default_rng(0)
     H, W = 90, 120
     img = rng.random((3, H, W)).astype(np.float32)
@@ -1082,6 +1141,12 @@ def test_remove_ego_motion_and_undistort(dfe, cuda):
     ref = np.where(inside, _np_bilinear(img, sy, sx), 0)
     assert np.array_equal(mask.cpu().numpy(), inside.astype(np.float32))
     assert np.abs(warped.cpu().numpy() - ref).max() < 2e-4
+    # the oracle: the same float expressions; the device fuses the multiply-adds of the sampling coordinates, the host compiler
+    # does not -- an ulp of a coordinate (1e-5 at x ~ 100) times the unit gradient of this white-noise image
+    ow, om = orc.remove_ego_motion(img, K, R)
+    assert np.array_equal(mask.cpu().numpy(), om) and np.abs(warped.cpu().numpy() - ow).max() <= 5e-5
+    oi, _ = orc.remove_ego_motion(img, K, R, inverse=True)
+    assert np.abs(dfe.sfm2.removeEgoMotion(T(img, cuda), K, R, inverse=True)[0].cpu().numpy() - oi).max() <= 5e-5
     smooth = np.stack([np.sin(xs / 9) + np.cos(ys / 7)] * 3).astype(np.float32)
     w2, _ = dfe.sfm2.removeEgoMotion(T(smooth, cuda), K, R)
     b2, m2 = dfe.sfm2.removeEgoMotion(w2, K, R, inverse=True)
@@ -1100,6 +1165,7 @@ def test_remove_ego_motion_and_undistort(dfe, cuda):
     inside = (sx >= 0) & (sx <= W - 1) & (sy >= 0) & (sy <= H - 1)
     ref = np.where(inside, _np_bilinear(smooth, sy, sx), 0)
     assert np.abs(und.cpu().numpy() - ref).max() < 2e-3
+    assert np.abs(und.cpu().numpy() - orc.undistort_image(smooth, K, cal["distortion"])).max() <= 2e-5
 
 
 def test_epipole_and_foe_from_dense_flow(dfe, cuda):
@@ -1114,6 +1180,9 @@ def test_epipole_and_foe_from_dense_flow(dfe, cuda):
     f0, f1, flow, (cx, cy) = rp.synth_pair(H, W, C=3, seed=1, max_flow=10, noise_sigma=0)
     (fx, fy), n = dfe.sfm2.getFOEFromFlow(T(flow.astype(np.float32), cuda), None, min_flow=1.0, iterations=0)
     assert abs(fx - cx) < 0.6 and abs(fy - cy) < 0.6 and n > 1000          # the planted (rounded) field itself
+    rc, (ox, oy), on = orc.foe_from_flow(flow.astype(np.float32), None, 1.0, 0)    # the oracle counterpart (double sums in another order)
+    assert rc == 0 and abs(ox - fx) < 1e-6 and abs(oy - fy) < 1e-6 and abs(on - n) < 1e-6 * n
+    assert abs(ex - orc.epipole(K, [0.1, -0.05, 1.0], 0.25)[1][0]) < 1e-12
     res = torch.empty((2, H, W), device=cuda)
     sc, dp, dc = (torch.empty((H, W), device=cuda) for _ in range(3))
     ctx = dfe.get_ctx(0)
