@@ -38,6 +38,8 @@ PROTOTYPES = {
                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "dfe_ego_motion_from_flow_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_double, C.c_int,
                                               C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "dfe_stage_timers_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_stage_timers_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dfe_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "dfe_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),

@@ -113,6 +113,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ms_graph.exec) (void)hipGraphExecDestroy(ctx->ms_graph.exec);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    for (const dfe_ctx::StageEvent &e : ctx->stage_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->dflag) (void)hipFree(ctx->dflag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -146,7 +147,10 @@ int dfe_free(dfe_ctx *ctx, void *dptr) {
 int dfe_memcpy_h2d(dfe_ctx *ctx, void *dst, const void *src, size_t bytes) {
     DFE_REQUIRE(ctx, ctx && (bytes == 0 || (dst && src)), DFE_E_ARG, "dfe_memcpy_h2d: NULL argument");
     DfeDeviceGuard guard(ctx);
-    DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    {
+        DfeStageScope st(ctx, DFE_STAGE_LOAD);
+        DFE_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return DFE_OK;
 }
@@ -214,6 +218,28 @@ int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes) {
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, bytes >= ((size_t)1 << 20), DFE_E_ARG, "scratch limit %zu below 1 MiB", bytes);
     ctx->scratch_limit = bytes;
+    return DFE_OK;
+}
+
+int dfe_stage_timers_enable(dfe_ctx *ctx, int on) {
+    DFE_ENTER(ctx);
+    ctx->stage_timers = on != 0;
+    ctx->stage_depth = 0;
+    return DFE_OK;
+}
+
+int dfe_stage_timers_read(dfe_ctx *ctx, double *ms, int *regions) {
+    DFE_REQUIRE(ctx, ctx && ms && regions, DFE_E_ARG, "dfe_stage_timers_read: NULL argument");
+    DfeDeviceGuard guard(ctx);
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < DFE_NSTAGES; ++s) { ms[s] = 0; regions[s] = 0; }
+    for (const dfe_ctx::StageEvent &e : ctx->stage_events) {
+        float t = 0.f;
+        if (e.stage >= 0 && e.stage < DFE_NSTAGES && hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) { ms[e.stage] += t; ++regions[e.stage]; }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    ctx->stage_events.clear();
     return DFE_OK;
 }
 

@@ -31,6 +31,12 @@ struct dfe_ctx {
     // measured SLOWER than the direct launches (VGA 3-level pyramid 0.0857 against 0.0803 ms per pair, 1080p 0.543 against
     // 0.537 ms: the graph launch costs more than four back-to-back kernel launches on one stream).  Profiling and the
     // legacy null stream (not capturable) also turn it off.
+    // stage timers with the reference's names (depth_estimation_opticalflow.lua:144-148: load / filter / match / extract): event
+    // pairs per stage on the ctx stream, resolved by dfe_stage_timers_read
+    bool stage_timers = false;
+    int stage_depth = 0;                     // only the outermost DfeStageScope records
+    struct StageEvent { int stage; hipEvent_t a, b; };
+    std::vector<StageEvent> stage_events;
     struct GraphSlot {
         std::vector<unsigned char> key;
         int hits = 0;
@@ -59,6 +65,26 @@ struct DfeProfScope {
             if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, ctx->stream); ctx->prof_events.push_back(e); }
         }
     }
+};
+
+// brackets the launches of one pipeline stage (DFE_STAGE_*) with events when the stage timers are on
+struct DfeStageScope {
+    dfe_ctx *ctx;
+    bool rec = false;
+    dfe_ctx::StageEvent ev{};
+    DfeStageScope(dfe_ctx *c, int stage) : ctx(c) {
+        if (ctx->stage_timers && ctx->stage_depth++ == 0) {
+            ev.stage = stage;
+            rec = hipEventCreate(&ev.a) == hipSuccess && hipEventCreate(&ev.b) == hipSuccess;
+            if (rec) (void)hipEventRecord(ev.a, ctx->stream);
+        }
+    }
+    ~DfeStageScope() {
+        if (ctx->stage_timers) --ctx->stage_depth;
+        if (rec) { (void)hipEventRecord(ev.b, ctx->stream); ctx->stage_events.push_back(ev); }
+    }
+    DfeStageScope(const DfeStageScope &) = delete;
+    DfeStageScope &operator=(const DfeStageScope &) = delete;
 };
 
 int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...);

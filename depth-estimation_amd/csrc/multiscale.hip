@@ -10,6 +10,7 @@
 #include <cstring>
 #include <type_traits>
 #include <cmath>
+#include <memory>
 
 namespace {
 
@@ -1001,10 +1002,14 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         mg.d[s] = g.d[s];
     }
     if (!filt) {
+        DfeStageScope st(ctx, DFE_STAGE_FILTER);
         hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
         DFE_LAUNCH_CHECK(ctx);
     }
     bool merged = false, soft_done = false, half_vol = false;
+    // stage "match": volumes, soft-min, cascade + fused arg-max (with learned filters it opens behind the per-scale filter / matching scopes)
+    std::unique_ptr<DfeStageScope> match_rest;
+    if (!filt) match_rest.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));
     const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
     // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
     bool px_path = fast && maxh == 8 && maxw == 8;
@@ -1026,12 +1031,16 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
             pf.pl[2 * s + 1] = pl; pf.pt[2 * s + 1] = pt; pf.Hp[2 * s + 1] = Hs + hp; pf.Wp[2 * s + 1] = Ws + wp;
             if ((long long)C * (Hs + hp) * (Ws + wp) > pmax) pmax = (long long)C * (Hs + hp) * (Ws + wp);
         }
-        hipLaunchKernelGGL(prep_frames_kernel, dim3(grid1d(pmax, 256 * 8), 2 * nratios), dim3(256), 0, ctx->stream, C, H, W, pf);
+        {
+            DfeStageScope st(ctx, DFE_STAGE_FILTER);
+            hipLaunchKernelGGL(prep_frames_kernel, dim3(grid1d(pmax, 256 * 8), 2 * nratios), dim3(256), 0, ctx->stream, C, H, W, pf);
+        }
         DFE_LAUNCH_CHECK(ctx);
         for (int s = 0; s < nratios; ++s) {
             const dfe_filter_layer *Ls = filt->layers + (filt->share ? 0 : s) * filt->nlayers;
             const float *feat[2];
             for (int f = 0; f < 2; ++f) {
+                DfeStageScope st(ctx, DFE_STAGE_FILTER);
                 const float *cur = pf.out[2 * s + f];
                 int h = pf.Hp[2 * s + f], w = pf.Wp[2 * s + f];
                 for (int l = 0; l < filt->nlayers; ++l) {
@@ -1043,10 +1052,12 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
                 feat[f] = cur;
             }
             const int K = filt->nlayers ? Ls[filt->nlayers - 1].nOut : C;
+            DfeStageScope st(ctx, DFE_STAGE_MATCH);
             rc = dfe_spatial_matching_dispatch(ctx, feat[0], feat[1], K, H / ratios[s], W / ratios[s], maxh, maxw, (float *)ss.cost[s]);
             if (rc) return rc;
         }
         merged = true;
+        match_rest.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));
     } else {
         // one launch for every scale's volume; on the fast path the coarser scales leave it as soft-min probabilities already
         // (their blocks run next to the scale-1 blocks that dominate the launch), scale 1 as costs for the cascade's SOFT0

@@ -20,6 +20,7 @@
 //                            as whole rows of W * hWin contiguous floats; first-minimum index - 1 = the radial flow
 //   p2c_flow_depth_kernel    P2C grid in place + bilinear sample of the polar flow + flow2depth
 #include "dfe_internal.h"
+#include <memory>
 #include <cmath>
 
 #ifndef DFE_RADIAL_RY
@@ -404,6 +405,7 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     if (polar_flow) pflow = polar_flow;
 
     const double rmax = lua_rmax(p->hImg, p->wImg, e2x, e2y);
+    std::unique_ptr<DfeStageScope> stage(new DfeStageScope(ctx, DFE_STAGE_FILTER));   // polar warps + filters
     {   // 1. both frames to polar (getC2PMask's constants: cartesian2polar.lua:13-14)
         const float kr = (float)(rmax / pow((double)H, (double)p->alpha_polar));
         const float ktheta = (float)(2 * M_PI / W);
@@ -430,10 +432,14 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     if (rc) return rc;
     rc = radial_filter(ctx, p, pol1, H, Wp, w1, b1, w2, b2, tmp, feat2);
     if (rc) return rc;
+    stage.reset();
+    stage.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));
     // 3. matcher + arg-min (+ the volume when asked for); the last flow row zeroed only on request (train_radial:178-180 does
     //    it for its display; test_radial:204-207, the path this call replaces, does not)
     rc = dfe_radial_match_argmin_f32(ctx, feat1, Hf2, feat2, p->n2, hm, W, p->hWin, volume, pflow, p->zero_last_row != 0);
     if (rc) return rc;
+    stage.reset();
+    stage.reset(new DfeStageScope(ctx, DFE_STAGE_EXTRACT));
     {   // 4. polar flow -> cartesian -> depth (getP2CMaskOF + flow2depth with center2 = e2 * getKOutput)
         const double kOut = (double)hm / (double)H;
         const double nrmax = rmax * kOut;

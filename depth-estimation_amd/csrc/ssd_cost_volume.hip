@@ -29,6 +29,7 @@
 //                       tile), so results do not depend on the launch geometry.
 #include "dfe_internal.h"
 #include <type_traits>
+#include <memory>
 
 // ------------------------------------------------------------------------------------------
 // reference-order kernel
@@ -1881,6 +1882,7 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
         bool fused = false;
         int nparts = nch;
+        std::unique_ptr<DfeStageScope> match_scope(new DfeStageScope(ctx, DFE_STAGE_MATCH));   // (closed in front of the finalize / tail pass below)
         if (kh == kw && f16_scale != 0.f) {
             fa.row_off = r0;
             rc = cv_frames_dispatch_f16(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, f16_scale, vol, &fa, &fused);
@@ -1893,6 +1895,8 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
             if (rc) return rc;
         }
         if (fused) {
+            match_scope.reset();
+            DfeStageScope ex(ctx, DFE_STAGE_EXTRACT);
             // one band: the finalize launch also zeroes the frame border and makes depth (pair step: 2 launches instead of 3)
             const bool frame_mode = pd && nr == Ho;
             rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nparts, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
@@ -1901,6 +1905,8 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         } else {
             rc = cv_frames_dispatch(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, kw, hWin, wWin, vol);
             if (rc) return rc;
+            match_scope.reset();
+            DfeStageScope ex(ctx, DFE_STAGE_EXTRACT);
             rc = dfe_flow_tail(ctx, vol, nr, Wo, hWin, wWin, thr, r0, idx, best, fy, fx, scores, imaxs, pitch, pad_t, pad_l, scores_padded);
         }
         if (rc) return rc;
@@ -1946,6 +1952,7 @@ int dfe_flow_depth_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int 
                            W, pad_t, pad_l, 1, &pd, &pd_done);
     if (rc || pd_done) return rc;
     // several bands, or no fused build for this shape: one pass afterwards zeroes the border and makes depth
+    DfeStageScope ex(ctx, DFE_STAGE_EXTRACT);
     return dfe_pair_border_depth(ctx, flow, scores, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
 }
 
@@ -2002,6 +2009,7 @@ int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int 
     int rc = flow_pipeline(ctx, I0, I1, C, H, W, k, k, hWin, wWin, 0.0, idx, best, flow, flow + HW, nullptr, nullptr, W, pad_t, pad_l, 1, &pd, &pd_done,
                            scale);
     if (rc || pd_done) return rc;
+    DfeStageScope ex(ctx, DFE_STAGE_EXTRACT);
     return dfe_pair_border_depth(ctx, flow, nullptr, H, W, pad_t, pad_l, Ho, Wo, foe_x, foe_y, depth, depth_conf);
 }
 

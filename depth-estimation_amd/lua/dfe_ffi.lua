@@ -29,6 +29,8 @@ const char *dfe_last_kernel(const dfe_ctx *ctx);
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
+int dfe_stage_timers_enable(dfe_ctx *ctx, int on);
+int dfe_stage_timers_read(dfe_ctx *ctx, double *ms , int *regions );
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float *out);
 int dfe_ssd_cost_volume_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float scale, void *out);
 int dfe_flow_depth_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, float scale, int64_t *idx, float *best, float *flow, float *depth, float *depth_conf);

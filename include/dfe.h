@@ -86,6 +86,21 @@ int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
 
+/* Stage timers with the reference's names -- `load / filter / match / extract` printed per frame by the dense driver
+ * (depth_estimation_opticalflow.lua:44-47,112-117,144-148): HIP events around the launches of each stage inside the
+ * one-call pipelines and the staging copies.  load = dfe_memcpy_h2d (the driver's image load + upload); filter = down-sampling,
+ * padding, polar warps and the learned filter stacks (its `filter:forward`); match = cost volumes, soft-min and cascade
+ * (`model:forward`); extract = arg-best / extractOutput / decode / border / depth passes (`processOutput`; where the arg-best
+ * is fused into the matching kernel -- the multiscale cascade, the fused cost-volume build -- that part counts as match).
+ * enable, run, read: ms[s] = summed GPU time of stage s, launches[s] = number of bracketed regions; read synchronises and resets. */
+#define DFE_STAGE_LOAD 0
+#define DFE_STAGE_FILTER 1
+#define DFE_STAGE_MATCH 2
+#define DFE_STAGE_EXTRACT 3
+#define DFE_NSTAGES 4
+int dfe_stage_timers_enable(dfe_ctx *ctx, int on);
+int dfe_stage_timers_read(dfe_ctx *ctx, double *ms /* [DFE_NSTAGES] */, int *regions /* [DFE_NSTAGES] */);
+
 /* ---- A0+A1: dense SSD cost volume from raw frames ----------------------- */
 /* replaces: unfold + SpatialPadding crop + nn.SpatialMatching(hWin,wWin,false):forward
  *   radial/radial_opticalflow_groundtruth.lua:79-84 (= version2/groundtruth.lua:77-82),

@@ -890,6 +890,58 @@ def test_benched_single_scale_sizes_properties(dfe, cuda, H, W):
     assert np.allclose(dd.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(cc.cpu().numpy(), ec)
 
 
+def test_stage_timers_with_the_reference_names(dfe, cuda):
+    """dfe_stage_timers_*: load / filter / match / extract (depth_estimation_opticalflow.lua:144-148) around the launches of the
+    one-call pipelines: every stage a pipeline has shows up with a positive time, nothing is counted twice (the stages sum to
+    less than the wall time of the calls), read resets."""
+    import time
+    from ctypes import c_double, c_int
+
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    H, W = 240, 320
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=3, seed=1, max_flow=8)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    flow = torch.empty((2, H, W), device=cuda)
+    sc, dd, cc = (torch.empty((H, W), device=cuda) for _ in range(3))
+
+    def read():
+        ms, n = (c_double * 4)(), (c_int * 4)()
+        ctx.check(lib.dfe_stage_timers_read(ctx.handle, ms, n))
+        return list(ms), list(n)
+
+    ctx.check(lib.dfe_stage_timers_enable(ctx.handle, 1))
+    try:
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(3):
+            ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 33, 33, cx, cy, 0.21, flow.data_ptr(), sc.data_ptr(),
+                                                  dd.data_ptr(), cc.data_ptr()))
+        ms, n = read()
+        wall = (time.perf_counter() - t) * 1e3
+        assert n == [0, 0, 3, 3] and ms[2] > 0 and ms[3] > 0 and ms[0] == 0 and ms[1] == 0
+        assert ms[2] > ms[3] and sum(ms) <= wall                      # the build dominates; no double counting
+        assert read() == ([0.0] * 4, [0] * 4)                         # read resets
+        # the learned multiscale matcher has a filter stage, its arg-max is fused into the cascade (match)
+        geo = dict(maxh=8, maxw=8, ratios=[1, 2, 4], multiscale=True, layers=[(3, 5, 5, 4), (4, 5, 5, 10)], share_filters=True, hImg=H, wImg=W,
+                   output_extraction_method="max")
+        model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=torch.Generator().manual_seed(1))
+        model.forwardFlow([t0 / 255, t1 / 255], False, one_call=True)
+        ms, n = read()
+        assert n[1] == 1 + 3 * 2 and n[2] == 3 + 1 and n[3] == 0 and ms[1] > 0 and ms[2] > 0      # prep + 2 frames x 3 scales; 3 matchers + the cascade
+        # a staged upload counts as load
+        host = np.zeros(1 << 16, np.float32)
+        dev = torch.empty(1 << 16, device=cuda)
+        ctx.check(lib.dfe_memcpy_h2d(ctx.handle, dev.data_ptr(), host.ctypes.data, host.nbytes))
+        ms, n = read()
+        assert n == [1, 0, 0, 0] and ms[0] > 0
+    finally:
+        ctx.check(lib.dfe_stage_timers_enable(ctx.handle, 0))
+    ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 33, 33, cx, cy, 0.21, flow.data_ptr(), sc.data_ptr(),
+                                          dd.data_ptr(), cc.data_ptr()))
+    assert read()[1] == [0] * 4                                       # off: nothing recorded
+
+
 # ------------------------------------------------------------------ one device per ctx
 def test_entry_points_run_on_their_ctx_device_and_leave_the_callers_alone(dfe, cuda):
     """Every entry point switches to its ctx's device for the call and restores the caller's current device (DFE_ENTER); two
