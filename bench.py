@@ -460,10 +460,10 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 --pmc passes (profiles/README.md)
             try:
                 tj = json.load(open(tpath))
-                import hashlib
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from kernel_hash import kernel_source_hash
 
-                src = os.path.join(ROOT, "depth-estimation_amd", "csrc", "ssd_cost_volume.hip")
-                same_src = os.path.exists(src) and tj.get("source_sha256") == hashlib.sha256(open(src, "rb").read()).hexdigest()
+                same_src = tj.get("source_sha256") == kernel_source_hash()
                 if same_src and tj.get("kernel_rev") == lib.dfe_kernel_revision().decode():   # counters of another kernel version say nothing
                     traffic = tj.get("hbm_bytes_per_launch")
                     build_traffic = tj.get("build_only", {}).get("hbm_bytes_per_launch")

@@ -155,10 +155,13 @@ def test_committed_traffic_summary_belongs_to_the_committed_kernel():
     src = open(os.path.join(root, "depth-estimation_amd", "csrc", "ssd_cost_volume.hip")).read()
     rev = re.search(r'#define DFE_CV_KERNEL_REV "([^"]+)"', src).group(1)
     traffic = json.load(open(os.path.join(root, "profiles", "traffic_vga.json")))
-    import hashlib
+    import sys
 
-    assert traffic.get("source_sha256") == hashlib.sha256(src.encode()).hexdigest(), (
-        "profiles/traffic_vga.json was measured on another version of ssd_cost_volume.hip: rerun tools/pmc_cv.sh + tools/make_traffic.py "
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from kernel_hash import kernel_source_hash
+
+    assert traffic.get("source_sha256") == kernel_source_hash(), (
+        "profiles/traffic_vga.json was measured on another version of the cost-volume kernels: rerun tools/refresh_traffic.sh on the GPU "
         "(and bump DFE_CV_KERNEL_REV if the change alters what the kernels read or write)")
     assert traffic["kernel_rev"] == rev, "profiles/traffic_vga.json is from %s, the source is %s: rerun tools/pmc_cv.sh + tools/make_traffic.py" % (traffic["kernel_rev"], rev)
     assert traffic["hbm_bytes_per_launch"] >= traffic["algorithmic_bytes_per_launch"]

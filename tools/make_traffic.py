@@ -25,7 +25,9 @@ H, W, C, k, hW, wW = WORKLOADS[wl]
 f, b = counters(fused, "rowimg"), counters(build, "rowimg")
 # gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact; both in KB
 hbm = lambda c: int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024))
-src_hash = hashlib.sha256(open(os.path.join(root, "depth-estimation_amd", "csrc", "ssd_cost_volume.hip"), "rb").read()).hexdigest()
+sys.path.insert(0, os.path.join(root, "tools"))
+from kernel_hash import kernel_source_hash
+src_hash = kernel_source_hash()
 out = {
     "workload": wl, "kernel_rev": rev,
     # the counters belong to exactly this source of the cost-volume kernels: tests/test_abi_cpu.py and bench.py compare the hash, so
