@@ -153,6 +153,89 @@ def gather_results(tensors, world, rank, dist, sync):
     return [[out[i][r] for i in range(len(tensors))] for r in range(world)], secs, nbytes
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# ONE frame pair over N GPUs (SURVEY 8(e) "single huge frame", BASELINE configs[4]: a 4K pair on 8 GPUs): row bands of the
+# output with a read halo.  Rank 0 holds the uint8 frames and broadcasts them (RCCL over xGMI: 2 x 24.9 MB at 4K); every rank
+# computes the bands it owns on the rows it needs; the owned rows are gathered to rank 0.  Strong scaling: the work of a step is
+# fixed, the ranks split it.
+# ------------------------------------------------------------------------------------------------------------------
+def band_plan(H, n_bands, align, halo):
+    """Row bands of a frame of H rows: band b OWNS frame rows [o0, o1) (o0 a multiple of `align`; equal shares up to `align`) and
+    READS rows [r0, r1) = the owned rows widened by `halo` and clipped to the frame.  -> list of (o0, o1, r0, r1); bands may be fewer
+    than n_bands when the frame is short."""
+    units = -(-H // align)
+    n = max(1, min(n_bands, units))
+    out = []
+    for b in range(n):
+        o0, o1 = (b * units // n) * align, min(H, ((b + 1) * units // n) * align)
+        out.append((o0, o1, max(0, o0 - halo), min(H, o1 + halo)))
+    return out
+
+
+def band_owner(b, world):
+    return b % world
+
+
+def run_banded_step(frames_u8, plan, world, rank, dist, compute_band, device, sync, timing=None):
+    """One step of the band-split pipeline.  frames_u8: on rank 0 the pair as ONE uint8 tensor [2][C][H][W], a same-shaped buffer on
+    the other ranks.  compute_band(sub_u8 [2][C][rows][W], o0 - r0, o1 - r0, r0) -> list of tensors whose FIRST dimension after
+    any leading plane dimension is the owned rows (each [.., o1-o0, W]).  Returns on rank 0 the stitched full-frame tensors
+    (list), None elsewhere.  Collectives: one broadcast of the frames, one gather per output tensor and band round."""
+    import torch
+
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.broadcast(frames_u8, src=0)
+    t1 = time.perf_counter()
+    mine = {}
+    for b, (o0, o1, r0, r1) in enumerate(plan):
+        if band_owner(b, world) != rank:
+            continue
+        mine[b] = compute_band(frames_u8[:, :, r0:r1], o0 - r0, o1 - r0, r0)
+    sync()
+    t2 = time.perf_counter()
+    full = None
+    H = plan[-1][1]
+    nrounds = -(-len(plan) // world)
+    hmax = max(o1 - o0 for o0, o1, _, _ in plan)
+    for rnd in range(nrounds):
+        b = rnd * world + rank
+        outs = mine.get(b)
+        if world == 1:
+            parts = [(b, outs)] if outs is not None else []
+        else:
+            # every rank sends tensors of ONE shape (its band padded to the tallest band): gather needs equal sizes
+            like = next(iter(mine.values())) if mine else None
+            shapes = compute_band.out_shapes(hmax) if like is None else [tuple(t.shape[:-2]) + (hmax, t.shape[-1]) for t in like]
+            dtypes = compute_band.out_dtypes if like is None else [t.dtype for t in like]
+            parts = []
+            got = []
+            for i, (shp, dt) in enumerate(zip(shapes, dtypes)):
+                send = torch.zeros(shp, dtype=dt, device=device)
+                if outs is not None:
+                    send[..., : outs[i].shape[-2], :] = outs[i]
+                wire = send.view(torch.uint8) if dt == torch.int16 else send
+                dst = [torch.empty_like(wire) for _ in range(world)] if rank == 0 else None
+                dist.gather(wire, dst, dst=0)
+                got.append([t.view(dt) for t in dst] if rank == 0 else None)
+            if rank == 0:
+                for r in range(world):
+                    bb = rnd * world + r
+                    if bb < len(plan):
+                        parts.append((bb, [got[i][r] for i in range(len(shapes))]))
+        if rank == 0:
+            for bb, ts in parts:
+                o0, o1 = plan[bb][0], plan[bb][1]
+                if full is None:
+                    full = [torch.empty(tuple(t.shape[:-2]) + (H, t.shape[-1]), dtype=t.dtype, device=t.device) for t in ts]
+                for f, t in zip(full, ts):
+                    f[..., o0:o1, :] = t[..., : o1 - o0, :]
+    sync()
+    if timing is not None:
+        timing.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
+    return full
+
+
 def launch_ranks(gpus, argv):
     """`python bench.py --gpus N` from a bare shell: start N fresh rank processes under torch.distributed.run (one per GPU,
     RCCL) and relay their output and exit code.  Called before this process touches torch.cuda or libdfe -- the ranks are
@@ -284,6 +367,95 @@ def main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp):
         dist.destroy_process_group()
 
 
+BAND_WORKLOADS = {
+    # one pair split into row bands over the ranks (BASELINE configs[4] on N GPUs; SURVEY 8(e) "single huge frame")
+    # name: (kind, H, W, C, k, window, ratios)
+    "4k-f16-bands": ("single", 2160, 3840, 3, 7, 33, None),
+    "4k-pyramid-f16-bands": ("pyramid", 2160, 3840, 3, 7, 8, (1, 2, 4, 8, 16)),
+    "1080p-f16-bands": ("single", 1080, 1920, 3, 7, 33, None),
+}
+
+
+def make_band_compute(kind, d, ctx, dev, Cc, W, k, win, ratios, cx, cy):
+    """compute_band for run_banded_step: the fp16-volume pipelines on a row band of the pair (uint8 rows in, owned rows out)."""
+    import torch
+
+    lib = d.lib()
+    if kind == "single":
+        def compute(sub_u8, a, b, r0):
+            f = sub_u8.to(torch.float32)                                   # [2][C][rows][W], contiguous
+            rows = f.shape[2]
+            flow = torch.empty((2, rows, W), device=dev)
+            depth, conf = torch.empty((rows, W), device=dev), torch.empty((rows, W), device=dev)
+            ctx.check(lib.dfe_flow_depth_pair_f16(ctx.handle, f[0].data_ptr(), f[1].data_ptr(), Cc, rows, W, k, win, win, cx, cy - r0, 2.0 ** -8, None, None,
+                                                  flow.data_ptr(), depth.data_ptr(), conf.data_ptr()))
+            return [flow[:, a:b].to(torch.int16), depth[a:b].contiguous()]
+        compute.out_shapes = lambda h: [(2, h, W), (h, W)]
+        compute.out_dtypes = [torch.int16, torch.float32]
+        compute.halo, compute.align = (win - 1) // 2 + (k - 1) // 2, 1     # the centre-paste offset: rows nearer than this to the band edge are border
+    else:
+        rr = (C.c_int32 * len(ratios))(*ratios)
+
+        def compute(sub_u8, a, b, r0):
+            f = sub_u8.to(torch.float32) * (1.0 / 64.0)
+            rows = f.shape[2]
+            flow = torch.empty((2, rows, W), device=dev)
+            ctx.check(lib.dfe_multiscale_flow_pair_f16(ctx.handle, f[0].data_ptr(), f[1].data_ptr(), Cc, rows, W, k, win, win, rr, len(ratios), 1.0,
+                                                       flow.data_ptr(), None))
+            return [flow[:, a:b].to(torch.int16)]
+        compute.out_shapes = lambda h: [(2, h, W)]
+        compute.out_dtypes = [torch.int16]
+        # scale r reads down-sampled rows ys - floor(hp/2) .. ys + ceil(hp/2) with hp = (win-1)+(k-1): at the coarsest ratio that is
+        # ceil(hp/2) = 7 coarse rows below the last owned one for the 8 x 8 / 7 x 7 geometry (6 above the first); bands and halo are
+        # multiples of rmax so that every scale's parent pixels stay aligned
+        hp = win - 1 + k - 1
+        compute.halo, compute.align = ratios[-1] * (hp - hp // 2), ratios[-1]
+    return compute
+
+
+def main_bands(args, world, rank, local_rank, dev, torch, dist, d, rp):
+    """One pair, row bands over the ranks: step = broadcast of the uint8 frames from rank 0 + every rank's band(s) + gather of the
+    owned rows to rank 0.  `--bands B` forces at least B bands (band b on rank b mod world), which is how the stitching is
+    exercised on one GPU."""
+    import numpy as np
+
+    kind, H, W, Cc, k, win, ratios = BAND_WORKLOADS[args.workload]
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=0, max_flow=12)
+    frames = torch.from_numpy(np.stack([f0, f1]).astype(np.uint8)).to(dev) if rank == 0 else torch.empty((2, Cc, H, W), dtype=torch.uint8, device=dev)
+    ctx = d.get_ctx(local_rank)
+    compute = make_band_compute(kind, d, ctx, dev, Cc, W, k, win, ratios, cx, cy)
+    plan = band_plan(H, max(world, args.bands), compute.align, compute.halo)
+    timing = []
+    out = [None]
+
+    def step():
+        out[0] = run_banded_step(frames, plan, world, rank, dist, compute, dev, torch.cuda.synchronize, timing)
+
+    elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize, spin_s=0.0)
+    if rank == 0:
+        tm = np.array(timing[-args.steps:])
+        step_s = elapsed / args.steps
+        vol = (H - k - win + 2) * (W - k - win + 2) * win * win * 2 if kind == "single" else sum((H // r) * (W // r) * win * win * 2 for r in ratios)
+        balg = 2 * Cc * H * W * 4 + vol
+        print(json.dumps({
+            "metric": "Mpixels/s dense flow%s, ONE %dx%d pair split into row bands over the GPUs" % ("+depth" if kind == "single" else "", W, H),
+            "value": round(args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 sums, f16 volume%s" % ("" if kind == "single" else "s"), "data": "synthetic",
+            "config": {"workload": "%dx%d C=%d %s, fp16 volume(s); uint8 frames broadcast from rank 0, %d row bands (halo %d rows), owned rows gathered to rank 0"
+                                   % (W, H, Cc, "single-scale 33x33" if kind == "single" else "pyramid %s 8x8" % list(ratios), len(plan), compute.halo),
+                       "pairs_per_step": 1, "sharding": "row-bands", "bands": len(plan)},
+            "roofline": {"bound": "hbm", "kernel": "whole step (broadcast, band pipelines, gather)", "achieved": round(balg / step_s / 1e9, 2),
+                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(balg / step_s / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": balg},
+            "step_breakdown_ms": {"broadcast": round(float(tm[:, 0].mean()) * 1e3, 4), "compute": round(float(tm[:, 1].mean()) * 1e3, 4),
+                                  "gather_and_stitch": round(float(tm[:, 2].mean()) * 1e3, 4)},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp):
     """Radial workload: step = dfe_radial_flow_depth_pair_f32 on one pair per GPU.  `roofline` is the matcher + arg-min kernel
     (A1r) against its algorithmic bytes (both feature maps read once + the hWin-cell volume written once), timed
@@ -345,7 +517,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS) + sorted(F16_WORKLOADS))
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS) + sorted(F16_WORKLOADS) + sorted(BAND_WORKLOADS))
+    ap.add_argument("--bands", type=int, default=1, help="*-bands workloads: at least this many row bands (default: one per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed) gather of the results to rank 0")
     args = ap.parse_args()
@@ -377,6 +550,8 @@ def main():
         return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
     if args.workload in RADIALS:
         return main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp)
+    if args.workload in BAND_WORKLOADS:
+        return main_bands(args, world, rank, local_rank, dev, torch, dist, d, rp)
     f16 = args.workload in F16_WORKLOADS
     H, W, Cc, k, hWin, wWin = (F16_WORKLOADS if f16 else WORKLOADS)[args.workload]
     (pair_id,) = shard_pairs(world, world, rank)                              # a batch of `world` pairs, pair p on rank p

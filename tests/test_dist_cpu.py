@@ -104,3 +104,83 @@ def test_bare_gpus_invocation_becomes_launcher(monkeypatch):
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and os.path.samefile(cmd[-7], os.path.join(ROOT, "bench.py"))
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert "torch.cuda" not in " ".join(cmd)
+
+
+def _band_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+
+    import bench
+
+    H, W, Cc = 52, 24, 3
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, (2, Cc, H, W)).astype(np.uint8)) if rank == 0 else torch.zeros((2, Cc, H, W), dtype=torch.uint8)
+    halo = 3
+
+    def compute(sub, a, b, r0):
+        # a stand-in with the band pipeline's locality: every output row depends on the input rows within `halo` of it (a vertical box
+        # sum, zero outside the FRAME) -- rows nearer than halo to an artificial band edge would be wrong, which is what the halo is for
+        x = sub.to(torch.float32).sum(1)                           # [2][rows][W]
+        rows = x.shape[1]
+        pad = torch.zeros((2, rows + 2 * halo, W))
+        pad[:, halo : halo + rows] = x
+        box = sum(pad[:, i : i + rows] for i in range(2 * halo + 1))
+        return [box[:, a:b].to(torch.int16), (box[0, a:b] - box[1, a:b] + r0 * 0).contiguous()]
+
+    compute.out_shapes = lambda h: [(2, h, W), (h, W)]
+    compute.out_dtypes = [torch.int16, torch.float32]
+    res = {}
+    for nb in (2, 3, 5):                                            # one band per rank; more bands than ranks (two rounds); an odd count
+        plan = bench.band_plan(H, nb, 4, halo)
+        t = []
+        full = bench.run_banded_step(frames, plan, world, rank, dist, compute, torch.device("cpu"), lambda: None, t)
+        res[nb] = (plan, None if full is None else [f.clone() for f in full], t)
+    whole = compute(frames, 0, H, 0) if rank == 0 else None
+    q.put((rank, {nb: (p, None if f is None else [x.numpy() for x in f]) for nb, (p, f, _) in res.items()}, None if whole is None else [x.numpy() for x in whole],
+           frames.numpy().sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_band_split_protocol_gloo_world2():
+    """ONE frame pair over the ranks (SURVEY 8(e) "single huge frame"): the uint8 frames are broadcast from rank 0, every rank computes
+    the row bands it owns on the rows it needs (owned rows + halo), the owned rows are gathered and stitched on rank 0 -- and the
+    result equals the whole frame computed in one piece, for one band per rank, for more bands than ranks and for ragged bands."""
+    import numpy as np
+
+    import bench
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = bench.free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, res0, whole, sum0), (r1, res1, whole1, sum1) = got
+    assert (r0, r1) == (0, 1) and whole1 is None and sum0 == sum1       # the broadcast delivered rank 0's frames
+    for nb, (plan, full) in res0.items():
+        assert len(plan) == nb and plan[0][0] == 0 and plan[-1][1] == 52
+        for (o0, o1, a, b), nxt in zip(plan, plan[1:] + [None]):
+            assert o0 % 4 == 0 and a == max(0, o0 - 3) and b == min(52, o1 + 3) and (nxt is None or nxt[0] == o1)
+        assert full is not None and res1[nb][1] is None                 # only rank 0 holds the stitched frame
+        for f, w in zip(full, whole):
+            assert f.shape == w.shape and f.dtype == w.dtype and np.array_equal(f, w)
+
+
+def test_band_plan_properties():
+    import bench
+
+    for H, n, align, halo in [(2160, 8, 1, 19), (2160, 8, 16, 128), (1080, 3, 8, 64), (40, 8, 16, 16), (17, 4, 1, 2)]:
+        plan = bench.band_plan(H, n, align, halo)
+        assert 1 <= len(plan) <= n and plan[0][0] == 0 and plan[-1][1] == H
+        for (o0, o1, r0, r1), nxt in zip(plan, plan[1:] + [None]):
+            assert o0 < o1 and o0 % align == 0 and r0 == max(0, o0 - halo) and r1 == min(H, o1 + halo)
+            assert nxt is None or nxt[0] == o1
+        sizes = [o1 - o0 for o0, o1, _, _ in plan]
+        assert max(sizes) - min(sizes) <= 2 * align

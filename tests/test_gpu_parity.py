@@ -890,6 +890,40 @@ def test_benched_single_scale_sizes_properties(dfe, cuda, H, W):
     assert np.allclose(dd.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(cc.cpu().numpy(), ec)
 
 
+@pytest.mark.parametrize("name,H,W,bands", [("single", 200, 256, 3), ("pyramid", 288, 512, 3), ("single", 2160, 3840, 8), ("pyramid", 2160, 3840, 8)])
+def test_row_band_split_equals_whole_frame(dfe, cuda, name, H, W, bands):
+    """BASELINE configs[4] over N GPUs = ONE pair split into row bands (bench.py's *-bands workloads; the N-rank protocol runs on gloo in
+    tests/test_dist_cpu.py).  Here the band arithmetic on the real pipelines, on one GPU: the bands a rank would compute -- owned rows
+    + halo, its own scratch, the epipole shifted by the band's first row -- stitched together equal the whole frame computed in one
+    call, bit for bit: dfe_flow_depth_pair_f16 (flow + depth) and the 5-level fp16 pyramid, at a small size and at 3840x2160 / 8 bands."""
+    import bench
+
+    ratios = (1, 2, 4, 8, 16)
+    Cc, k = 3, 7
+    win = 33 if name == "single" else 8
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=Cc, seed=7, max_flow=10)
+    frames = torch.from_numpy(np.stack([f0, f1]).astype(np.uint8)).to(cuda)
+    ctx = dfe.get_ctx(0)
+    compute = bench.make_band_compute(name, dfe, ctx, cuda, Cc, W, k, win, ratios, cx, cy)
+    whole = compute(frames, 0, H, 0)
+    plan = bench.band_plan(H, bands, compute.align, compute.halo)
+    assert len(plan) == bands
+    full = bench.run_banded_step(frames, plan, 1, 0, None, compute, cuda, torch.cuda.synchronize)
+    for a, b in zip(full, whole):
+        assert a.shape == b.shape and torch.equal(a, b)
+    if name == "single":      # and the band pipeline is the product pipeline: same flow as the fp32 one-call on the float frames
+        flow = torch.empty((2, H, W), device=cuda)
+        sc, dd, cc = (torch.empty((H, W), device=cuda) for _ in range(3))
+        t0, t1 = T(f0, cuda), T(f1, cuda)
+        ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, win, win, cx, cy, 0.21, flow.data_ptr(), sc.data_ptr(),
+                                                    dd.data_ptr(), cc.data_ptr()))
+        assert torch.equal(full[0], flow.to(torch.int16)) and torch.equal(full[1], dd)
+    # a halo one row short is NOT enough (the test would not notice a halo that is merely generous)
+    short = bench.band_plan(H, bands, compute.align, compute.halo - compute.align)
+    bad = bench.run_banded_step(frames, short, 1, 0, None, compute, cuda, torch.cuda.synchronize)
+    assert not all(torch.equal(a, b) for a, b in zip(bad, whole))
+
+
 def test_stage_timers_with_the_reference_names(dfe, cuda):
     """dfe_stage_timers_*: load / filter / match / extract (depth_estimation_opticalflow.lua:144-148) around the launches of the
     one-call pipelines: every stage a pipeline has shows up with a positive time, nothing is counted twice (the stages sum to
