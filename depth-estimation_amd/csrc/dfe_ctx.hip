@@ -25,6 +25,9 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
         hipError_t e = hipMalloc(&ctx->scratch, bytes);
         if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         ctx->scratch_bytes = bytes;
+        // DFE_DEBUG_ARENA=1: where the arena landed (the 1080p step time is bimodal per PROCESS; DESIGN section 5 ties it to this)
+        if (getenv("DFE_DEBUG_ARENA")) fprintf(stderr, "[dfe] scratch arena %p .. %p (%zu bytes, %s2 MiB-aligned)\n", ctx->scratch, (char *)ctx->scratch + bytes,
+                                               bytes, ((uintptr_t)ctx->scratch & ((1u << 21) - 1)) ? "not " : "");
     }
     *out = ctx->scratch;
     return DFE_OK;

@@ -100,6 +100,9 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least 
 // one layer of a filter stack (filters.hip): in [nIn][H][W] -> out [nOut][H-kH+1][W-kW+1], nn.Tanh fused behind it when
 // L.tanh_after (the same tanhf as dfe_tanh_f32: bit-identical to the two separate calls)
 int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out);
+// the same layer position of n independent inputs (both frames of every pyramid scale) in ONE launch where a batched kernel exists
+int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
+                                   float *const *out);
 // nn.SpatialMatching on feature maps, fast kernels or the reference-order one (ssd_cost_volume.hip)
 int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 
@@ -172,19 +175,33 @@ struct CvFuseArgs {
     long long Ptot;
     int cmid, lmid;        // chunk / lane of the centre cell
     int row_off;           // output-row offset of this launch inside the pair
+    float *rec;            // the role-split row-image kernels leave their per-pixel results here instead of in the planes above:
+                           // [column group = tile column][output row of the pair][DFE_REC floats] -- one 128-B line per TILE ROW:
+                           // 8 x (minimum, first index as int bits) | 8 x centre cost | 8 x 0 -- written whole by ONE store of one wave,
+                           // a block sweeping down its column writes consecutive lines.  (The planes took four partial-line stores per
+                           // PIXEL and row step -- 8 B + 8 B + 64 B + 4 B, lines shared with neighbouring blocks on other XCDs -- and made
+                           // the fused 1080p kernel take 1.78 .. 2.21 ms depending on the process; a 128-B record per pixel, 251 MB at
+                           // 1080p, cost 0.8 ms: DESIGN section 5.)  The pixel's first DFE_LEAD cells are read back from the volume.
+    int rec_rows;          // output rows of the pair (the record's row pitch)
 };
+#define DFE_REC 32         // floats per tile-row record
+#define DFE_REC_CENTRE 16  // (entries 0..15: (minimum, index) of the 8 pixels; 16..23: their centre costs)
 // frame mode of dfe_flow_finalize (one band only): finalize also zeroes the frame border and makes depth / confidence
 struct DfePairDepth { int H, W; float cx, cy; float *depth, *conf; };
+// (rec != nullptr: part / centre / lead are ignored -- minimum / index / centre come from the tile-row records [col group][rec_rows][DFE_REC],
+//  the lead cells from the volume itself)
 int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
                       float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
-                      const struct DfePairDepth *pd = nullptr);
+                      const struct DfePairDepth *pd = nullptr, const float *rec = nullptr, int rec_rows = 0);
 int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
                           float cy, float *depth, float *conf);
 int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,
                            bool *handled);
+int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
+                                  int maxw, float *const *out, float f16_scale, bool *handled);
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
-                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts);
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts, bool *recs = nullptr);
 
 // multiscale class-id geometry and decode, shared by postops.hip (x2yxMulti) and multiscale.hip (fused cascade -> flow)
 struct MultiGeom {

@@ -7,6 +7,7 @@
 // TX x TY pixels and deals its TY * ceil(D/64) (row, chunk) tasks to 8 waves, which keep the 8 accumulators of each of their
 // tasks in registers across the slabs.  Stores are the tiled kernel's 256-B pieces (same store-pattern bound).
 #include "dfe_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -165,7 +166,154 @@ __global__ __launch_bounds__(1024) void feat_matching_rows_kernel(const float *_
     }
 }
 
+// ---- windows of exactly one chunk (maxh * maxw == 64: the pyramid's 8 x 8), K <= 16 planes, several independent pairs per launch ----
+// The matcher behind the learned filters of getModelMultiscale (every scale's nn.SpatialMatching(maxh, maxw) on K-plane features).
+// feat_matching_kernel above spends its time waiting: one s_load_dwordx8 per plane in front of the arithmetic that needs it (an
+// SMEM round trip per plane, K of them in a row), 256-B dword stores.  Here: lane <-> cell, a thread owns 8 adjacent columns, a block
+// of 8 waves a tile of 8 columns x 16 rows (two rows per wave, 16 accumulators); ALL K planes of the in2 tile sit in LDS (pitch ==
+// maxw mod 32: the 64 cells of a wave hit 64 different banks in two passes); the in1 scalars of planes k+2, k+3 are requested
+// behind the LDS reads of planes k, k+1 and in front of their arithmetic, so the SMEM round trip is covered by 48 VALU
+// instructions and never in flight while LDS data is waited for (SMEM returns out of order: any LDS wait would have to drain
+// it); a task row (8 pixels x 256 B) leaves through a 2-KB transpose of the wave as two 1-KB stores -- or, for fp16 volumes, is
+// converted (cost * scale, round to nearest even) and leaves as one.  Same k-ordered, separately rounded sums: bit-identical
+// to the other matchers and to the CPU loop.
+struct FmBatch {
+    const float *in1[DFE_MAX_RATIOS], *in2[DFE_MAX_RATIOS];
+    float *out[DFE_MAX_RATIOS];
+    int H1[DFE_MAX_RATIOS], W1[DFE_MAX_RATIOS];
+};
+constexpr int F64_TY = 16;
+__global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, int K, int maxh, int maxw, int pitch, float f16_scale, int nt) {
+#pragma clang fp contract(off)
+    const int z = gridDim.z - 1 - blockIdx.z;              // (the smallest pair first: its few blocks must not form the tail)
+    const int H1 = fb.H1[z], W1 = fb.W1[z];
+    if ((int)blockIdx.x * FM_TX >= W1 || (int)blockIdx.y * F64_TY >= H1) return;   // block-uniform
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = min((int)blockIdx.x * FM_TX, W1 - FM_TX), y0 = min((int)blockIdx.y * F64_TY, H1 - F64_TY);   // edge tiles shifted inwards
+    const int W2 = W1 + maxw - 1, H2 = H1 + maxh - 1;
+    const int trows = F64_TY + maxh - 1, tcols = FM_TX + maxw - 1;
+    const long long plane1 = (long long)H1 * W1, plane2 = (long long)H2 * W2;
+    const float *__restrict__ in2 = fb.in2[z];
+    for (int r = wave; r < K * trows; r += 8) {            // tile rows dealt to the waves, lanes along a row
+        const int k = r / trows, rr = r - k * trows;
+        if (lane < tcols) fm_smem[r * pitch + lane] = in2[k * plane2 + (long long)(y0 + rr) * W2 + x0 + lane];
+    }
+    __syncthreads();
+    const int dy = lane / maxw, dx = lane - dy * maxw;
+    const int pl = trows * pitch;                          // floats per plane of the tile
+    float acc[2][FM_TX];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int x = 0; x < FM_TX; ++x) acc[t][x] = 0.f;
+    const float *a_base = fb.in1[z] + (long long)y0 * W1 + x0;
+    auto lda = [&](int k, int row) -> fm_f8 {
+        return *(const __attribute__((address_space(4))) fm_f8u *)(fm_cfptr)(a_base + (long long)k * plane1 + (long long)row * W1);   // s_load_dwordx8
+    };
+    fm_f8 a[2][2];                                         // [task][plane parity]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { a[t][0] = lda(0, wave + 8 * t); a[t][1] = lda(K > 1 ? 1 : 0, wave + 8 * t); }
+    for (int k = 0; k < K; k += 2) {
+        const bool two = k + 1 < K;                        // (wave-uniform)
+        float b[2][2][FM_TX];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *bp = fm_smem + (wave + 8 * t + dy) * pitch + dx + k * pl;
+#pragma unroll
+            for (int x = 0; x < FM_TX; ++x) { b[t][0][x] = bp[x]; b[t][1][x] = two ? bp[pl + x] : 0.f; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's LDS data (and the scalars requested a step ago) are in
+        __builtin_amdgcn_sched_barrier(0);
+        fm_f8 an[2][2];
+        const int k2 = min(k + 2, K - 1), k3 = min(k + 3, K - 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { an[t][0] = lda(k2, wave + 8 * t); an[t][1] = lda(k3, wave + 8 * t); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int x = 0; x < FM_TX; ++x) {
+                const float df = a[t][0][x] - b[t][0][x];
+                acc[t][x] = acc[t][x] + df * df;
+            }
+            if (two) {
+#pragma unroll
+                for (int x = 0; x < FM_TX; ++x) {
+                    const float df = a[t][1][x] - b[t][1][x];
+                    acc[t][x] = acc[t][x] + df * df;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { a[t][0] = an[t][0]; a[t][1] = an[t][1]; }
+    }
+    // copy-out through the wave's own 2-KB scratch (the tile is no longer read by THIS wave; other waves' rows are elsewhere)
+    __syncthreads();                                       // every wave is done with the tile: its space is the scratch now
+    float *xp = fm_smem + wave * (FM_TX * 64);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int y = y0 + wave + 8 * t;
+#pragma unroll
+        for (int x = 0; x < FM_TX; ++x) xp[x * 64 + lane] = acc[t][x];
+        const long long pix = (long long)y * W1 + x0;
+        if (f16_scale != 0.f) {
+            const f4v lo = *reinterpret_cast<const f4v *>(xp + 8 * lane), hi = *reinterpret_cast<const f4v *>(xp + 8 * lane + 4);
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            union { h2_t h[4]; f4v v; } u;
+            u.h[0] = h2_t{(_Float16)(lo[0] * f16_scale), (_Float16)(lo[1] * f16_scale)};
+            u.h[1] = h2_t{(_Float16)(lo[2] * f16_scale), (_Float16)(lo[3] * f16_scale)};
+            u.h[2] = h2_t{(_Float16)(hi[0] * f16_scale), (_Float16)(hi[1] * f16_scale)};
+            u.h[3] = h2_t{(_Float16)(hi[2] * f16_scale), (_Float16)(hi[3] * f16_scale)};
+            const char *orow = (const char *)fb.out[z] + pix * 128;
+            if (nt) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"((unsigned)lane * 16u), "v"(u.v), "s"(orow) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"((unsigned)lane * 16u), "v"(u.v), "s"(orow) : "memory");
+        } else {
+            const f4v lo = *reinterpret_cast<const f4v *>(xp + 4 * lane), hi = *reinterpret_cast<const f4v *>(xp + 256 + 4 * lane);
+            const char *orow = (const char *)(fb.out[z] + pix * 64);
+            if (nt) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\tglobal_store_dwordx4 %0, %3, %2 offset:1024 nt" ::"v"((unsigned)lane * 16u), "v"(lo), "s"(orow), "v"(hi) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:1024" ::"v"((unsigned)lane * 16u), "v"(lo), "s"(orow), "v"(hi) : "memory");
+        }
+    }
+}
+
 }  // namespace
+
+// n pairs (pyramid scales) of K-plane features through one launch of the one-chunk matcher; out[i] [H1][W1][64] f32, or half volumes
+// (half(cost * f16_scale)) when f16_scale != 0.  *handled = false: not this kernel's shape (the caller launches pair by pair).
+int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
+                                  int maxw, float *const *out, float f16_scale, bool *handled) {
+    *handled = false;
+    if (maxh * maxw != 64 || K < 1 || K > 16 || n < 1 || n > DFE_MAX_RATIOS || ctx->cv_mode == 1 || getenv("DFE_NO_FM64")) return DFE_OK;
+    FmBatch fb;
+    int gx = 0, gy = 0;
+    size_t vol = 0;
+    for (int i = 0; i < n; ++i) {
+        if (H1[i] < F64_TY || W1[i] < FM_TX || ((uintptr_t)in1[i] & 3) || ((uintptr_t)out[i] & 15)) return DFE_OK;
+        fb.in1[i] = in1[i]; fb.in2[i] = in2[i]; fb.out[i] = out[i]; fb.H1[i] = H1[i]; fb.W1[i] = W1[i];
+        gx = gx > dfe_cdiv(W1[i], FM_TX) ? gx : dfe_cdiv(W1[i], FM_TX);
+        gy = gy > dfe_cdiv(H1[i], F64_TY) ? gy : dfe_cdiv(H1[i], F64_TY);
+        vol += (size_t)H1[i] * W1[i] * 64 * (f16_scale != 0.f ? 2 : 4);
+    }
+    const int tcols = FM_TX + maxw - 1, trows = F64_TY + maxh - 1;
+    int pitch = tcols;
+    while ((pitch - maxw) % 32 != 0) ++pitch;              // pitch == maxw (mod 32): conflict-free for the lane <-> (dy, dx) reads
+    size_t lds = (size_t)K * trows * pitch * sizeof(float);
+    if (lds < (size_t)8 * FM_TX * 64 * sizeof(float)) lds = (size_t)8 * FM_TX * 64 * sizeof(float);   // the copy-out scratch reuses the tile
+    if (lds > 64 * 1024) return DFE_OK;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)feat_matching_win64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nt = vol > ((size_t)160 << 20);              // (volumes that do not stay in the memory-side cache: non-temporal stores)
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(feat_matching_win64_kernel, dim3(gx, gy, n), dim3(512), lds, ctx->stream, fb, K, maxh, maxw, pitch, f16_scale, nt);
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = f16_scale != 0.f ? "feat_matching_win64_kernel_f16" : "feat_matching_win64_kernel";
+    *handled = true;
+    return DFE_OK;
+}
 
 // *handled stays false when the shape has no fast instantiation (the caller falls back to the reference-order kernel)
 int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,
@@ -173,10 +321,15 @@ int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int
     *handled = false;
     const int D = maxh * maxw, nchunks = (D + 63) / 64;
     if (ctx->cv_mode == 1) return DFE_OK;
+    if (maxh * maxw == 64 && K <= 16 && ctx->cv_mode != 2) {   // one-chunk windows (the pyramid's 8 x 8): the prefetching, transposing matcher
+        int rc = dfe_feat_matching_win64_batch(ctx, 1, &in1, &in2, K, &H1, &W1, maxh, maxw, &out, 0.f, handled);
+        if (rc != DFE_OK || *handled) return rc;
+    }
     // The row kernel pays a barrier and a tile refill per plane and only fills its 256-column blocks on wide frames: measured
     // K = 32, 625 x 465, 16 x 16: 0.46 ms against 0.54 ms for the chunk kernel below; K = 10, 293 x 153: 0.064 against 0.039 ms.
     // (W1 == 1: the patch-mode call of the trainers, any K -- the chunk kernel needs 8 x 8 pixels.)
-    const bool rows_pays = (K >= 24 && W1 >= 400) || W1 < FM_TX || H1 < FM_TY;
+    bool rows_pays = (K >= 24 && W1 >= 400) || W1 < FM_TX || H1 < FM_TY;
+    if (const char *e = getenv("DFE_FM_ROWS")) rows_pays = atoi(e) != 0;   // tuning
     if (rows_pays && (maxw == 16 || maxw == 8) && maxh >= 2 && maxh <= 16 && ctx->cv_mode != 2 && ((uintptr_t)out & 15) == 0) {
         FmArgs a{};
         a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.maxw = maxw; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;

@@ -4,6 +4,7 @@
 // connection, then ky, kx) so results are bit-identical to it.  Untuned: this is the one place on the path where an
 // implicit-GEMM MFMA kernel applies; the layers are a few percent of a matcher pass at the reference's sizes.
 #include "dfe_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -86,6 +87,136 @@ int grid_n(long long n) {
 }
 
 }  // namespace
+
+// ---- the same layer for a BATCH of independent inputs in one launch (both frames of every pyramid scale), LDS-tiled ----------------
+// A block = 32 x 8 threads owns 128 x 8 output pixels of one entry; a thread owns a strip of 4 adjacent pixels and a group of NT
+// output planes (blockIdx.y = entry * groups + group).  The block stages the (8 + kH - 1) x (128 + KW - 1) tile of every input
+// plane in LDS once; per (input plane, kernel row) a thread reads its 4 + KW - 1 tile values (two ds_read_b128) and the KW weights
+// of each of its NT planes through scalar loads (the weight index is wave-uniform), i.e. 4 KW NT multiply-adds per 2 LDS reads.
+// Accumulation order per output: bias, then (input plane, ky, kx) with separately rounded multiply and add -- exactly
+// conv_kernel's, so the results are bit-identical to it and to the CPU loop.
+struct ConvBatch {
+    const float *in[2 * DFE_MAX_RATIOS];
+    float *out[2 * DFE_MAX_RATIOS];
+    const float *w[2 * DFE_MAX_RATIOS], *bias[2 * DFE_MAX_RATIOS];
+    int H[2 * DFE_MAX_RATIOS], W[2 * DFE_MAX_RATIOS];
+};
+constexpr int CB_TW = 128, CB_TH = 8, CB_PX = 4;
+extern __shared__ __attribute__((aligned(16))) float conv_smem[];
+
+template <int KW, int NT, bool TANH>
+__global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, int nOut, int kH, int groups) {
+#pragma clang fp contract(off)
+    constexpr int PITCH = CB_TW + 8;                       // (KW - 1 <= 8 halo columns; rows stay 16-B aligned)
+    const int ent = blockIdx.y / groups, grp = blockIdx.y - ent * groups;
+    const int H = cb.H[ent], W = cb.W[ent];
+    const int Ho = H - kH + 1, Wo = W - KW + 1;
+    const int tilesx = (Wo + CB_TW - 1) / CB_TW;
+    const int by = blockIdx.x / tilesx, bx = blockIdx.x - by * tilesx;
+    if (by * CB_TH >= Ho) return;                         // (entries of different sizes share one grid: block-uniform)
+    const int x0 = bx * CB_TW, y0 = by * CB_TH;
+    const int trows = CB_TH + kH - 1;
+    const float *__restrict__ in = cb.in[ent];
+    // stage: every input plane's tile (zero beyond the frame: those values only feed outputs that are not stored)
+    for (int e = threadIdx.x; e < nIn * trows * PITCH; e += 256) {
+        const int c = e % PITCH, t = e / PITCH;
+        const int r = t % trows, i = t / trows;
+        const int yy = y0 + r, xx = x0 + c;
+        conv_smem[e] = (yy < H && xx < W) ? in[((long long)i * H + yy) * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int o0 = grp * NT;
+    float acc[NT][CB_PX];
+#pragma unroll
+    for (int o = 0; o < NT; ++o) {
+        const float b = cb.bias[ent] ? cb.bias[ent][o0 + o] : 0.f;
+#pragma unroll
+        for (int q = 0; q < CB_PX; ++q) acc[o][q] = b;
+    }
+    const float *__restrict__ w = cb.w[ent];
+    for (int i = 0; i < nIn; ++i)
+        for (int u = 0; u < kH; ++u) {
+            const float4 *row = reinterpret_cast<const float4 *>(conv_smem + (i * trows + ty + u) * PITCH + CB_PX * tx);
+            const float4 t0 = row[0], t1 = row[1], t2 = row[2];
+            const float v[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+#pragma unroll
+            for (int o = 0; o < NT; ++o) {
+                typedef const float __attribute__((address_space(4))) *cfp;               // constant address space: the backend selects SMEM
+                const cfp wr = (cfp)(w + (((long long)(o0 + o) * nIn + i) * kH + u) * KW);   // (the index is wave-uniform)
+#pragma unroll
+                for (int k = 0; k < KW; ++k) {
+                    const float wk = wr[k];
+#pragma unroll
+                    for (int q = 0; q < CB_PX; ++q) acc[o][q] = acc[o][q] + wk * v[q + k];
+                }
+            }
+        }
+    const int y = y0 + ty;
+    if (y < Ho) {
+        float *__restrict__ out = cb.out[ent];
+#pragma unroll
+        for (int o = 0; o < NT; ++o)
+#pragma unroll
+            for (int q = 0; q < CB_PX; ++q) {
+                const int x = x0 + CB_PX * tx + q;
+                if (x < Wo) out[((long long)(o0 + o) * Ho + y) * Wo + x] = TANH ? tanhf(acc[o][q]) : acc[o][q];
+            }
+    }
+}
+
+template <int KW, int NT>
+static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn, int nOut, int kH, int tanh_after, int maxblocks) {
+    const int groups = nOut / NT;
+    const size_t lds = (size_t)nIn * (CB_TH + kH - 1) * (CB_TW + 8) * sizeof(float);
+    if (lds > 64 * 1024) return false;
+    auto kern = tanh_after ? conv_batch_kernel<KW, NT, true> : conv_batch_kernel<KW, NT, false>;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    hipLaunchKernelGGL(kern, dim3(maxblocks, n * groups), dim3(256), lds, ctx->stream, cb, nIn, nOut, kH, groups);
+    return true;
+}
+
+// n inputs through ONE layer (full connection): in[e] [nIn][H[e]][W[e]] -> out[e]; per-entry weights (the scales may have their own).
+// Falls back to one dfe_filter_layer_forward launch per entry for shapes without a batched instantiation.
+int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
+                                   float *const *out) {
+    DFE_REQUIRE(ctx, n >= 1 && n <= 2 * DFE_MAX_RATIOS, DFE_E_ARG, "filter layer batch: n=%d", n);
+    const dfe_filter_layer &L0 = *L[0];
+    bool same = true;
+    for (int e = 1; e < n; ++e)
+        same = same && L[e]->nIn == L0.nIn && L[e]->nOut == L0.nOut && L[e]->kH == L0.kH && L[e]->kW == L0.kW && L[e]->tanh_after == L0.tanh_after && !L[e]->conn;
+    if (same && !L0.conn && !getenv("DFE_NO_CONV_BATCH")) {
+        ConvBatch cb;
+        int maxblocks = 0;
+        bool ok = true;
+        for (int e = 0; e < n; ++e) {
+            DFE_REQUIRE(ctx, in[e] && out[e] && L[e]->weight && H[e] >= L0.kH && W[e] >= L0.kW, DFE_E_SHAPE, "filter layer batch: entry %d: %dx%d kernel on %dx%d", e,
+                        L0.kH, L0.kW, H[e], W[e]);
+            cb.in[e] = in[e]; cb.out[e] = out[e]; cb.w[e] = L[e]->weight; cb.bias[e] = L[e]->bias; cb.H[e] = H[e]; cb.W[e] = W[e];
+            const int b = dfe_cdiv(W[e] - L0.kW + 1, CB_TW) * dfe_cdiv(H[e] - L0.kH + 1, CB_TH);
+            if (b > maxblocks) maxblocks = b;
+        }
+        const int nt = L0.nOut % 8 == 0 ? 8 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
+        bool done = false;
+#define DFE_CB(KWV)                                                                                                                       \
+    if (L0.kW == KWV) {                                                                                                                   \
+        if (nt == 8) done = launch_conv_batch<KWV, 8>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                      \
+        else if (nt == 5) done = launch_conv_batch<KWV, 5>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
+        else if (nt == 4) done = launch_conv_batch<KWV, 4>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
+    }
+        if (ok && nt) { DFE_CB(3) DFE_CB(5) DFE_CB(7) }
+#undef DFE_CB
+        if (done) {
+            DFE_LAUNCH_CHECK(ctx);
+            return DFE_OK;
+        }
+    }
+    for (int e = 0; e < n; ++e) {
+        int rc = dfe_filter_layer_forward(ctx, in[e], *L[e], H[e], W[e], out[e]);
+        if (rc) return rc;
+    }
+    return DFE_OK;
+}
 
 int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out) {
     DFE_REQUIRE(ctx, in && L.weight && out, DFE_E_ARG, "filter layer: NULL tensor");

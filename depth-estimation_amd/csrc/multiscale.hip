@@ -1036,25 +1036,45 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
             hipLaunchKernelGGL(prep_frames_kernel, dim3(grid1d(pmax, 256 * 8), 2 * nratios), dim3(256), 0, ctx->stream, C, H, W, pf);
         }
         DFE_LAUNCH_CHECK(ctx);
-        for (int s = 0; s < nratios; ++s) {
-            const dfe_filter_layer *Ls = filt->layers + (filt->share ? 0 : s) * filt->nlayers;
-            const float *feat[2];
-            for (int f = 0; f < 2; ++f) {
-                DfeStageScope st(ctx, DFE_STAGE_FILTER);
-                const float *cur = pf.out[2 * s + f];
-                int h = pf.Hp[2 * s + f], w = pf.Wp[2 * s + f];
-                for (int l = 0; l < filt->nlayers; ++l) {
-                    float *dst = (float *)((char *)scr + off_f[s] + (size_t)(2 * f + (l & 1)) * fbuf[s]);
-                    rc = dfe_filter_layer_forward(ctx, cur, Ls[l], h, w, dst);
-                    if (rc) return rc;
-                    cur = dst; h -= Ls[l].kH - 1; w -= Ls[l].kW - 1;
-                }
-                feat[f] = cur;
+        // layer by layer, both frames of every scale in ONE launch (18 launches of a few microseconds each otherwise)
+        const float *cur[2 * DFE_MAX_RATIOS];
+        int ch[2 * DFE_MAX_RATIOS], cw[2 * DFE_MAX_RATIOS];
+        for (int e = 0; e < 2 * nratios; ++e) { cur[e] = pf.out[e]; ch[e] = pf.Hp[e]; cw[e] = pf.Wp[e]; }
+        for (int l = 0; l < filt->nlayers; ++l) {
+            DfeStageScope st(ctx, DFE_STAGE_FILTER);
+            const dfe_filter_layer *Lp[2 * DFE_MAX_RATIOS];
+            float *dst[2 * DFE_MAX_RATIOS];
+            for (int e = 0; e < 2 * nratios; ++e) {
+                const int s = e >> 1, f = e & 1;
+                Lp[e] = filt->layers + (filt->share ? 0 : s) * filt->nlayers + l;
+                dst[e] = (float *)((char *)scr + off_f[s] + (size_t)(2 * f + (l & 1)) * fbuf[s]);
             }
-            const int K = filt->nlayers ? Ls[filt->nlayers - 1].nOut : C;
-            DfeStageScope st(ctx, DFE_STAGE_MATCH);
-            rc = dfe_spatial_matching_dispatch(ctx, feat[0], feat[1], K, H / ratios[s], W / ratios[s], maxh, maxw, (float *)ss.cost[s]);
+            rc = dfe_filter_layer_forward_batch(ctx, 2 * nratios, cur, Lp, ch, cw, dst);
             if (rc) return rc;
+            for (int e = 0; e < 2 * nratios; ++e) { cur[e] = dst[e]; ch[e] -= Lp[e]->kH - 1; cw[e] -= Lp[e]->kW - 1; }
+        }
+        {
+            // every scale's nn.SpatialMatching in ONE launch where the one-chunk matcher applies (8 x 8 windows) -- with fp16 volumes
+            // written as halves directly when the lane <-> pixel cascade will read them; else scale by scale
+            DfeStageScope st(ctx, DFE_STAGE_MATCH);
+            const int K = filt->layers[filt->nlayers - 1].nOut;
+            bool same_k = true;
+            for (int s = 1; s < nratios && !filt->share; ++s) same_k = same_k && filt->layers[s * filt->nlayers + filt->nlayers - 1].nOut == K;
+            const float *m1[DFE_MAX_RATIOS], *m2[DFE_MAX_RATIOS];
+            float *mo[DFE_MAX_RATIOS];
+            int mh[DFE_MAX_RATIOS], mw[DFE_MAX_RATIOS];
+            for (int s = 0; s < nratios; ++s) { m1[s] = cur[2 * s]; m2[s] = cur[2 * s + 1]; mo[s] = (float *)ss.cost[s]; mh[s] = H / ratios[s]; mw[s] = W / ratios[s]; }
+            bool done = false;
+            if (same_k) {
+                rc = dfe_feat_matching_win64_batch(ctx, nratios, m1, m2, K, mh, mw, maxh, maxw, mo, (f16_scale != 0.f && px_path) ? f16_scale : 0.f, &done);
+                if (rc) return rc;
+                half_vol = done && f16_scale != 0.f && px_path;
+            }
+            for (int s = 0; s < nratios && !done; ++s) {
+                const dfe_filter_layer *Ls = filt->layers + (filt->share ? 0 : s) * filt->nlayers;
+                rc = dfe_spatial_matching_dispatch(ctx, m1[s], m2[s], Ls[filt->nlayers - 1].nOut, mh[s], mw[s], maxh, maxw, mo[s]);
+                if (rc) return rc;
+            }
         }
         merged = true;
         match_rest.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));

@@ -218,7 +218,10 @@ template <int M>
 __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__restrict__ part, const float *__restrict__ centre,
                                                             const float *__restrict__ lead, int nchunks, long long Ptot,
                                                             const float *__restrict__ vol, long long Pband, int N, int hWin,
-                                                            int wWin, int middle, double threshold, TailOut o) {
+                                                            int wWin, int middle, double threshold, TailOut o, const float *__restrict__ rec,
+                                                            int rec_rows) {
+    // rec != nullptr (launch-uniform): minimum / first index / centre cost of a pixel come from its tile row's record
+    // [column group][rec_rows][DFE_REC] (CvFuseArgs::rec), its lead cells from the volume; else from the three planes
     const long long nthreads_work = o.frame_H ? (long long)o.frame_H * o.frame_W : Pband;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nthreads_work; q += (long long)gridDim.x * blockDim.x) {
         long long p = q;
@@ -237,7 +240,22 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
             p = (long long)iy * o.Wo + ix;
         }
         const long long pg = o.p_off + p;
-        float2 b = part[pg];
+        const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
+        float2 b;
+        float cen;
+        if (rec) {
+            const int ncols = (o.Wo + 7) >> 3;
+            const int g = min(x >> 3, ncols - 1), xb = g == ncols - 1 ? o.Wo - 8 : g << 3;   // (the last tile column is shifted inwards)
+            const float *rp = rec + ((long long)g * rec_rows + y) * DFE_REC;
+            // (non-temporal: what this kernel reads is REWRITTEN by the next frame's cost-volume launch -- lines left in the memory-side
+            //  cache by these reads made that launch's stores slower: 1080p 2.4 against 1.8 ms)
+            b.x = __builtin_nontemporal_load(rp + 2 * (x - xb));
+            b.y = __builtin_nontemporal_load(rp + 2 * (x - xb) + 1);
+            cen = __builtin_nontemporal_load(rp + DFE_REC_CENTRE + x - xb);
+        } else {
+            b = part[pg];
+            cen = centre[pg];
+        }
         for (int c0 = 1; c0 < nchunks; c0 += 6) {   // six loads in flight, compared in chunk order (first chunk wins ties)
             float2 t[6];
 #pragma unroll
@@ -248,10 +266,9 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
                 if (t[j].x < b.x) b = t[j];
         }
         long long id = (long long)__float_as_int(b.y) + 1;
-        if (middle > 0 && b.x == centre[pg]) id = middle;
+        if (middle > 0 && b.x == cen) id = middle;
         if (o.idx) o.idx[pg] = id;
         if (o.best) o.best[pg] = b.x;
-        const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
         const long long fo = (long long)(y + o.pad_t) * o.pitch + x + o.pad_l;
         const long long fl = (id - 1) / wWin;
         const float dyf = (float)(fl - (hWin - 1) / 2), dxf = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
@@ -266,7 +283,14 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
             float qq[DFE_LEAD];
 #pragma unroll
             for (int g4 = 0; g4 < DFE_LEAD / 4; ++g4) {                                   // pixel-major [P][DFE_LEAD]: 4 x 16 B
-                const float4 q4 = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD)[g4];
+                // (record mode: the pixel's first cells straight from the volume -- N is a multiple of nothing in particular, but p * N * 4
+                //  bytes is 4-B aligned only: scalar loads)
+                float4 q4;
+                if (rec) {
+                    const float *lv = vol + p * N + 4 * g4;
+                    q4 = make_float4(__builtin_nontemporal_load(lv), __builtin_nontemporal_load(lv + 1), __builtin_nontemporal_load(lv + 2), __builtin_nontemporal_load(lv + 3));
+                }
+                else q4 = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD)[g4];
                 qq[4 * g4] = q4.x; qq[4 * g4 + 1] = q4.y; qq[4 * g4 + 2] = q4.z; qq[4 * g4 + 3] = q4.w;
             }
 #pragma unroll
@@ -465,7 +489,8 @@ int grid_for(long long n, int block) {
 int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
                       float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
-                      const DfePairDepth *pd) {
+                      const DfePairDepth *pd, const float *rec, int rec_rows) {
+    if (rec) nchunks = 1;
     TailOut o;
     o.frame_H = 0; o.frame_W = 0; o.depth = nullptr; o.conf = nullptr; o.mw = o.mh = o.infty = 0.f;
     if (pd) {   // frame mode: this call owns the whole frame (one band), fy / fx / scores are full-frame planes
@@ -481,10 +506,10 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
     const int grid = grid_for(pd ? (long long)pd->H * pd->W : Pb, 256);
     if (threshold < 0.2)   // extract_output.cpp:83-85
         hipLaunchKernelGGL(flow_finalize_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
-                           hWin, wWin, middle, threshold, o);
+                           hWin, wWin, middle, threshold, o, rec, rec_rows);
     else
         hipLaunchKernelGGL(flow_finalize_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
-                           hWin, wWin, middle, threshold, o);
+                           hWin, wWin, middle, threshold, o, rec, rec_rows);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

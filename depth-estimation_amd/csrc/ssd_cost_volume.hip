@@ -223,7 +223,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.1"
+#define DFE_CV_KERNEL_REV "cv-r3.2"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -262,6 +262,9 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #endif
 #ifndef DFE_CW0
 #define DFE_CW0 5    // row-image kernel: first wave that takes part in the copy-out (0 = all waves)
+#endif
+#ifndef DFE_REC_ST_FLAGS
+#define DFE_REC_ST_FLAGS ""   // cache-policy bits of the per-pixel record stores (tuning)
 #endif
 #ifndef DFE_ST_FLAGS
 // cache-policy bits of the copy-out stores.  The volume streams out and nothing re-reads it from L2: with the non-temporal
@@ -1127,7 +1130,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // ROLES: one wave per pixel.  121 lanes' worth of 9 cells = lanes 0..63 (cells 9 l ..) and a second unit on lanes 0..56
     // (cells 9 (64 + l) ..); both units' reads in flight together, ONE wave minimum for both, the first index from the lower
     // unit if any of its lanes attains the minimum.  Plane 1 of fa.part gets +inf (finalize keeps the smaller of the two).
-    auto scan_row_whole = [&](const float *stp, long long pgp) {
+    float *recbuf = stage + 2 * g_stage_len;       // ROLES: [2][DFE_REC] the tile row's record, double-buffered like the images
+    auto scan_row_whole = [&](const float *stp, int rpar) {
         if (DFE_ABLATE & 512) return;
         constexpr int CPL = 9;
         static_assert(!ROLES || DC % CPL == 0, "whole lanes only");
@@ -1163,23 +1167,42 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == vmin));
             idx = (64 + f) * CPL + __builtin_amdgcn_readlane(i1, f);
         }
-        if (lsc < 2 && xx >= nover)
-            fa.part[(long long)lsc * fa.Ptot + pgp + xx] = lsc == 0 ? make_float2(__int_as_float(vmin), __int_as_float(idx)) : make_float2(__int_as_float(0x7f800000), 0.f);
-        if (DFE_LEAD_FROM_IMAGE && !(DFE_ABLATE & 192)) {
-            // the pixel's lead cells (lanes 0..15) and its centre cell (lane 16) leave from the image too: ONE store of this wave
-            // instead of eight dword stores of wave 0 and two of wave 8 from their registers in front of the barrier -- a wave's
-            // own stores issue one behind the other, and wave 0 also carries a quarter task
-            static_assert(!ROLES || DC == 1089, "centre cell 544");
-            const float val = stp[xx * D + (lsc < DFE_LEAD ? lsc : 544)];
-            const float *lb = fa.lead + (pgp + xx) * DFE_LEAD, *cb = fa.centre + pgp + xx;   // (scalar bases, 32-bit lane offsets: no per-lane pointers)
-            if (xx >= nover) {
-                if (lsc < DFE_LEAD) asm volatile("global_store_dword %0, %1, %2" ::"v"((unsigned)lsc * 4u), "v"(val), "s"(lb) : "memory");
-                if (lsc == DFE_LEAD) asm volatile("global_store_dword %0, %1, %2" ::"v"(0u), "v"(val), "s"(cb) : "memory");
+        // The pixel's minimum, first index and centre cost go into the tile row's RECORD in LDS (8 x (min, idx) | 8 x centre | 0 ...);
+        // behind the NEXT barrier one wave writes the 128-B record out whole (write_record below).  Until round 3 every scan wave
+        // stored its pixel's entries into three planes itself: two 8-B entries, 64 B of lead cells, 4 B of centre per pixel and row
+        // step -- partial lines that neighbouring blocks on other XCDs complete, and the reason the fused 1080p kernel took
+        // 1.78 .. 2.21 ms depending on where the process' arena had landed (without them: 1.78 .. 1.81 ms in every process).
+        // The lead cells are not kept at all any more: finalize reads them back from the volume.
+        static_assert(!ROLES || DC == 1089, "centre cell 544");
+        if (!(DFE_ABLATE & 192)) {
+            const float cen = stp[xx * D + 544];
+            if (lsc == 0) {
+                float *rb = recbuf + rpar * DFE_REC;
+                rb[2 * xx] = __int_as_float(vmin);
+                rb[2 * xx + 1] = __int_as_float(idx);
+                rb[DFE_REC_CENTRE + xx] = cen;
             }
         }
     };
+    // the record of the tile row whose scan ran behind the previous barrier: [column group bx][output row yrow of the pair]
+    // (rb: the record's address, carried from row to row like G0 -- one 64-bit scalar instead of the base, the row pitch and the band
+    //  offset live across the sweep: this kernel has no scalar or vector register to spare, and a spill inside the row loop costs
+    //  the 1080p launch, whose scratch lines do not survive in L2 behind the 8.6-GB stream, 0.6 ms)
+    auto write_record = [&](int rpar, const float *rb) {
+        int lw = lane;
+        asm volatile("" : "+v"(lw));
+        if (lw < 8 && !(DFE_ABLATE & 192)) {
+            const f4_t v = *reinterpret_cast<const f4_t *>(recbuf + rpar * DFE_REC + 4 * lw);
+            asm volatile("global_store_dwordx4 %0, %1, %2" DFE_REC_ST_FLAGS ::"v"((unsigned)lw * 16u), "v"(v), "s"(rb) : "memory");
+        }
+    };
+    if constexpr (ROLES) {   // the record's tail (8 zeros per buffer) is written once per piece; the scans fill the rest
+        if (wave == 0 && lane < 16) recbuf[(lane >> 3) * DFE_REC + 24 + (lane & 7)] = 0.f;
+    }
     long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
     long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
+    // ROLES: record of the row BEFORE row r = 0 of this piece (output row y0 - K of column group bx); + DFE_REC per row step
+    const float *rec_prev = ROLES ? fa.rec + ((long long)bx * fa.rec_rows + (fa.row_off + y0 - (K - 1) - 1)) * DFE_REC : nullptr;
     const int nq = (nsweep + U - 1) / U;
     for (int q = 0; q < nq; ++q) {
         static_for<0, U>([&](auto mc) {
@@ -1345,7 +1368,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     }
                 }
                 if constexpr (ROLES) {
-                    if (store_row && wave < TX) scan_row_whole(st, pg_run);
+                    // (row r-1's record is complete: every scan wave has passed this barrier; its buffer is rewritten by the scan of
+                    //  row r+1, behind the next barrier)
+                    // (written by the first COPY wave: wave LW refills the rings and waits for its loads with vmcnt(0) -- a store of its own
+                    //  would put the whole store stream's latency into that wait: 1080p 2.32 against 1.8 ms)
+                    if (wave == TX && r - 1 >= K - 1 && y - 1 >= y0n) write_record((r - 1) & 1, rec_prev);
+                    if (store_row && wave < TX) scan_row_whole(st, r & 1);
                 } else if constexpr (FUSE && !DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
@@ -1437,7 +1465,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 }
                 DFE_TL(6);
             }
+            if constexpr (ROLES) rec_prev += DFE_REC;
         });
+    }
+    if constexpr (ROLES) {   // the piece's last row: its scan has no next barrier to be written behind
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int rl = nsweep - 1, yl = y0 + rl - (K - 1);
+        if (wave == TX && rl >= K - 1 && yl >= y0n) write_record(rl & 1, rec_prev);   // (rec_prev has been stepped past the last row: its record)
     }
     if constexpr (!SWEEP) break;
     pos += prows;
@@ -1473,7 +1507,7 @@ static size_t rowimg_plan(int ty, int H, int W, long long plane, int hWin, int w
     a.chunk0 = 0;
     a.sw_ovh = a.sw_min = 0;
     a.scale = 1.f;
-    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
+    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float) + 2 * DFE_REC * sizeof(float);   // images + the fused tile-row records
     if (lds_bytes > 160 * 1024) return 0;
     if (out_args) *out_args = a;
     return lds_bytes;
@@ -1565,7 +1599,7 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     a.stage_off = a.tile0_off + (int)(((size_t)R0 * kT0W * sizeof(px_t) + (size_t)U * 64 * sizeof(float) + 127) / 128 * 128);
     a.stage_len = (TX * D + 32 + 31) / 32 * 32;
     a.chunk0 = 0;
-    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float);
+    size_t lds_bytes = a.stage_off + (size_t)2 * a.stage_len * sizeof(float) + 2 * DFE_REC * sizeof(float);   // images + the fused tile-row records
     if (lds_bytes > 160 * 1024) return DFE_OK;
     const bool sq33 = hWin == 33 && wWin == 33;
     if (sq33 && (a.pitch != RowimgGeom<C, K, TX>::pitch33 || a.tile0_off != RowimgGeom<C, K, TX>::sweep_tile0_off ||
@@ -1657,10 +1691,14 @@ static int launch_cv_rowimg_f16(dfe_ctx *ctx, const float *I0, const float *I1, 
     return launch_cv_rowimg_one<C, K, TX, FUSE, true>(ctx, I0, I1, H, W, plane, hWin, wWin, ty, (float *)out, fa, handled, scale);
 }
 
+// the row-image kernel's role-split instantiations (3 channels, 33 x 33, fused) leave per-pixel RECORDS (fa.rec) instead of the planes
+static bool rowimg_writes_records(int C, int hWin, int wWin) { return DFE_ROLES && DFE_ROLES_STATIC && DFE_LEAD_FROM_IMAGE && C == 3 && hWin == 33 && wWin == 33; }
+
 // fp16 build of raw frames (C in {1, 3}, k = 7, 769..1096 window cells); *handled = false: no fast kernel for the shape
 int cv_frames_dispatch_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin, int wWin,
-                           float scale, void *out, const CvFuseArgs *fa, bool *handled) {
+                           float scale, void *out, const CvFuseArgs *fa, bool *handled, bool *recs = nullptr) {
     *handled = false;
+    if (recs) *recs = fa && rowimg_writes_records(C, hWin, wWin);
     if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || k != 7 || (C != 3 && C != 1)) return DFE_OK;
     if (fa) return C == 3 ? launch_cv_rowimg_f16<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, fa, handled)
                           : launch_cv_rowimg_f16<1, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, scale, out, fa, handled);
@@ -1754,8 +1792,9 @@ int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const 
 // *nparts: planes of fa.part the launched kernel filled -- 2 (the row-image kernel scans a pixel's run in two halves)
 // or ceil(D/64) (the tiled kernel leaves one entry per chunk)
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,
-                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts) {
+                             int wWin, float *out, const CvFuseArgs &fa, bool *handled, int *nparts, bool *recs) {
     *handled = false;
+    if (recs) *recs = false;
     *nparts = (hWin * wWin + 63) / 64;
     if (ctx->cv_mode == 1) return DFE_OK;
     if (hWin * wWin < 64) return DFE_OK;   // less than one full chunk: not worth a fused instantiation
@@ -1763,6 +1802,7 @@ int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int
         int rc = C == 3 ? launch_cv_rowimg<3, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled)
                         : launch_cv_rowimg<1, 7, 8, true>(ctx, I0, I1, H, W, plane, hWin, wWin, out, &fa, handled);
         if (*handled) *nparts = 2;
+        if (*handled && recs) *recs = rowimg_writes_records(C, hWin, wWin);
         if (rc != DFE_OK || *handled) return rc;
     }
     if (ctx->cv_mode == 3) return DFE_OK;   // forced row-image kernel that does not apply: unfused path reports it
@@ -1862,14 +1902,19 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
     const size_t part_bytes = ((size_t)nch * P * sizeof(float2) + 255) / 256 * 256;
     const size_t cen_bytes = ((size_t)P * sizeof(float) + 255) / 256 * 256;
     const size_t lead_bytes = ((size_t)P * DFE_LEAD * sizeof(float) + 255) / 256 * 256;
+    // per-pixel records of the role-split row-image kernels (one whole 128-B line per pixel instead of entries in the three planes)
+    const bool want_rec = kh == kw && kh == 7 && rowimg_writes_records(C, hWin, wWin);
+    const size_t rec_bytes = want_rec ? (size_t)dfe_cdiv(Wo, 8) * Ho * DFE_REC * sizeof(float) : 0;   // [tile column][output row][DFE_REC]
     void *scr = nullptr;
-    int rc = dfe_scratch(ctx, vol_bytes + part_bytes + cen_bytes + lead_bytes, &scr);
+    int rc = dfe_scratch(ctx, vol_bytes + part_bytes + cen_bytes + lead_bytes + rec_bytes, &scr);
     if (rc) return rc;
     float *vol = (float *)scr;
     CvFuseArgs fa{};
     fa.part = (float2 *)((char *)scr + vol_bytes);
     fa.centre = (float *)((char *)scr + vol_bytes + part_bytes);
     fa.lead = (float *)((char *)scr + vol_bytes + part_bytes + cen_bytes);
+    fa.rec = want_rec ? (float *)((char *)scr + vol_bytes + part_bytes + cen_bytes + lead_bytes) : nullptr;
+    fa.rec_rows = Ho;
     fa.Ptot = P;
     {
         const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);   // radial/radial_opticalflow_groundtruth.lua:91
@@ -1880,18 +1925,18 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
         const int r0 = (int)((long long)bi * Ho / nb), nr = (int)((long long)(bi + 1) * Ho / nb) - r0;   // (nr <= band)
         const int Hb = nr + kh - 1 + hWin - 1;
         const float *b0 = I0 + (long long)r0 * W, *b1 = I1 + (long long)r0 * W;
-        bool fused = false;
+        bool fused = false, recs = false;
         int nparts = nch;
         std::unique_ptr<DfeStageScope> match_scope(new DfeStageScope(ctx, DFE_STAGE_MATCH));   // (closed in front of the finalize / tail pass below)
         if (kh == kw && f16_scale != 0.f) {
             fa.row_off = r0;
-            rc = cv_frames_dispatch_f16(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, f16_scale, vol, &fa, &fused);
+            rc = cv_frames_dispatch_f16(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, f16_scale, vol, &fa, &fused, &recs);
             if (rc) return rc;
             nparts = 2;
             if (!fused) return dfe_fail(ctx, DFE_E_UNSUPPORTED, "no fused fp16 cost-volume kernel for C=%d k=%d win=%dx%d out=%dx%d (band of %d rows)", C, kh, hWin, wWin, Ho, Wo, nr);
         } else if (kh == kw) {
             fa.row_off = r0;
-            rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused, &nparts);
+            rc = cv_frames_dispatch_fused(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, hWin, wWin, vol, fa, &fused, &nparts, &recs);
             if (rc) return rc;
         }
         if (fused) {
@@ -1900,7 +1945,7 @@ static int flow_pipeline(dfe_ctx *ctx, const float *I0, const float *I1, int C, 
             // one band: the finalize launch also zeroes the frame border and makes depth (pair step: 2 launches instead of 3)
             const bool frame_mode = pd && nr == Ho;
             rc = dfe_flow_finalize(ctx, fa.part, fa.centre, fa.lead, nparts, P, vol, thr, nr, Wo, hWin, wWin, r0, idx, best, fy, fx, scores,
-                                   imaxs, pitch, pad_t, pad_l, scores_padded, frame_mode ? pd : nullptr);
+                                   imaxs, pitch, pad_t, pad_l, scores_padded, frame_mode ? pd : nullptr, (recs && fused) ? fa.rec : nullptr, Ho);
             if (frame_mode && pd_done) *pd_done = true;
         } else {
             rc = cv_frames_dispatch(ctx, b0, b1, C, Hb, W, (long long)H * W, kh, kw, hWin, wWin, vol);

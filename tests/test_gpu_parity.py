@@ -962,7 +962,7 @@ def test_stage_timers_with_the_reference_names(dfe, cuda):
         model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=torch.Generator().manual_seed(1))
         model.forwardFlow([t0 / 255, t1 / 255], False, one_call=True)
         ms, n = read()
-        assert n[1] == 1 + 3 * 2 and n[2] == 3 + 1 and n[3] == 0 and ms[1] > 0 and ms[2] > 0      # prep + 2 frames x 3 scales; 3 matchers + the cascade
+        assert n[1] == 1 + 2 and n[2] == 1 + 1 and n[3] == 0 and ms[1] > 0 and ms[2] > 0      # prep + one batched launch per layer; the batched matcher + the cascade
         # a staged upload counts as load
         host = np.zeros(1 << 16, np.float32)
         dev = torch.empty(1 << 16, device=cuda)
