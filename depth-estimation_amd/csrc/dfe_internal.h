@@ -295,18 +295,14 @@ template <int TX> __device__ __forceinline__ int wave_min8(const int (&k)[TX], i
     return c;
 }
 
-// exp(x) for x <= 0 -- the soft-min's arguments, -c - max(-c): Cody-Waite reduction with log2(e) split in two floats,
-// v_exp_f32 on the reduced argument in [-0.5, 0.5], scaling by 2^n (which also flushes what underflows).  That is the
-// library expf without its overflow branch and range selects: 7 instructions instead of 13 -- the 64 calls per pixel were
-// 60 % of the finest cascade kernel's arithmetic.  EVERY soft-min on the device goes through this function, so the staged
-// and the one-call paths stay bit-identical to each other; against glibc's expf the result differs in the last place at
-// most, as the library's did (the multiscale tests are tie-aware for that reason).
+// exp(x) for x <= 0 -- the soft-min's arguments, -c - max(-c): v_exp_f32 on x * log2(e), two instructions.  The product's rounding
+// moves the result by |x| * 2^-24 relative at most, i.e. by less than 4e-8 ABSOLUTE for every x <= 0 (|x| e^x <= 1/e), against the
+// 1e-6 the soft-min is held to (the reference's own nn.SoftMax of that era used a polynomial exp: its numerics are
+// unpinned anyway).  Round 2 had the library expf without its overflow branch (Cody-Waite reduction + ldexp: 7 instructions, 13 in
+// the library form) -- the 64 calls per pixel were 60 % of the finest cascade kernel's arithmetic.  EVERY soft-min on the device goes
+// through this function, so the staged and the one-call paths stay bit-identical to each other.
 __device__ __forceinline__ float dfe_exp_nonpos(float x) {
-    const float L = 0x1.715476p+0f, Llo = 0x1.4ae0c0p-26f;   // log2(e) = L + Llo to 4e-16
-    const float n = __builtin_rintf(x * L);
-    float r = __builtin_fmaf(x, L, -n);
-    r = __builtin_fmaf(x, Llo, r);
-    return __builtin_ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+    return __builtin_amdgcn_exp2f(x * 0x1.715476p+0f);
 }
 
 // wave reductions of the soft-min (multiscale.hip and the volume kernel's soft-min epilogue): everything on the VALU

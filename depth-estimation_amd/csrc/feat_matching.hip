@@ -195,9 +195,27 @@ __global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, in
     const int trows = F64_TY + maxh - 1, tcols = FM_TX + maxw - 1;
     const long long plane1 = (long long)H1 * W1, plane2 = (long long)H2 * W2;
     const float *__restrict__ in2 = fb.in2[z];
-    for (int r = wave; r < K * trows; r += 8) {            // tile rows dealt to the waves, lanes along a row
-        const int k = r / trows, rr = r - k * trows;
-        if (lane < tcols) fm_smem[r * pitch + lane] = in2[k * plane2 + (long long)(y0 + rr) * W2 + x0 + lane];
+    {
+        // staging: a load instruction covers FOUR tile rows (16 lanes each: tcols <= 16 here), and a thread issues all of its loads
+        // before the first LDS write -- one exposed memory latency per block instead of one per tile row (the first version, a row
+        // per iteration with the LDS write behind each load, spent 80 % of the launch waiting here)
+        constexpr int NB = 8;                                  // loads in flight per thread
+        const int rsub = threadIdx.x >> 4, c = threadIdx.x & 15;     // 32 row slots x 16 columns per pass
+        const int nrows = K * trows;
+        for (int r0 = 0; r0 < nrows; r0 += 32 * NB) {
+            float v[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = min(r0 + i * 32 + rsub, nrows - 1);
+                const int k = r / trows, rr = r - k * trows;
+                v[i] = in2[k * plane2 + (long long)(y0 + rr) * W2 + x0 + min(c, tcols - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int r = r0 + i * 32 + rsub;
+                if (r < nrows && c < tcols) fm_smem[r * pitch + c] = v[i];
+            }
+        }
     }
     __syncthreads();
     const int dy = lane / maxw, dx = lane - dy * maxw;
@@ -298,6 +316,7 @@ int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, 
         vol += (size_t)H1[i] * W1[i] * 64 * (f16_scale != 0.f ? 2 : 4);
     }
     const int tcols = FM_TX + maxw - 1, trows = F64_TY + maxh - 1;
+    if (tcols > 16) return DFE_OK;                         // (the staging deals 16 columns per tile row)
     int pitch = tcols;
     while ((pitch - maxw) % 32 != 0) ++pitch;              // pitch == maxw (mod 32): conflict-free for the lane <-> (dy, dx) reads
     size_t lds = (size_t)K * trows * pitch * sizeof(float);

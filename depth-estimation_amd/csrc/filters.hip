@@ -118,11 +118,27 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
     const int trows = CB_TH + kH - 1;
     const float *__restrict__ in = cb.in[ent];
     // stage: every input plane's tile (zero beyond the frame: those values only feed outputs that are not stored)
-    for (int e = threadIdx.x; e < nIn * trows * PITCH; e += 256) {
-        const int c = e % PITCH, t = e / PITCH;
-        const int r = t % trows, i = t / trows;
-        const int yy = y0 + r, xx = x0 + c;
-        conv_smem[e] = (yy < H && xx < W) ? in[((long long)i * H + yy) * W + xx] : 0.f;
+    {
+        // (all of a thread's loads in flight before the first LDS write: NB independent loads per round instead of a load -> wait ->
+        //  write chain per element; rows of 136 = 34 float4-wide groups would also do, but the frame rows are only 4-B aligned)
+        constexpr int NB = 8;
+        const int total = nIn * trows * PITCH;
+        for (int e0 = 0; e0 < total; e0 += 256 * NB) {
+            float v[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int e = min(e0 + j * 256 + (int)threadIdx.x, total - 1);
+                const int c = e % PITCH, t = e / PITCH;
+                const int r = t % trows, i = t / trows;
+                const int yy = min(y0 + r, H - 1), xx = min(x0 + c, W - 1);        // (clamped: those values only feed outputs that are not stored)
+                v[j] = in[((long long)i * H + yy) * W + xx];
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int e = e0 + j * 256 + (int)threadIdx.x;
+                if (e < total) conv_smem[e] = v[j];
+            }
+        }
     }
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;

@@ -81,6 +81,103 @@ template <int VAR> __global__ __launch_bounds__(1024) void k(const float *__rest
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
+// The same task row with the frame-1 tile PLANAR in LDS ([row][channel][75] floats: row stride 225 == 33 mod 32, conflict-free) and
+// the squared differences in PACKED fp32 (two pixels per instruction): per channel 7 ds_read2_b32 give the pixel pairs (2j, 2j+1),
+// v_pk_add_f32 with the frame-0 pair as an SGPR-pair operand and neg modifiers subtracts, v_pk_mul / v_pk_fma square and add.  21 LDS
+// reads of 512 B instead of 14 of 1 KB; 42 packed instead of 84 plain VALU instructions for the 14 squared differences.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef f2 f2u __attribute__((aligned(4)));
+extern __shared__ float ldsf[];
+template <int VAR> __global__ __launch_bounds__(1024) void kp(const float *__restrict__ a0, float *out, int iters) {
+    constexpr int PP = 75, RS = 3 * PP;
+    for (int i = threadIdx.x; i < 64 * RS; i += blockDim.x) ldsf[i] = i * 0.5f;
+    __syncthreads();
+    float *stage = ldsf + 64 * RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *lr0 = ldsf + (lane / 33) * RS + (lane % 33);
+    float ring[6][8];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) ring[i][x] = 0.f;
+    f2 av[3][7];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int s = 0; s < 7; ++s) av[c][s] = f2{((cfptr)a0)[c * 14 + 2 * s], ((cfptr)a0)[c * 14 + 2 * s + 1]};    // uniform -> SGPR pairs
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const float *lr = lr0 + ((it * 6 + m) & 15) * RS;
+            f2 e2[7];
+            f2 b[2][7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) b[0][j] = *reinterpret_cast<const f2u *>(lr + 2 * j);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (c < 2) {
+#pragma unroll
+                    for (int j = 0; j < 7; ++j) b[(c + 1) & 1][j] = *reinterpret_cast<const f2u *>(lr + (c + 1) * PP + 2 * j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (all seven differences first, in place over the pixel pairs, then the seven squares: a packed op that consumes the
+                //  result of the one just in front of it costs a wait state and the full pipeline latency)
+#pragma unroll
+                for (int j = 0; j < 7; ++j) asm("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(b[c & 1][j]) : "s"(av[c][j]));
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    if (c == 0) asm("v_pk_mul_f32 %0, %1, %1" : "=v"(e2[j]) : "v"(b[c & 1][j]));
+                    else asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(e2[j]) : "v"(b[c & 1][j]));
+                }
+            }
+            float e[14];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) { e[2 * j] = e2[j][0]; e[2 * j + 1] = e2[j][1]; }
+            float sa[7], pb[7], h[8];
+            sa[6] = e[6];
+#pragma unroll
+            for (int i = 5; i >= 0; --i) sa[i] = e[i] + sa[i + 1];
+            pb[0] = e[7];
+#pragma unroll
+            for (int j = 1; j < 7; ++j) pb[j] = pb[j - 1] + e[7 + j];
+            h[0] = sa[0];
+#pragma unroll
+            for (int x = 1; x < 7; ++x) h[x] = sa[x] + pb[x - 1];
+            h[7] = pb[6];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float v = (ring[m][x] + ring[(m + 2) % 6][x]) + (ring[(m + 4) % 6][x] + h[x]);
+                ring[(m + 5) % 6][x] += h[x];
+                ring[m][x] = h[x];
+                if (VAR >= 1) stage[(m & 1) * 8800 + x * 1089 + wave * 64 + lane] = v; else
+                acc += v;
+            }
+            if (VAR >= 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+template <int VAR> void runp(const float *a0, float *d, int wps, const char *name) {
+    int iters = 512, blocks = 256, threads = 256 * wps;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void *)kp<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
+    hipLaunchKernelGGL(kp<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, 8);
+    (void)hipDeviceSynchronize();
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(kp<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, iters);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    double rows = (double)iters * 6;
+    double us_per_row = best * 1e3 / rows;
+    printf("%-28s waves/SIMD=%d  %.3f ms  %.4f us per row step (all waves of a SIMD)  = %.0f cycles @2.3GHz per wave-row\n", name, wps, best,
+           us_per_row, us_per_row * 2300.0 / wps);
+}
 template <int VAR> void run(const float *a0, float *d, int wps, const char *name) {
     int iters = 512, blocks = 256, threads = 256 * wps;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -104,5 +201,6 @@ int main() {
     float *a0, *d; (void)hipMalloc(&a0, 64 * 4); (void)hipMalloc(&d, 256 * 1024 * 4);
     (void)hipMemset(a0, 0, 64 * 4);
     for (int w : {4, 2, 1}) { run<0>(a0, d, w, "arithmetic only"); run<3>(a0, d, w, "+ 14 ds_read_b128"); run<4>(a0, d, w, "+ reads + 8 ds_write_b32"); run<5>(a0, d, w, "+ reads, writes, barrier"); }
+    for (int w : {4, 2, 1}) { runp<0>(a0, d, w, "PACKED planar: reads + arith"); runp<1>(a0, d, w, "PACKED + 8 ds_write_b32"); runp<2>(a0, d, w, "PACKED + writes, barrier"); }
     return 0;
 }
