@@ -1090,6 +1090,14 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     for (int s = 0; s < nratios; ++s)
         if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
     if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
+    // raw patches, 3 channels, 7 x 7, on the lane <-> pixel path: the finest scale is fused into its volume kernel (no volume)
+    // -- where it pays: the fused kernel is VALU-bound (three 64-lane reductions per pixel), the volume it saves is HBM traffic that the
+    // small frames hide behind the coarse scales' launches.  Measured, volume path -> fused: VGA 0.076 -> 0.099 ms, 720p 0.213 ->
+    // 0.185, 1080p 0.430 -> 0.366, 4K 1.94 -> 1.40; fp16 volumes (half the bytes to save): 1080p 0.344 -> 0.368, 4K 1.48 -> 1.32.
+    // DFE_FINE_FUSE=0 / 1 forces the choice.
+    bool try_fine = px_path && !filt && C == 3 && k == 7 && (long long)H * W >= (f16_scale != 0.f ? 3000000ll : 600000ll);
+    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && !filt && C == 3 && k == 7 && atoi(e) != 0;
+    const int s0 = try_fine ? 1 : 0;
     if (filt) {
         // learned filters (getModelMultiscale's filter1 / filter2, opticalflow_model_multiscale.lua:196-211): frame 0 is cropped by
         // the search window BEFORE the filter (its zero padding shrinks by floor / ceil((maxh-1)/2)), both padded frames go
@@ -1155,31 +1163,34 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     } else {
         // one launch for every scale's volume; on the fast path the coarser scales leave it as soft-min probabilities already
         // (their blocks run next to the scale-1 blocks that dominate the launch), scale 1 as costs for the cascade's SOFT0
+        // (s0 = 1: the finest scale has NO volume -- its task rows are consumed inside the volume kernel, cv_frames_finest_fused below)
         const float *f0[DFE_MAX_RATIOS], *f1[DFE_MAX_RATIOS];
         float *vo[DFE_MAX_RATIOS], *pr[DFE_MAX_RATIOS];
-        for (int s = 0; s < nratios; ++s) {
-            f0[s] = ps.p0[s]; f1[s] = ps.p1[s]; vo[s] = (float *)ss.cost[s];
-            pr[s] = (fast && s > 0 && !px_path) ? ss.prob[s] : nullptr;
+        int vh[DFE_MAX_RATIOS], vw[DFE_MAX_RATIOS];
+        const int nv = nratios - s0;
+        for (int s = s0; s < nratios; ++s) {
+            f0[s - s0] = ps.p0[s]; f1[s - s0] = ps.p1[s]; vo[s - s0] = (float *)ss.cost[s]; vh[s - s0] = ps.Hp[s]; vw[s - s0] = ps.Wp[s];
+            pr[s - s0] = (fast && s > 0 && !px_path) ? ss.prob[s] : nullptr;
         }
         // fp16 volumes: written as halves by the volume kernel itself where the lane <-> pixel cascade will read them (8 x 8
         // windows, C = 3, k = 7); any other shape builds fp32 volumes and rounds them to half precision in place -- same values
-        if (f16_scale != 0.f && px_path) {
-            rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, nullptr, &merged, &soft_done, f16_scale);
+        if (f16_scale != 0.f && px_path && nv >= 1) {
+            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, nullptr, &merged, &soft_done, f16_scale);
             if (rc) return rc;
             half_vol = merged;
         }
-        if (!merged) {
-            rc = cv_frames_dispatch_multi(ctx, nratios, f0, f1, C, ps.Hp, ps.Wp, k, maxh, maxw, vo, f16_scale != 0.f ? nullptr : pr, &merged, &soft_done);
+        if (!merged && nv >= 1) {
+            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, f16_scale != 0.f ? nullptr : pr, &merged, &soft_done);
             if (rc) return rc;
         }
     }
-    for (int s = 0; s < nratios && !merged; ++s) {
+    for (int s = s0; s < nratios && !merged; ++s) {
         rc = cv_frames_dispatch(ctx, ps.p0[s], ps.p1[s], C, ps.Hp[s], ps.Wp[s], (long long)ps.Hp[s] * ps.Wp[s], k, k, maxh, maxw,
                                 (float *)ss.cost[s]);
         if (rc) return rc;
     }
     if (f16_scale != 0.f && !half_vol) {
-        for (int s = 0; s < nratios; ++s) {
+        for (int s = s0; s < nratios; ++s) {
             const long long n = ss.P[s] * N;
             hipLaunchKernelGGL(round_half_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, (float *)ss.cost[s], n, f16_scale, 1.0f / f16_scale);
         }
@@ -1192,13 +1203,40 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         fill_cell_maps(g, dt);
         // coarse -> fine: one launch per scale, except that the coarsest scale is recomputed inside its child's launch
         const int top = nratios >= 2 ? nratios - 2 : 0;
-        for (int s = top; s >= 0; --s) {
+        bool fine_done = false;
+        // with the fused finest scale and only two ratios the coarsest scale is the finest one's parent: it needs a launch of its own
+        const bool lone_parent = try_fine && nratios == 2;
+        for (int s = lone_parent ? 1 : top; s >= 0; --s) {
             const int r = ratios[s];
+            if (s == 0 && try_fine) {
+                CvFineArgs fine{};
+                if (nratios >= 2) {
+                    fine.pcasc = (const float *)((char *)scr + off_q[1]);
+                    fine.pbest = (const float2 *)((char *)scr + off_b[1]);
+                }
+                fine.idx = (long long *)idx;
+                fine.fy = flow;
+                fine.fx = flow ? flow + (size_t)H * W : nullptr;
+                fine.middle = middle;
+                fine.f16_scale = f16_scale;
+                fine.f16_inv = f16_scale != 0.f ? 1.0f / f16_scale : 0.f;
+                for (int c = 0; c < 5 * 64; ++c) fine.dec[c] = c < g.ncls ? dt.v[c] : 0;
+                rc = cv_frames_finest_fused(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], k, maxh, maxw, fine, &fine_done);
+                if (rc) return rc;
+                if (fine_done) break;
+                // no plan for this frame: the scale-1 volume after all (fp32; rounded in place for the fp16 entry), then the px kernel
+                rc = cv_frames_dispatch(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], (long long)ps.Hp[0] * ps.Wp[0], k, k, maxh, maxw, (float *)ss.cost[0]);
+                if (rc) return rc;
+                if (f16_scale != 0.f) {
+                    const long long n = ss.P[0] * N;
+                    hipLaunchKernelGGL(round_half_kernel, dim3(grid1d(n, 256)), dim3(256), 0, ctx->stream, (float *)ss.cost[0], n, f16_scale, 1.0f / f16_scale);
+                }
+            }
             CascadePxArgs a{};
             a.cost = (const float *)ss.cost[s];
             a.Hs = H / r; a.Ws = W / r; a.scale = s; a.middle = middle; a.cls_base = g.base[s];
-            a.inv_scale = half_vol ? 1.0f / f16_scale : 1.0f;
-            const bool inl = nratios >= 2 && s == top;
+            a.inv_scale = (half_vol && !(s == 0 && try_fine)) ? 1.0f / f16_scale : 1.0f;
+            const bool inl = nratios >= 2 && s == top && !lone_parent && !(s == 0 && try_fine);
             if (inl) {
                 a.pcost = (const float *)ss.cost[s + 1];
                 a.pcls_base = g.base[s + 1];
@@ -1219,7 +1257,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
                 a.idx = (long long *)idx;
                 a.fy = flow;
                 a.fx = flow ? flow + (size_t)H * W : nullptr;
-                if (half_vol) {
+                if (half_vol && !try_fine) {
                     if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
                     else hipLaunchKernelGGL((cascade_px_kernel<true, false, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
                 } else if (inl) hipLaunchKernelGGL((cascade_px_kernel<true, true>), dim3(blocks), dim3(256), 0, ctx->stream, a, dt);
@@ -1227,6 +1265,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
             }
         }
         DFE_LAUNCH_CHECK(ctx);
+        (void)fine_done;
         return DFE_OK;
     }
     // one-cell-per-lane path: the scale-1 soft-min happens inside the cascade kernel (SOFT0), the coarser scales' here

@@ -223,7 +223,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.2"
+#define DFE_CV_KERNEL_REV "cv-r3.3"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -367,6 +367,120 @@ __device__ __forceinline__ int wave_min1(int c) {
     return min((int)q[0], (int)q[1]);
 }
 
+// Eight wave reductions at once, "transposed": v[x] is pixel x's value in this lane's cell; the butterfly's first three steps pair
+// up REGISTERS as well as lanes (v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two registers, so one swap
+// + one op serves two pixels), halving the live registers at every step, and the last three run on one register.  The result for
+// pixel g ends up in lane 8 g.  Partners at distance 32, 16, 8, 4, 2, 1 and the lower lane's value on the left of every +: the sum
+// has the association of wave_sum_f32_ordered / px_softmin64 bit for bit.  18 VALU operations instead of 8 x 12.
+// OP 0: fp32 sum; 1 / 2: minimum / maximum of NON-NEGATIVE floats, taken on their bit patterns as integers (the same order, and no
+// canonicalising v_max x, x, x in front of every operand the way fminf / fmaxf compile).
+template <int OP>
+__device__ __forceinline__ int wave_reduce8_op(int a, int b) {
+#pragma clang fp contract(off)
+    return OP == 0 ? __float_as_int(__int_as_float(a) + __int_as_float(b)) : OP == 1 ? min(a, b) : max(a, b);
+}
+template <int OP>
+__device__ __forceinline__ int wave_reduce8_transposed(const float (&v)[8], int lane) {
+    int r1[4], r2[2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {        // lanes < 32: pixel x, lanes >= 32: pixel x + 4
+        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_int(v[x]), __float_as_int(v[x + 4]), false, false);
+        r1[x] = wave_reduce8_op<OP>((int)q[0], (int)q[1]);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {        // rows 0..3: pixels x, x + 2, x + 4, x + 6
+        const auto q = __builtin_amdgcn_permlane16_swap(r1[x], r1[x + 2], false, false);
+        r2[x] = wave_reduce8_op<OP>((int)q[0], (int)q[1]);
+    }
+    const bool up = (lane & 8) != 0;     // from here on lane L works for pixel L >> 3
+    const int keep = up ? r2[1] : r2[0], send = up ? r2[0] : r2[1];
+    int r = wave_reduce8_op<OP>(keep, __builtin_amdgcn_update_dpp(0, send, 0x128, 0xf, 0xf, true));                  // row_ror:8
+    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0x104, 0xf, 0xf, true));                           // row_shl:4 (lane j reads lane j + 4)
+    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xf, 0xf, true));                            // quad_perm [2,3,0,1]
+    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xf, 0xf, true));                            // quad_perm [1,0,3,2]
+    return r;                             // lane 8 g: pixel g (other lanes: partial results)
+}
+
+// The finest scale of the multiscale matcher, consumed where it is produced: a task row is 8 pixels x the 64 cells of their 8 x 8
+// windows, lane <-> cell.  Per pixel: soft-min over the wave (wave minimum of the costs, exponential, wave sum in the association
+// order of every other soft-min on the device, e * (1 / sum)), cascade add of the parent pixel's window (cell (a, b) reads the
+// parent's cell (2 + a/2, 2 + b/2): one ds_bpermute of the parent value every lane holds for its own cell), arg-max over the 64
+// classes of this scale (wave maximum, lowest lane attaining it) against the coarser chain's running best (this scale wins ties:
+// its class ids are smaller), centre override, decode -- the operations of cascade_px_kernel<FINEST> in the lane <-> cell form, on
+// the same values in the same order: bit-identical results, and the scale-1 volume (84 % of the pyramid's bytes) is never written
+// or read.  The three reductions run for the 8 pixels together (wave_reduce8_transposed); lane 8 g finishes pixel g and stores it.
+//   (-c) - max(-c) == min(c) - c bit for bit; costs are sums of squares (>= +0) and the cascaded values sums of probabilities, so the
+//   integer order of the bit patterns is the float order (frames with NaN / Inf give garbage on either path, not the same garbage).
+//   Centre override (bv == centre value): the centre is one of the 64 cells, so centre <= fv; if the coarser chain's best wins
+//   (pbv > fv) it is larger than the centre, otherwise bv = fv and the test is "the centre cell attains the maximum" = its bit in
+//   the ballot the arg-max needs anyway.
+template <int TX, bool F16>
+__device__ __forceinline__ void fine_epilogue(const float (&vrow)[TX], int lane, int y, int xt, int Wo, const CvFineArgs &fa) {
+#pragma clang fp contract(off)
+    static_assert(TX == 8, "8 fine pixels = 4 parent pixels");
+    const int a = lane >> 3, b = lane & 7;
+    const int gsrc = (((2 + (a >> 1)) << 3) + 2 + (b >> 1)) << 2;          // byte address for ds_bpermute: the parent cell this cell adds
+    const bool has_parent = fa.pcasc != nullptr;                            // (launch-uniform)
+    float par[4];
+    float2 pb = make_float2(0.f, 0.f);
+    if (has_parent) {
+        const long long pp = (long long)(y >> 1) * (Wo >> 1) + (xt >> 1);
+        const float *pc = fa.pcasc + pp * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) par[j] = pc[j * 64];
+        pb = fa.pbest[pp + (lane >> 4)];                                    // lane 8 g: the running best of pixel g's parent
+    }
+    float v[TX];
+#pragma unroll
+    for (int x = 0; x < TX; ++x) v[x] = F16 ? (float)(_Float16)(vrow[x] * fa.f16_scale) * fa.f16_inv : vrow[x];   // what a stored fp16 volume would hold
+    const int mn = wave_reduce8_transposed<1>(v, lane);
+    int bc[TX];
+#define DFE_BCAST8(src)                                                                                                          \
+    _Pragma("unroll") for (int x = 0; x < TX; ++x) bc[x] = __builtin_amdgcn_readlane(src, 8 * x);                                \
+    asm volatile("" : "+s"(bc[0]), "+s"(bc[1]), "+s"(bc[2]), "+s"(bc[3]), "+s"(bc[4]), "+s"(bc[5]), "+s"(bc[6]), "+s"(bc[7]))   // (all eight read before the first use: no wait states between a v_readlane and its consumer)
+    DFE_BCAST8(mn);
+#pragma unroll
+    for (int x = 0; x < TX; ++x) v[x] = dfe_exp_nonpos(__int_as_float(bc[x]) - v[x]);
+    const int rs = __float_as_int(1.0f / __int_as_float(wave_reduce8_transposed<0>(v, lane)));
+    DFE_BCAST8(rs);
+#undef DFE_BCAST8
+#pragma unroll
+    for (int x = 0; x < TX; ++x) v[x] = v[x] * __int_as_float(bc[x]);
+    if (has_parent) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g = __int_as_float(__builtin_amdgcn_ds_bpermute(gsrc, __float_as_int(par[j])));
+            v[2 * j] = v[2 * j] + g;
+            v[2 * j + 1] = v[2 * j + 1] + g;
+        }
+    }
+    const int fvp = wave_reduce8_transposed<2>(v, lane);
+    const int mbit = (fa.middle - 1) & 63;
+    unsigned long long codes = 0;                                           // byte x: pixel x's first maximal cell | centre-is-maximal << 6
+#pragma unroll
+    for (int x = 0; x < TX; ++x) {
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(__float_as_int(v[x]) == __builtin_amdgcn_readlane(fvp, 8 * x));
+        const unsigned long long code = (unsigned long long)__builtin_ctzll(hit) | (((hit >> mbit) & 1ull) << 6);
+        codes |= code << (8 * x);
+    }
+    if ((lane & 7) == 0) {
+        const int g = lane >> 3;
+        const int code = (int)(codes >> (8 * g)) & 0xff;
+        int bi = code & 63;
+        bool centre = (code & 64) != 0;
+        if (has_parent && !(__int_as_float(fvp) >= pb.x)) { bi = __float_as_int(pb.y); centre = false; }   // the scale wins ties against the coarser chain
+        int id = bi + 1;
+        if (fa.middle > 0 && centre) id = fa.middle;
+        const long long p = (long long)y * Wo + xt + g;
+        if (fa.idx) fa.idx[p] = id;
+        if (fa.fy) {
+            const int d = fa.dec[id - 1];
+            fa.fy[p] = (float)(d >> 16);
+            fa.fx[p] = (float)(short)(d & 0xffff);
+        }
+    }
+}
+
 // Rows are swept in groups of U (the unroll that makes every ring index static):
 //   K == 7: U = 6, vertical sum as the fixed tree ((H0+H1)+(H2+H3))+((H4+H5)+H6) kept as a ring of six
 //           pair sums P_r = H_r + H_{r+1}  -> 4 adds per output;
@@ -384,9 +498,11 @@ template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K;
 // SOFT (windows of at most one chunk): where `prob` is given, a task row leaves as soft-min probabilities instead of costs --
 // p = e / sum(e), e = expf(-c - max(-c)) over the cells of a pixel = the lanes of the wave, with the arithmetic of
 // softmin_kernel (multiscale.hip), so the result is bit-identical to running that kernel on the stored volume.
-template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE, bool SOFT = false>
+// FINE (8 x 8 windows, the finest scale of the multiscale matcher): nothing is stored; a task row goes through fine_epilogue below
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE, bool SOFT = false, bool FINE = false, bool FINE16 = false>
 __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, const float *__restrict__ I1, float *__restrict__ out,
-                                                  const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by, float *__restrict__ prob = nullptr) {
+                                                  const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by, float *__restrict__ prob = nullptr,
+                                                  const CvFineArgs *fine = nullptr) {
     using px_t = typename Px<C>::type;
     constexpr int U = VUnroll<K>::value;
     constexpr int ROWS = U * NQ;
@@ -430,7 +546,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
         const bool valid = d < D;
         // plain build: one divergent region per task (only the last chunk is partial).  FUSE: every lane runs
         // (idle lanes shadow the last cell) because the wave reductions need the full wave; their stores are masked.
-        if (FUSE || (SOFT && prob) || valid) {   // (wave reductions need the whole wave: idle lanes shadow the last cell, masked)
+        if (FUSE || FINE || (SOFT && prob) || valid) {   // (wave reductions need the whole wave: idle lanes shadow the last cell, masked)
             const int dc = valid ? d : D - 1;
             const int dy = dc / p.wWin, dx = dc - dy * p.wWin;
             const px_t *lp = lds + dy * p.pitch + dx + tile * TX;
@@ -527,6 +643,9 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                             vrow[x] = t;
                         }
                     }
+                    if constexpr (FINE) {
+                        if (store_row) fine_epilogue<TX, FINE16>(vrow, lane, y, xt, p.Wo, *fine);
+                    } else
                     if (SOFT && prob && store_row) {   // (wave-uniform)
                         const char *prow = (const char *)(prob + ((long long)y * p.Wo + xt) * D);
 #pragma unroll
@@ -606,6 +725,11 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_multi_kernel(CvTiledMult
     const int z = gridDim.z - 1 - blockIdx.z;
     if ((int)blockIdx.x >= m.gx[z] || (int)blockIdx.y >= m.gy[z]) return;   // block-uniform
     ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, true>(m.I0[z], m.I1[z], m.out[z], m.p[z], CvFuseArgs{}, blockIdx.x, blockIdx.y, m.prob[z]);
+}
+
+template <int C, int K, int TX, int NT, int NW, int NQ, bool F16>
+__global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_fine_kernel(const float *__restrict__ I0, const float *__restrict__ I1, CvTiledArgs p, CvFineArgs fine) {
+    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, false, true, F16>(I0, I1, nullptr, p, CvFuseArgs{}, blockIdx.x, blockIdx.y, nullptr, &fine);
 }
 
 // geometry of one tiled launch
@@ -1773,6 +1897,40 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
 }
 
 // f16_scale != 0: out[i] are HALF volumes, out[i][..] = half(cost * f16_scale) (8 x 8 windows only: *handled = false otherwise)
+// the finest pyramid scale through the tiled kernel's fused epilogue (C = 3, k = 7, 8 x 8 windows); I0p / I1p: the padded scale-1 frames
+template <int NQ>
+static int launch_cv_fine(dfe_ctx *ctx, const float *I0p, const float *I1p, int Hp, int Wp, int maxh, int maxw, const CvFineArgs &fine, bool *handled) {
+    constexpr int K = 7, TX = 8, NT = 4, NW = 4;
+    const int Ho = Hp - K + 1 - maxh + 1, Wo = Wp - K + 1 - maxw + 1;
+    const CvTilePlan pl = plan_cv_tiled<3, K, TX, NT, NW>(NQ, Ho, Wo, maxh, maxw, ctx->ncu);
+    if (pl.score <= 0) return DFE_OK;
+    CvTiledArgs a;
+    a.plane = (long long)Hp * Wp;
+    a.H = Hp; a.W = Wp; a.hWin = maxh; a.wWin = maxw; a.Ho = Ho; a.Wo = Wo;
+    a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.seg_rows = 0; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
+    a.chunk0 = 0;
+    auto kern = fine.f16_scale != 0.f ? ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, true> : ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, false>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, dim3(dfe_cdiv(Wo, pl.GX), dfe_cdiv(Ho, pl.TY)), dim3(NW * 64), pl.lds_bytes, ctx->stream, I0p, I1p, a, fine);
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = fine.f16_scale != 0.f ? "ssd_cv_tiled_fine_kernel_f16" : "ssd_cv_tiled_fine_kernel";
+    *handled = true;
+    return DFE_OK;
+}
+int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int C, int Hp, int Wp, int k, int maxh, int maxw, const CvFineArgs &fine,
+                           bool *handled) {
+    *handled = false;
+    if (C != 3 || k != 7 || maxh != 8 || maxw != 8 || ctx->cv_mode == 1 || ctx->cv_mode == 3) return DFE_OK;
+    const int Ho = Hp - 7 + 1 - maxh + 1, Wo = Wp - 7 + 1 - maxw + 1;
+    if (fine.pcasc && ((Wo | Ho) & 1)) return DFE_OK;
+    const char *e = getenv("DFE_FINE_NQ");
+    if (e && atoi(e) == 5) return launch_cv_fine<5>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
+    return launch_cv_fine<4>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
+}
+
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
                              int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale) {
     *handled = false;

@@ -591,7 +591,7 @@ def test_one_call_multiscale_f16_equals_oracle_chain(dfe, cuda, ratios, mh, H, W
     ref = rp.multiscale_flow_oracle(f0, f1, 7, mh, mh, ratios, f16_scale=scale)
     gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, mh, mh, ratios, scale)
     if mh == 8 and C == 3 and H // ratios[-1] >= 18 and W // ratios[-1] >= 32:
-        assert kern == "ssd_cv_tiled_multi_kernel_f16"     # the volumes really were written and read as halves
+        assert kern in ("ssd_cv_tiled_multi_kernel_f16", "ssd_cv_tiled_fine_kernel_f16")     # the volumes really were written and read as halves
     if integer:
         # integer-valued frames: fp32 sums are exact in any order -> the half volumes are bit-identical to the oracle's
         _assert_matches_oracle(gi, gflow, ref, mh, mh, ratios)
@@ -611,6 +611,38 @@ def test_one_call_multiscale_f16_equals_oracle_chain(dfe, cuda, ratios, mh, H, W
     assert (gi32 == gi).mean() > 0.9
 
 
+@pytest.mark.parametrize("ratios,H,W", [
+    ([1], 64, 96),                       # no parent: the finest scale alone
+    ([1, 2], 96, 128),                   # the coarsest scale is the parent (a cascade launch of its own)
+    ([1, 2, 4], 96, 136),                # ragged last tile (136 = 17 x 8; 17 tiles = 4 blocks + 1)
+    ([1, 2, 4, 8, 16], 288, 512),
+    ([1, 2, 4, 8], 360, 648),            # frame narrower than a multiple of 32 pixels
+])
+@pytest.mark.parametrize("f16", [False, True])
+def test_fused_finest_scale_equals_volume_path_bitwise(dfe, cuda, monkeypatch, ratios, H, W, f16):
+    """The finest scale consumed inside its volume kernel (ssd_cv_tiled_fine_kernel: no scale-1 volume) == the volume written and read by
+    cascade_px_kernel<FINEST> (DFE_FINE_FUSE=0; the library picks by frame size, DFE_FINE_FUSE=1 forces the fused kernel), bit for bit: class indices and decoded flow, fp32 and fp16 volumes."""
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + len(ratios), max_flow=min(10, 2 * ratios[-1]), noise_sigma=2.0)
+    f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+    ctx = dfe.get_ctx(0)
+
+    def run():
+        if f16:
+            gi, gf, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
+        else:
+            gi, gf = _one_call(dfe, cuda, f0, f1, 7, 8, 8, ratios)
+            kern = ctx.last_kernel()
+        return gi, gf, kern
+
+    monkeypatch.setenv("DFE_FINE_FUSE", "1")
+    gi, gf, kern = run()
+    assert kern.startswith("ssd_cv_tiled_fine_kernel")
+    monkeypatch.setenv("DFE_FINE_FUSE", "0")
+    wi, wf, kern2 = run()
+    assert not kern2.startswith("ssd_cv_tiled_fine_kernel")
+    assert np.array_equal(gi, wi) and np.array_equal(gf, wf)
+
+
 def test_one_call_multiscale_f16_equals_staged_bitwise(dfe, cuda):
     """one-call fp16 (real half volumes through ssd_cv_tiled_multi_kernel + cascade_px_kernel<H16>) == the staged HIP path with its
     fp32 volumes rounded to half on the host side, bit for bit (same volume kernel arithmetic, same soft-min / cascade)."""
@@ -619,7 +651,7 @@ def test_one_call_multiscale_f16_equals_staged_bitwise(dfe, cuda):
     f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
     Hp, Wp = -(-H // 16) * 16, -(-W // 16) * 16
     gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
-    assert kern == "ssd_cv_tiled_multi_kernel_f16"
+    assert kern in ("ssd_cv_tiled_multi_kernel_f16", "ssd_cv_tiled_fine_kernel_f16")
     geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=Hp, wImg=Wp, output_extraction_method="max")
     staged = dfe.getModelMultiscale(geo).forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False, f16_scale=1.0)
     assert np.array_equal(staged["index"].cpu().numpy(), gi)
@@ -634,7 +666,7 @@ def test_4k_five_level_f16_pyramid_properties(dfe, cuda):
     f0, f1, flow, _ = rp.synth_pair(H, W, C=3, seed=4, max_flow=12, noise_sigma=0)
     f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
     gi, gflow, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
-    assert kern == "ssd_cv_tiled_multi_kernel_f16"
+    assert kern in ("ssd_cv_tiled_multi_kernel_f16", "ssd_cv_tiled_fine_kernel_f16")
     geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, hKernel=7, wKernel=7, hImg=H, wImg=W, output_extraction_method="max")
     staged = dfe.getModelMultiscale(geo).forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False, f16_scale=1.0)
     assert np.array_equal(staged["index"].cpu().numpy(), gi)
