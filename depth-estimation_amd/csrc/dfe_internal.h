@@ -95,7 +95,7 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 // prob (may be NULL): per pair, non-null = leave soft-min probabilities there instead of the costs in out[i] -- if the
 // launcher finds that worthwhile for the shape (*prob_used)
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale = 0.f);
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale = 0.f, int nq_hint = 0);
 // The finest scale of the multiscale matcher WITHOUT its volume (multiscale.hip -> ssd_cost_volume.hip): the tiled kernel's task rows
 // (8 pixels x the 64 cells of an 8 x 8 window, lane <-> cell) go through soft-min, cascade add, arg-max and decode in registers
 struct CvFineArgs {
@@ -106,9 +106,14 @@ struct CvFineArgs {
     int middle;                // centre class (yx2xMulti(0, 0)), 1-based
     float f16_scale, f16_inv;  // != 0: the costs are rounded to half precision (cost * scale) first, as a stored fp16 volume would be
     int dec[5 * 64];           // class id - 1 -> (oy << 16) | (ox & 0xffff)
+    // a scale > 1 (the same epilogue up to the cascade add, then what cascade_px_kernel<false> leaves for the next finer scale):
+    float *casc;               // != NULL: out [H][W][64] cascaded windows of THIS scale; idx / fy / fx unused
+    float2 *best;              //          out [H][W] running best (value, 0-based class as int bits)
+    int cls_base;              //          0-based class id of this scale's first ring cell
 };
 int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int C, int Hp, int Wp, int k, int maxh, int maxw, const CvFineArgs &fine,
                            bool *handled);
+bool cv_finest_plan_ok(dfe_ctx *ctx, int Hp, int Wp, int maxh, int maxw);   // cv_frames_finest_fused (with a parent scale) would take this frame
 int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
 // one layer of a filter stack (filters.hip): in [nIn][H][W] -> out [nOut][H-kH+1][W-kW+1], nn.Tanh fused behind it when
 // L.tanh_after (the same tanhf as dfe_tanh_f32: bit-identical to the two separate calls)

@@ -1064,12 +1064,36 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         mg.ratios[s] = r;
         mg.d[s] = g.d[s];
     }
+    const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
+    // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
+    bool px_path = fast && maxh == 8 && maxw == 8;
+    for (int s = 0; s < nratios; ++s)
+        if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
+    if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
+    // raw patches, 3 channels, 7 x 7, on the lane <-> pixel path: the finest scale is fused into its volume kernel (no volume)
+    // -- where it pays: the fused kernel is VALU-bound (three 64-lane reductions per pixel), the volume it saves is HBM traffic that the
+    // small frames hide behind the coarse scales' launches.  Measured, volume path -> fused: VGA 0.076 -> 0.099 ms, 720p 0.213 ->
+    // 0.185, 1080p 0.430 -> 0.366, 4K 1.94 -> 1.40; fp16 volumes (half the bytes to save): 1080p 0.344 -> 0.368, 4K 1.48 -> 1.32.
+    // DFE_FINE_FUSE=0 / 1 forces the choice.
+    bool try_fine = px_path && !filt && C == 3 && k == 7 && (long long)H * W >= (f16_scale != 0.f ? 3000000ll : 600000ll);
+    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && !filt && C == 3 && k == 7 && atoi(e) != 0;
+    // the second scale the same way (its volume, 21 % of the rest, is otherwise written by the volume kernel and read back by its
+    // cascade launch): wherever the finest scale is fused and a coarser scale exists above it.  DFE_MID_FUSE=0 / 1 forces the choice.
+    // Measured, finest scale fused -> both: 1080p 0.363 -> 0.346 ms, 4K 1.40 -> 1.29; 720p 0.179 -> 0.205 (230 k pixels: one partial round
+    // of blocks, latency-bound); fp16 volumes (half the bytes to save) 4K 1.315 -> 1.320.
+    bool try_mid = try_fine && f16_scale == 0.f && (long long)H * W >= 1500000ll && nratios >= 3 && cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw);
+    if (const char *e = getenv("DFE_MID_FUSE"))
+        try_mid = try_fine && atoi(e) != 0 && nratios >= 3 && cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw);
+    const int s0 = try_mid ? 2 : try_fine ? 1 : 0;      // the first scale whose volume is materialised
     if (!filt) {
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
         bool pow2 = nratios <= 5;
         for (int s = 0; s < nratios; ++s) pow2 = pow2 && (ratios[s] == 1 || ratios[s] == 2 || ratios[s] == 4 || ratios[s] == 8 || ratios[s] == 16);
         // (large frames only: at VGA the per-scale kernel's 8.8 us are all latency and the tile kernel's sequential r x r sums are
         //  slower -- 0.082 against 0.076 ms per pair; 1080p 0.451 -> 0.430 ms, 4K five levels 1.69 -> 1.48 ms)
+        // (tried: the finest scale's padded frames made on a second stream next to the coarse scales' chain, forked here and joined in
+        //  front of the fused kernel, which alone reads them -- 720p 0.178 -> 0.190 ms, 1080p 0.347 -> 0.348, 4K 1.27 -> 1.31: the
+        //  frames are read twice and the cross-stream waits cost more than the overlap gives)
         if (pow2 && (long long)H * W >= 1500000 && !getenv("DFE_NO_PREP_TILES")) {       // every scale from one read of the frames
             PrepTile pq;
             pq.ns = nratios;
@@ -1084,20 +1108,6 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     // stage "match": volumes, soft-min, cascade + fused arg-max (with learned filters it opens behind the per-scale filter / matching scopes)
     std::unique_ptr<DfeStageScope> match_rest;
     if (!filt) match_rest.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));
-    const bool fast = N <= 64 && nratios <= 5;   // one-cell-per-lane path of the cascade kernel
-    // lane <-> pixel path (cascade_px_kernel): 8 x 8 windows, ratios 1, 2, 4, ...; DFE_CASCADE_PX=0 keeps the lane <-> cell kernels
-    bool px_path = fast && maxh == 8 && maxw == 8;
-    for (int s = 0; s < nratios; ++s)
-        if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
-    if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
-    // raw patches, 3 channels, 7 x 7, on the lane <-> pixel path: the finest scale is fused into its volume kernel (no volume)
-    // -- where it pays: the fused kernel is VALU-bound (three 64-lane reductions per pixel), the volume it saves is HBM traffic that the
-    // small frames hide behind the coarse scales' launches.  Measured, volume path -> fused: VGA 0.076 -> 0.099 ms, 720p 0.213 ->
-    // 0.185, 1080p 0.430 -> 0.366, 4K 1.94 -> 1.40; fp16 volumes (half the bytes to save): 1080p 0.344 -> 0.368, 4K 1.48 -> 1.32.
-    // DFE_FINE_FUSE=0 / 1 forces the choice.
-    bool try_fine = px_path && !filt && C == 3 && k == 7 && (long long)H * W >= (f16_scale != 0.f ? 3000000ll : 600000ll);
-    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && !filt && C == 3 && k == 7 && atoi(e) != 0;
-    const int s0 = try_fine ? 1 : 0;
     if (filt) {
         // learned filters (getModelMultiscale's filter1 / filter2, opticalflow_model_multiscale.lua:196-211): frame 0 is cropped by
         // the search window BEFORE the filter (its zero padding shrinks by floor / ceil((maxh-1)/2)), both padded frames go
@@ -1168,6 +1178,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         float *vo[DFE_MAX_RATIOS], *pr[DFE_MAX_RATIOS];
         int vh[DFE_MAX_RATIOS], vw[DFE_MAX_RATIOS];
         const int nv = nratios - s0;
+        const int nq_hint = (try_fine && (long long)H * W < 4000000ll) ? 3 : 0;
         for (int s = s0; s < nratios; ++s) {
             f0[s - s0] = ps.p0[s]; f1[s - s0] = ps.p1[s]; vo[s - s0] = (float *)ss.cost[s]; vh[s - s0] = ps.Hp[s]; vw[s - s0] = ps.Wp[s];
             pr[s - s0] = (fast && s > 0 && !px_path) ? ss.prob[s] : nullptr;
@@ -1175,12 +1186,12 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         // fp16 volumes: written as halves by the volume kernel itself where the lane <-> pixel cascade will read them (8 x 8
         // windows, C = 3, k = 7); any other shape builds fp32 volumes and rounds them to half precision in place -- same values
         if (f16_scale != 0.f && px_path && nv >= 1) {
-            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, nullptr, &merged, &soft_done, f16_scale);
+            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, nullptr, &merged, &soft_done, f16_scale, nq_hint);
             if (rc) return rc;
             half_vol = merged;
         }
         if (!merged && nv >= 1) {
-            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, f16_scale != 0.f ? nullptr : pr, &merged, &soft_done);
+            rc = cv_frames_dispatch_multi(ctx, nv, f0, f1, C, vh, vw, k, maxh, maxw, vo, f16_scale != 0.f ? nullptr : pr, &merged, &soft_done, 0.f, nq_hint);
             if (rc) return rc;
         }
     }
@@ -1204,10 +1215,25 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         // coarse -> fine: one launch per scale, except that the coarsest scale is recomputed inside its child's launch
         const int top = nratios >= 2 ? nratios - 2 : 0;
         bool fine_done = false;
-        // with the fused finest scale and only two ratios the coarsest scale is the finest one's parent: it needs a launch of its own
-        const bool lone_parent = try_fine && nratios == 2;
-        for (int s = lone_parent ? 1 : top; s >= 0; --s) {
+        // where the coarsest scale is the parent of a fused scale it needs a launch of its own (it cannot be recomputed inside its child's)
+        const bool lone_parent = (try_mid && nratios == 3) || (try_fine && !try_mid && nratios == 2);
+        for (int s = lone_parent ? nratios - 1 : top; s >= 0; --s) {
             const int r = ratios[s];
+            if (s == 1 && try_mid) {
+                CvFineArgs mid{};
+                mid.pcasc = (const float *)((char *)scr + off_q[2]);
+                mid.pbest = (const float2 *)((char *)scr + off_b[2]);
+                mid.casc = (float *)((char *)scr + off_q[1]);
+                mid.best = (float2 *)((char *)scr + off_b[1]);
+                mid.cls_base = g.base[1];
+                mid.f16_scale = f16_scale;
+                mid.f16_inv = f16_scale != 0.f ? 1.0f / f16_scale : 0.f;
+                bool mid_done = false;
+                rc = cv_frames_finest_fused(ctx, ps.p0[1], ps.p1[1], C, ps.Hp[1], ps.Wp[1], k, maxh, maxw, mid, &mid_done);
+                if (rc) return rc;
+                DFE_REQUIRE(ctx, mid_done, DFE_E_UNSUPPORTED, "multiscale: no plan for the fused second scale (%d x %d) although cv_finest_plan_ok said so", ps.Hp[1], ps.Wp[1]);
+                continue;
+            }
             if (s == 0 && try_fine) {
                 CvFineArgs fine{};
                 if (nratios >= 2) {

@@ -223,7 +223,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.3"
+#define DFE_CV_KERNEL_REV "cv-r3.4"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -414,7 +414,11 @@ __device__ __forceinline__ int wave_reduce8_transposed(const float (&v)[8], int 
 //   Centre override (bv == centre value): the centre is one of the 64 cells, so centre <= fv; if the coarser chain's best wins
 //   (pbv > fv) it is larger than the centre, otherwise bv = fv and the test is "the centre cell attains the maximum" = its bit in
 //   the ballot the arg-max needs anyway.
-template <int TX, bool F16>
+//   MID (a scale > 1 with a coarser one above it, cascade_px_kernel<false>): the cascaded window is stored for the next finer scale, and
+//   the arg-max runs over the 48 ring cells in CLASS order (top two rows, left 4 x 2, right 4 x 2, bottom two rows): cells outside
+//   the ring take the most negative integer before the maximum; among the cells that attain it the class order is "first non-empty
+//   group, lowest cell in it" -- scalar arithmetic on the ballot.
+template <int TX, bool F16, bool MID>
 __device__ __forceinline__ void fine_epilogue(const float (&vrow)[TX], int lane, int y, int xt, int Wo, const CvFineArgs &fa) {
 #pragma clang fp contract(off)
     static_assert(TX == 8, "8 fine pixels = 4 parent pixels");
@@ -454,14 +458,41 @@ __device__ __forceinline__ void fine_epilogue(const float (&vrow)[TX], int lane,
             v[2 * j + 1] = v[2 * j + 1] + g;
         }
     }
+    if constexpr (MID) {
+        float *cq = fa.casc + ((long long)y * Wo + xt) * 64 + lane;
+        const bool ring = !(a >= 2 && a <= 5 && b >= 2 && b <= 5);
+#pragma unroll
+        for (int x = 0; x < TX; ++x) {
+            cq[x * 64] = v[x];
+            v[x] = ring ? v[x] : __int_as_float(0x80000000);
+        }
+    }
     const int fvp = wave_reduce8_transposed<2>(v, lane);
     const int mbit = (fa.middle - 1) & 63;
     unsigned long long codes = 0;                                           // byte x: pixel x's first maximal cell | centre-is-maximal << 6
 #pragma unroll
     for (int x = 0; x < TX; ++x) {
         const unsigned long long hit = __builtin_amdgcn_ballot_w64(__float_as_int(v[x]) == __builtin_amdgcn_readlane(fvp, 8 * x));
-        const unsigned long long code = (unsigned long long)__builtin_ctzll(hit) | (((hit >> mbit) & 1ull) << 6);
+        unsigned long long code;
+        if constexpr (MID) {                                                // (byte x: the class rank 0..47 of pixel x's first maximal ring cell)
+            const unsigned long long top = hit & 0xffffull, left = hit & 0x0000030303030000ull, right = hit & 0x0000c0c0c0c00000ull;
+            const int cell = __builtin_ctzll(top ? top : left ? left : right ? right : hit);
+            const int side = 16 + ((cell >> 3) - 2) * 2 + (cell & 7);      // left columns 0, 1 -> ranks 16..23; right columns 6, 7 -> 24..31
+            code = (unsigned long long)(cell < 16 ? cell : cell >= 48 ? cell - 16 : (cell & 7) < 2 ? side : side + 2);
+        } else {
+            code = (unsigned long long)__builtin_ctzll(hit) | (((hit >> mbit) & 1ull) << 6);
+        }
         codes |= code << (8 * x);
+    }
+    if constexpr (MID) {
+        if ((lane & 7) == 0) {
+            const int g = lane >> 3;
+            float bv = __int_as_float(fvp);
+            int bi = ((int)(codes >> (8 * g)) & 0xff) + fa.cls_base;
+            if (has_parent && !(bv >= pb.x)) { bv = pb.x; bi = __float_as_int(pb.y); }      // the scale wins ties against the coarser chain
+            fa.best[(long long)y * Wo + xt + g] = make_float2(bv, __int_as_float(bi));
+        }
+        return;
     }
     if ((lane & 7) == 0) {
         const int g = lane >> 3;
@@ -499,7 +530,7 @@ template <int K> struct VUnroll { static constexpr int value = (K == 7) ? 6 : K;
 // p = e / sum(e), e = expf(-c - max(-c)) over the cells of a pixel = the lanes of the wave, with the arithmetic of
 // softmin_kernel (multiscale.hip), so the result is bit-identical to running that kernel on the stored volume.
 // FINE (8 x 8 windows, the finest scale of the multiscale matcher): nothing is stored; a task row goes through fine_epilogue below
-template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE, bool SOFT = false, bool FINE = false, bool FINE16 = false>
+template <int C, int K, int TX, int NT, int NW, int NQ, bool FUSE, bool SOFT = false, bool FINE = false, bool FINE16 = false, bool MID = false>
 __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, const float *__restrict__ I1, float *__restrict__ out,
                                                   const CvTiledArgs &p, const CvFuseArgs &fa, int bx, int by, float *__restrict__ prob = nullptr,
                                                   const CvFineArgs *fine = nullptr) {
@@ -644,7 +675,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                         }
                     }
                     if constexpr (FINE) {
-                        if (store_row) fine_epilogue<TX, FINE16>(vrow, lane, y, xt, p.Wo, *fine);
+                        if (store_row) fine_epilogue<TX, FINE16, MID>(vrow, lane, y, xt, p.Wo, *fine);
                     } else
                     if (SOFT && prob && store_row) {   // (wave-uniform)
                         const char *prow = (const char *)(prob + ((long long)y * p.Wo + xt) * D);
@@ -727,9 +758,9 @@ __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_multi_kernel(CvTiledMult
     ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, true>(m.I0[z], m.I1[z], m.out[z], m.p[z], CvFuseArgs{}, blockIdx.x, blockIdx.y, m.prob[z]);
 }
 
-template <int C, int K, int TX, int NT, int NW, int NQ, bool F16>
+template <int C, int K, int TX, int NT, int NW, int NQ, bool F16, bool MID>
 __global__ __launch_bounds__(NW * 64) void ssd_cv_tiled_fine_kernel(const float *__restrict__ I0, const float *__restrict__ I1, CvTiledArgs p, CvFineArgs fine) {
-    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, false, true, F16>(I0, I1, nullptr, p, CvFuseArgs{}, blockIdx.x, blockIdx.y, nullptr, &fine);
+    ssd_cv_tiled_body<C, K, TX, NT, NW, NQ, false, false, true, F16, MID>(I0, I1, nullptr, p, CvFuseArgs{}, blockIdx.x, blockIdx.y, nullptr, &fine);
 }
 
 // geometry of one tiled launch
@@ -1909,16 +1940,24 @@ static int launch_cv_fine(dfe_ctx *ctx, const float *I0p, const float *I1p, int 
     a.H = Hp; a.W = Wp; a.hWin = maxh; a.wWin = maxw; a.Ho = Ho; a.Wo = Wo;
     a.lrows = pl.lrows; a.lcols = pl.lcols; a.pitch = pl.pitch; a.seg_rows = 0; a.tile0_off = 0; a.stage_off = 0; a.stage_len = 0;
     a.chunk0 = 0;
-    auto kern = fine.f16_scale != 0.f ? ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, true> : ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, false>;
+    const bool h16 = fine.f16_scale != 0.f;
+    auto kern = fine.casc ? (h16 ? ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, true, true> : ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, false, true>)
+                          : (h16 ? ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, true, false> : ssd_cv_tiled_fine_kernel<3, K, TX, NT, NW, NQ, false, false>);
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, dim3(dfe_cdiv(Wo, pl.GX), dfe_cdiv(Ho, pl.TY)), dim3(NW * 64), pl.lds_bytes, ctx->stream, I0p, I1p, a, fine);
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = fine.f16_scale != 0.f ? "ssd_cv_tiled_fine_kernel_f16" : "ssd_cv_tiled_fine_kernel";
+    ctx->last_kernel = fine.casc ? (h16 ? "ssd_cv_tiled_mid_kernel_f16" : "ssd_cv_tiled_mid_kernel") : h16 ? "ssd_cv_tiled_fine_kernel_f16" : "ssd_cv_tiled_fine_kernel";
     *handled = true;
     return DFE_OK;
+}
+bool cv_finest_plan_ok(dfe_ctx *ctx, int Hp, int Wp, int maxh, int maxw) {
+    if (maxh != 8 || maxw != 8 || ctx->cv_mode == 1 || ctx->cv_mode == 3) return false;
+    const int Ho = Hp - 7 + 1 - maxh + 1, Wo = Wp - 7 + 1 - maxw + 1;
+    if ((Wo | Ho) & 1) return false;
+    return plan_cv_tiled<3, 7, 8, 4, 4>(4, Ho, Wo, maxh, maxw, ctx->ncu).score > 0;
 }
 int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int C, int Hp, int Wp, int k, int maxh, int maxw, const CvFineArgs &fine,
                            bool *handled) {
@@ -1926,19 +1965,21 @@ int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int
     if (C != 3 || k != 7 || maxh != 8 || maxw != 8 || ctx->cv_mode == 1 || ctx->cv_mode == 3) return DFE_OK;
     const int Ho = Hp - 7 + 1 - maxh + 1, Wo = Wp - 7 + 1 - maxw + 1;
     if (fine.pcasc && ((Wo | Ho) & 1)) return DFE_OK;
-    const char *e = getenv("DFE_FINE_NQ");
+    const char *e = getenv(fine.casc ? "DFE_MID_NQ" : "DFE_FINE_NQ");
     if (e && atoi(e) == 5) return launch_cv_fine<5>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
     return launch_cv_fine<4>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
 }
 
 int cv_frames_dispatch_multi(dfe_ctx *ctx, int n, const float *const *I0, const float *const *I1, int C, const int *H, const int *W, int k,
-                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale) {
+                             int hWin, int wWin, float *const *out, float *const *prob, bool *handled, bool *prob_used, float f16_scale, int nq_hint) {
     *handled = false;
     if (prob_used) *prob_used = false;
     if (ctx->cv_mode == 1 || ctx->cv_mode == 3 || C != 3 || k != 7 || hWin * wWin > 64 || n < 2 || n > DFE_MAX_RATIOS) return DFE_OK;
     // 4 row groups (18-row tiles) unless forced: measured at VGA, 3 scales, 2 / 3 / 4 / 5 groups -> 0.161 / 0.159 / 0.151 /
     // 0.155 ms per pair (short tiles pay the K-1 warm-up rows too often, tall ones leave the coarse scales too few blocks)
-    const int nq = (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5) ? ctx->cv_tyq : 4;
+    // nq_hint: the caller's choice for a launch without the finest scale (the fused pyramid: 3 groups, measured 720p 0.184 -> 0.179,
+    // 1080p 0.369 -> 0.363 ms; 4K prefers 4)
+    const int nq = (ctx->cv_tyq >= 2 && ctx->cv_tyq <= 5) ? ctx->cv_tyq : (nq_hint >= 2 && nq_hint <= 5) ? nq_hint : 4;
     switch (nq) {
         case 2: return launch_cv_tiled_multi_one<2>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);
         case 5: return launch_cv_tiled_multi_one<5>(ctx, n, I0, I1, H, W, hWin, wWin, out, prob, handled, prob_used, f16_scale);

@@ -617,6 +617,7 @@ def test_one_call_multiscale_f16_equals_oracle_chain(dfe, cuda, ratios, mh, H, W
     ([1, 2, 4], 96, 136),                # ragged last tile (136 = 17 x 8; 17 tiles = 4 blocks + 1)
     ([1, 2, 4, 8, 16], 288, 512),
     ([1, 2, 4, 8], 360, 648),            # frame narrower than a multiple of 32 pixels
+    ([1, 2, 4], 136, 200),               # second scale 68 x 100: ragged tiles in both directions
 ])
 @pytest.mark.parametrize("f16", [False, True])
 def test_fused_finest_scale_equals_volume_path_bitwise(dfe, cuda, monkeypatch, ratios, H, W, f16):
@@ -635,12 +636,19 @@ def test_fused_finest_scale_equals_volume_path_bitwise(dfe, cuda, monkeypatch, r
         return gi, gf, kern
 
     monkeypatch.setenv("DFE_FINE_FUSE", "1")
-    gi, gf, kern = run()
+    monkeypatch.setenv("DFE_MID_FUSE", "1")
+    gi, gf, kern = run()                                    # finest scale fused, and the second one too where there are >= 3 ratios
     assert kern.startswith("ssd_cv_tiled_fine_kernel")
     monkeypatch.setenv("DFE_FINE_FUSE", "0")
     wi, wf, kern2 = run()
     assert not kern2.startswith("ssd_cv_tiled_fine_kernel")
     assert np.array_equal(gi, wi) and np.array_equal(gf, wf)
+    if len(ratios) >= 3:
+        monkeypatch.setenv("DFE_FINE_FUSE", "1")
+        monkeypatch.setenv("DFE_MID_FUSE", "0")             # the second scale through its volume and cascade_px_kernel<false>
+        mi, mf, kern3 = run()
+        assert kern3.startswith("ssd_cv_tiled_fine_kernel")
+        assert np.array_equal(mi, wi) and np.array_equal(mf, wf)
 
 
 def test_one_call_multiscale_f16_equals_staged_bitwise(dfe, cuda):
