@@ -100,6 +100,8 @@ struct ConvBatch {
     float *out[2 * DFE_MAX_RATIOS];
     const float *w[2 * DFE_MAX_RATIOS], *bias[2 * DFE_MAX_RATIOS];
     int H[2 * DFE_MAX_RATIOS], W[2 * DFE_MAX_RATIOS];
+    int blk0[2 * DFE_MAX_RATIOS + 1];   // first block of entry e (tiles x output groups each): the grid holds no idle blocks
+    int n;
 };
 constexpr int CB_TW = 128, CB_TH = 8, CB_PX = 4;
 extern __shared__ __attribute__((aligned(16))) float conv_smem[];
@@ -108,47 +110,60 @@ template <int KW, int NT, bool TANH>
 __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, int nOut, int kH, int groups) {
 #pragma clang fp contract(off)
     constexpr int PITCH = CB_TW + 8;                       // (KW - 1 <= 8 halo columns; rows stay 16-B aligned)
-    const int ent = blockIdx.y / groups, grp = blockIdx.y - ent * groups;
+    int ent = 0;
+    while (ent + 1 < cb.n && (int)blockIdx.x >= cb.blk0[ent + 1]) ++ent;       // (block-uniform; at most 10 entries)
     const int H = cb.H[ent], W = cb.W[ent];
     const int Ho = H - kH + 1, Wo = W - KW + 1;
     const int tilesx = (Wo + CB_TW - 1) / CB_TW;
-    const int by = blockIdx.x / tilesx, bx = blockIdx.x - by * tilesx;
-    if (by * CB_TH >= Ho) return;                         // (entries of different sizes share one grid: block-uniform)
+    const int rel = blockIdx.x - cb.blk0[ent], grp = rel % groups, tile = rel / groups;   // (the groups of a tile next to each other: they stage the same input)
+    const int by = tile / tilesx, bx = tile - by * tilesx;
     const int x0 = bx * CB_TW, y0 = by * CB_TH;
     const int trows = CB_TH + kH - 1;
     const float *__restrict__ in = cb.in[ent];
-    // stage: every input plane's tile (zero beyond the frame: those values only feed outputs that are not stored)
+    // stage: every input plane's tile (clamped at the frame edge: those values only feed outputs that are not stored).  A wave takes
+    // whole tile rows (row = wave, wave + 4, ...: the plane / row split is scalar arithmetic), its lanes the row's 136 columns in three
+    // passes, and all of a wave's loads for two rows are in flight before the first LDS write.  (The first version dealt single
+    // elements to threads: two integer divisions per element cost as many instructions as the convolution itself.)
     {
-        // (all of a thread's loads in flight before the first LDS write: NB independent loads per round instead of a load -> wait ->
-        //  write chain per element; rows of 136 = 34 float4-wide groups would also do, but the frame rows are only 4-B aligned)
-        constexpr int NB = 8;
-        const int total = nIn * trows * PITCH;
-        for (int e0 = 0; e0 < total; e0 += 256 * NB) {
-            float v[NB];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int nrows = nIn * trows;
+        const int c0 = min(x0 + lane, W - 1), c1 = min(x0 + lane + 64, W - 1), c2 = min(x0 + min(lane + 128, PITCH - 1), W - 1);
+        for (int rr = wv; rr < nrows; rr += 8) {
+            float v[2][3];
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = min(e0 + j * 256 + (int)threadIdx.x, total - 1);
-                const int c = e % PITCH, t = e / PITCH;
-                const int r = t % trows, i = t / trows;
-                const int yy = min(y0 + r, H - 1), xx = min(x0 + c, W - 1);        // (clamped: those values only feed outputs that are not stored)
-                v[j] = in[((long long)i * H + yy) * W + xx];
+            for (int j = 0; j < 2; ++j) {
+                const int r2 = min(rr + 4 * j, nrows - 1);
+                const int i = r2 / trows, r = r2 - i * trows;
+                const float *src = in + ((long long)i * H + min(y0 + r, H - 1)) * W;
+                v[j][0] = src[c0]; v[j][1] = src[c1]; v[j][2] = src[c2];
             }
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int e = e0 + j * 256 + (int)threadIdx.x;
-                if (e < total) conv_smem[e] = v[j];
+            for (int j = 0; j < 2; ++j) {
+                const int r2 = rr + 4 * j;
+                if (r2 < nrows) {
+                    float *dst = conv_smem + r2 * PITCH;
+                    dst[lane] = v[j][0]; dst[lane + 64] = v[j][1];
+                    if (lane + 128 < PITCH) dst[lane + 128] = v[j][2];
+                }
             }
         }
     }
     __syncthreads();
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int o0 = grp * NT;
-    float acc[NT][CB_PX];
+    // Two pixels per instruction: the multiply and the add of a tap are v_pk_mul_f32 / v_pk_add_f32 on pixel pairs (the weight is an
+    // SGPR pair with op_sel broadcasting its low half) -- each element rounded exactly as the scalar multiply and add are, in the same
+    // order, so the results do not change; the odd taps' pixel pairs (v[k], v[k+1] with k odd: not an aligned register pair) are
+    // copies made once per input row and shared by every output plane.  The scalar form issued every operation on the VALU's slow
+    // path (SGPR operand: 0.9 per cycle and CU); this one issues half as many.
+    static_assert(CB_PX == 4, "two pixel pairs per thread");
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[NT][2];
 #pragma unroll
     for (int o = 0; o < NT; ++o) {
         const float b = cb.bias[ent] ? cb.bias[ent][o0 + o] : 0.f;
-#pragma unroll
-        for (int q = 0; q < CB_PX; ++q) acc[o][q] = b;
+        acc[o][0] = f2{b, b};
+        acc[o][1] = f2{b, b};
     }
     const float *__restrict__ w = cb.w[ent];
     for (int i = 0; i < nIn; ++i)
@@ -156,6 +171,9 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
             const float4 *row = reinterpret_cast<const float4 *>(conv_smem + (i * trows + ty + u) * PITCH + CB_PX * tx);
             const float4 t0 = row[0], t1 = row[1], t2 = row[2];
             const float v[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+            f2 pr[KW][2];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) { pr[k][0] = f2{v[k], v[k + 1]}; pr[k][1] = f2{v[k + 2], v[k + 3]}; }
 #pragma unroll
             for (int o = 0; o < NT; ++o) {
                 typedef const float __attribute__((address_space(4))) *cfp;               // constant address space: the backend selects SMEM
@@ -163,8 +181,9 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
 #pragma unroll
                 for (int k = 0; k < KW; ++k) {
                     const float wk = wr[k];
-#pragma unroll
-                    for (int q = 0; q < CB_PX; ++q) acc[o][q] = acc[o][q] + wk * v[q + k];
+                    const f2 w2 = f2{wk, wk};
+                    acc[o][0] = acc[o][0] + w2 * pr[k][0];
+                    acc[o][1] = acc[o][1] + w2 * pr[k][1];
                 }
             }
         }
@@ -176,7 +195,8 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
 #pragma unroll
             for (int q = 0; q < CB_PX; ++q) {
                 const int x = x0 + CB_PX * tx + q;
-                if (x < Wo) out[((long long)(o0 + o) * Ho + y) * Wo + x] = TANH ? tanhf(acc[o][q]) : acc[o][q];
+                const float a = acc[o][q >> 1][q & 1];
+                if (x < Wo) out[((long long)(o0 + o) * Ho + y) * Wo + x] = TANH ? tanhf(a) : a;
             }
     }
 }
@@ -188,7 +208,12 @@ static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn,
     if (lds > 64 * 1024) return false;
     auto kern = tanh_after ? conv_batch_kernel<KW, NT, true> : conv_batch_kernel<KW, NT, false>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-    hipLaunchKernelGGL(kern, dim3(maxblocks, n * groups), dim3(256), lds, ctx->stream, cb, nIn, nOut, kH, groups);
+    ConvBatch c2 = cb;
+    c2.n = n;
+    c2.blk0[0] = 0;
+    for (int e = 0; e < n; ++e) c2.blk0[e + 1] = c2.blk0[e] + dfe_cdiv(cb.W[e] - KW + 1, CB_TW) * dfe_cdiv(cb.H[e] - kH + 1, CB_TH) * groups;
+    (void)maxblocks;
+    hipLaunchKernelGGL(kern, dim3(c2.blk0[n]), dim3(256), lds, ctx->stream, c2, nIn, nOut, kH, groups);
     return true;
 }
 

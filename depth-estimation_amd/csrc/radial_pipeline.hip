@@ -180,30 +180,39 @@ __global__ __launch_bounds__(256) void conv_cols_kernel(const float *__restrict_
     const int Ho = H - KH + 1;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * RY;
     if (x >= W) return;
-    float acc[RY][NOUT];
+    // two output rows per instruction (v_pk_mul_f32 / v_pk_add_f32 on row pairs, the weight an SGPR pair with its low half broadcast):
+    // every element is rounded as the scalar multiply and add are, in the same order -- same results, half the VALU issues
+    static_assert(RY % 2 == 0, "row pairs");
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 acc[RY / 2][NOUT];
 #pragma unroll
-    for (int r = 0; r < RY; ++r)
+    for (int r = 0; r < RY / 2; ++r)
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) acc[r][o] = bias ? bias[o] : 0.f;
+        for (int o = 0; o < NOUT; ++o) { const float b = bias ? bias[o] : 0.f; acc[r][o] = f2{b, b}; }
     for (int i = 0; i < nIn; ++i) {
         float col[RY + KH - 1];
 #pragma unroll
         for (int s = 0; s < RY + KH - 1; ++s) col[s] = in[((long long)i * H + min(y0 + s, H - 1)) * W + x];
+        f2 pr[RY + KH - 2];                       // (col[s], col[s + 1]): the odd ones are register copies, shared by every output plane
+#pragma unroll
+        for (int s = 0; s < RY + KH - 2; ++s) pr[s] = f2{col[s], col[s + 1]};
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
             float wv[KH];
             load_uniform<KH>(w + ((long long)o * nIn + i) * KH, wv);
 #pragma unroll
-            for (int u = 0; u < KH; ++u)
+            for (int u = 0; u < KH; ++u) {
+                const f2 w2 = f2{wv[u], wv[u]};
 #pragma unroll
-                for (int r = 0; r < RY; ++r) acc[r][o] = acc[r][o] + wv[u] * col[r + u];
+                for (int r = 0; r < RY / 2; ++r) acc[r][o] = acc[r][o] + w2 * pr[2 * r + u];
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < RY; ++r)
         if (y0 + r < Ho)
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) out[((long long)o * Ho + y0 + r) * W + x] = acc[r][o];
+            for (int o = 0; o < NOUT; ++o) out[((long long)o * Ho + y0 + r) * W + x] = acc[r >> 1][o][r & 1];
 }
 
 // A1r + arg-min.  in1 [K][H1p >= H1][W] (only the first H1 rows of a plane are used: the cropped previous frame), in2 [K][H1+HW-1][W]; vol [H1][W][HW] (may be NULL), flow [H1][W] = first-min index (0-based)
