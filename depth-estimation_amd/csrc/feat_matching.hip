@@ -183,7 +183,11 @@ struct FmBatch {
     int H1[DFE_MAX_RATIOS], W1[DFE_MAX_RATIOS];
 };
 constexpr int F64_TY = 16;
-__global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, int K, int maxh, int maxw, int pitch, float f16_scale, int nt) {
+// MODE 0: the volume is stored.  MODE 1 / 2 (8 x 8 windows, one pair): the task rows -- 8 pixels x 64 cells, lane <-> cell, exactly the
+// tiled SSD kernel's -- go through fine_epilogue (dfe_internal.h) instead: the finest pyramid scale (1) or a scale between (2) without
+// its volume, as in ssd_cv_tiled_fine_kernel.  F16: the costs are rounded as the stored fp16 volume would hold them.
+template <int MODE, bool F16>
+__device__ __forceinline__ void feat_matching_win64_body(const FmBatch &fb, int K, int maxh, int maxw, int pitch, float f16_scale, int nt, const CvFineArgs *fine) {
 #pragma clang fp contract(off)
     const int z = gridDim.z - 1 - blockIdx.z;              // (the smallest pair first: its few blocks must not form the tail)
     const int H1 = fb.H1[z], W1 = fb.W1[z];
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, in
 #pragma unroll
         for (int t = 0; t < 2; ++t) { a[t][0] = an[t][0]; a[t][1] = an[t][1]; }
     }
+    if constexpr (MODE != 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fine_epilogue<FM_TX, F16, MODE == 2>(acc[t], lane, y0 + wave + 8 * t, x0, W1, *fine);
+        return;
+    }
     // copy-out through the wave's own 2-KB scratch (the tile is no longer read by THIS wave; other waves' rows are elsewhere)
     __syncthreads();                                       // every wave is done with the tile: its space is the scratch now
     float *xp = fm_smem + wave * (FM_TX * 64);
@@ -296,21 +305,31 @@ __global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, in
         }
     }
 }
+__global__ __launch_bounds__(512) void feat_matching_win64_kernel(FmBatch fb, int K, int maxh, int maxw, int pitch, float f16_scale, int nt) {
+    feat_matching_win64_body<0, false>(fb, K, maxh, maxw, pitch, f16_scale, nt, nullptr);
+}
+template <int MODE, bool F16>
+__global__ __launch_bounds__(512) void feat_matching_win64_fine_kernel(FmBatch fb, int K, int pitch, CvFineArgs fine) {
+    feat_matching_win64_body<MODE, F16>(fb, K, 8, 8, pitch, 0.f, 0, &fine);
+}
 
 }  // namespace
 
 // n pairs (pyramid scales) of K-plane features through one launch of the one-chunk matcher; out[i] [H1][W1][64] f32, or half volumes
 // (half(cost * f16_scale)) when f16_scale != 0.  *handled = false: not this kernel's shape (the caller launches pair by pair).
+// fine != NULL (n == 1, 8 x 8 windows): no volume -- the pair's task rows go through the fused pyramid epilogue (fine->casc == NULL: the
+// finest scale; else a scale between), fine->f16_scale as in cv_frames_finest_fused; out is not used.
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
-                                  int maxw, float *const *out, float f16_scale, bool *handled) {
+                                  int maxw, float *const *out, float f16_scale, bool *handled, const CvFineArgs *fine) {
     *handled = false;
     if (maxh * maxw != 64 || K < 1 || K > 16 || n < 1 || n > DFE_MAX_RATIOS || ctx->cv_mode == 1 || getenv("DFE_NO_FM64")) return DFE_OK;
+    if (fine && (n != 1 || maxh != 8 || maxw != 8 || (fine->pcasc && ((H1[0] | W1[0]) & 1)))) return DFE_OK;
     FmBatch fb;
     int gx = 0, gy = 0;
     size_t vol = 0;
     for (int i = 0; i < n; ++i) {
-        if (H1[i] < F64_TY || W1[i] < FM_TX || ((uintptr_t)in1[i] & 3) || ((uintptr_t)out[i] & 15)) return DFE_OK;
-        fb.in1[i] = in1[i]; fb.in2[i] = in2[i]; fb.out[i] = out[i]; fb.H1[i] = H1[i]; fb.W1[i] = W1[i];
+        if (H1[i] < F64_TY || W1[i] < FM_TX || ((uintptr_t)in1[i] & 3) || (!fine && ((uintptr_t)out[i] & 15))) return DFE_OK;
+        fb.in1[i] = in1[i]; fb.in2[i] = in2[i]; fb.out[i] = fine ? nullptr : out[i]; fb.H1[i] = H1[i]; fb.W1[i] = W1[i];
         gx = gx > dfe_cdiv(W1[i], FM_TX) ? gx : dfe_cdiv(W1[i], FM_TX);
         gy = gy > dfe_cdiv(H1[i], F64_TY) ? gy : dfe_cdiv(H1[i], F64_TY);
         vol += (size_t)H1[i] * W1[i] * 64 * (f16_scale != 0.f ? 2 : 4);
@@ -322,6 +341,20 @@ int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, 
     size_t lds = (size_t)K * trows * pitch * sizeof(float);
     if (lds < (size_t)8 * FM_TX * 64 * sizeof(float)) lds = (size_t)8 * FM_TX * 64 * sizeof(float);   // the copy-out scratch reuses the tile
     if (lds > 64 * 1024) return DFE_OK;
+    if (fine) {
+        const bool h16 = fine->f16_scale != 0.f, mid = fine->casc != nullptr;
+        auto kern = mid ? (h16 ? feat_matching_win64_fine_kernel<2, true> : feat_matching_win64_fine_kernel<2, false>)
+                        : (h16 ? feat_matching_win64_fine_kernel<1, true> : feat_matching_win64_fine_kernel<1, false>);
+        DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            DfeProfScope prof(ctx);
+            hipLaunchKernelGGL(kern, dim3(gx, gy, 1), dim3(512), lds, ctx->stream, fb, K, pitch, *fine);
+        }
+        DFE_LAUNCH_CHECK(ctx);
+        ctx->last_kernel = mid ? (h16 ? "feat_matching_win64_mid_kernel_f16" : "feat_matching_win64_mid_kernel") : h16 ? "feat_matching_win64_fine_kernel_f16" : "feat_matching_win64_fine_kernel";
+        *handled = true;
+        return DFE_OK;
+    }
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)feat_matching_win64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nt = vol > ((size_t)160 << 20);              // (volumes that do not stay in the memory-side cache: non-temporal stores)
     {

@@ -1075,15 +1075,26 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     // small frames hide behind the coarse scales' launches.  Measured, volume path -> fused: VGA 0.076 -> 0.099 ms, 720p 0.213 ->
     // 0.185, 1080p 0.430 -> 0.366, 4K 1.94 -> 1.40; fp16 volumes (half the bytes to save): 1080p 0.344 -> 0.368, 4K 1.48 -> 1.32.
     // DFE_FINE_FUSE=0 / 1 forces the choice.
-    bool try_fine = px_path && !filt && C == 3 && k == 7 && (long long)H * W >= (f16_scale != 0.f ? 3000000ll : 600000ll);
-    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && !filt && C == 3 && k == 7 && atoi(e) != 0;
+    // Learned filters: the same epilogue behind the one-chunk feature matcher (feat_matching_win64_fine_kernel), where every scale's
+    // stack ends in the same number of planes (<= 16).
+    int fK = 0;
+    bool fine_shape = C == 3 && k == 7;
+    if (filt) {
+        fK = filt->layers[filt->nlayers - 1].nOut;
+        fine_shape = fK >= 1 && fK <= 16;
+        for (int s = 1; s < nratios && !filt->share; ++s) fine_shape = fine_shape && filt->layers[s * filt->nlayers + filt->nlayers - 1].nOut == fK;
+    }
+    // (learned filters, volume path -> fused: VGA 0.193 -> 0.183 ms, 1080p 1.064 -> 0.912: the matcher's launch is long enough at VGA already)
+    bool try_fine = px_path && fine_shape && (long long)H * W >= (filt ? 250000ll : f16_scale != 0.f ? 3000000ll : 600000ll);
+    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && fine_shape && atoi(e) != 0;
     // the second scale the same way (its volume, 21 % of the rest, is otherwise written by the volume kernel and read back by its
     // cascade launch): wherever the finest scale is fused and a coarser scale exists above it.  DFE_MID_FUSE=0 / 1 forces the choice.
     // Measured, finest scale fused -> both: 1080p 0.363 -> 0.346 ms, 4K 1.40 -> 1.29; 720p 0.179 -> 0.205 (230 k pixels: one partial round
     // of blocks, latency-bound); fp16 volumes (half the bytes to save) 4K 1.315 -> 1.320.
-    bool try_mid = try_fine && f16_scale == 0.f && (long long)H * W >= 1500000ll && nratios >= 3 && cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw);
-    if (const char *e = getenv("DFE_MID_FUSE"))
-        try_mid = try_fine && atoi(e) != 0 && nratios >= 3 && cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw);
+    const bool mid_shape = nratios >= 3 && (filt ? (H / ratios[1] >= 16 && W / ratios[1] >= 8 && ((H / ratios[1]) | (W / ratios[1])) % 2 == 0)
+                                                 : cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw));
+    bool try_mid = try_fine && f16_scale == 0.f && (long long)H * W >= 1500000ll && mid_shape;
+    if (const char *e = getenv("DFE_MID_FUSE")) try_mid = try_fine && atoi(e) != 0 && mid_shape;
     const int s0 = try_mid ? 2 : try_fine ? 1 : 0;      // the first scale whose volume is materialised
     if (!filt) {
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
@@ -1105,6 +1116,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         DFE_LAUNCH_CHECK(ctx);
     }
     bool merged = false, soft_done = false, half_vol = false;
+    const float *feat0[2] = {nullptr, nullptr}, *feat1[2] = {nullptr, nullptr};      // learned filters: the two finest scales' feature planes (frame 0, frame 1)
     // stage "match": volumes, soft-min, cascade + fused arg-max (with learned filters it opens behind the per-scale filter / matching scopes)
     std::unique_ptr<DfeStageScope> match_rest;
     if (!filt) match_rest.reset(new DfeStageScope(ctx, DFE_STAGE_MATCH));
@@ -1156,13 +1168,15 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
             float *mo[DFE_MAX_RATIOS];
             int mh[DFE_MAX_RATIOS], mw[DFE_MAX_RATIOS];
             for (int s = 0; s < nratios; ++s) { m1[s] = cur[2 * s]; m2[s] = cur[2 * s + 1]; mo[s] = (float *)ss.cost[s]; mh[s] = H / ratios[s]; mw[s] = W / ratios[s]; }
-            bool done = false;
-            if (same_k) {
-                rc = dfe_feat_matching_win64_batch(ctx, nratios, m1, m2, K, mh, mw, maxh, maxw, mo, (f16_scale != 0.f && px_path) ? f16_scale : 0.f, &done);
+            feat0[0] = m1[0]; feat0[1] = m2[0];
+            if (nratios > 1) { feat1[0] = m1[1]; feat1[1] = m2[1]; }
+            bool done = nratios - s0 < 1;       // (s0 = 1: the finest scale's matcher runs last, with the fused epilogue -- below)
+            if (same_k && !done) {
+                rc = dfe_feat_matching_win64_batch(ctx, nratios - s0, m1 + s0, m2 + s0, K, mh + s0, mw + s0, maxh, maxw, mo + s0, (f16_scale != 0.f && px_path) ? f16_scale : 0.f, &done);
                 if (rc) return rc;
                 half_vol = done && f16_scale != 0.f && px_path;
             }
-            for (int s = 0; s < nratios && !done; ++s) {
+            for (int s = s0; s < nratios && !done; ++s) {
                 const dfe_filter_layer *Ls = filt->layers + (filt->share ? 0 : s) * filt->nlayers;
                 rc = dfe_spatial_matching_dispatch(ctx, m1[s], m2[s], Ls[filt->nlayers - 1].nOut, mh[s], mw[s], maxh, maxw, mo[s]);
                 if (rc) return rc;
@@ -1229,7 +1243,13 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
                 mid.f16_scale = f16_scale;
                 mid.f16_inv = f16_scale != 0.f ? 1.0f / f16_scale : 0.f;
                 bool mid_done = false;
-                rc = cv_frames_finest_fused(ctx, ps.p0[1], ps.p1[1], C, ps.Hp[1], ps.Wp[1], k, maxh, maxw, mid, &mid_done);
+                if (filt) {
+                    float *none = nullptr;
+                    const int h1 = H / ratios[1], w1 = W / ratios[1];
+                    rc = dfe_feat_matching_win64_batch(ctx, 1, &feat1[0], &feat1[1], fK, &h1, &w1, maxh, maxw, &none, 0.f, &mid_done, &mid);
+                } else {
+                    rc = cv_frames_finest_fused(ctx, ps.p0[1], ps.p1[1], C, ps.Hp[1], ps.Wp[1], k, maxh, maxw, mid, &mid_done);
+                }
                 if (rc) return rc;
                 DFE_REQUIRE(ctx, mid_done, DFE_E_UNSUPPORTED, "multiscale: no plan for the fused second scale (%d x %d) although cv_finest_plan_ok said so", ps.Hp[1], ps.Wp[1]);
                 continue;
@@ -1247,11 +1267,17 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
                 fine.f16_scale = f16_scale;
                 fine.f16_inv = f16_scale != 0.f ? 1.0f / f16_scale : 0.f;
                 for (int c = 0; c < 5 * 64; ++c) fine.dec[c] = c < g.ncls ? dt.v[c] : 0;
-                rc = cv_frames_finest_fused(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], k, maxh, maxw, fine, &fine_done);
+                if (filt) {
+                    float *none = nullptr;
+                    rc = dfe_feat_matching_win64_batch(ctx, 1, &feat0[0], &feat0[1], fK, &H, &W, maxh, maxw, &none, 0.f, &fine_done, &fine);
+                } else {
+                    rc = cv_frames_finest_fused(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], k, maxh, maxw, fine, &fine_done);
+                }
                 if (rc) return rc;
                 if (fine_done) break;
                 // no plan for this frame: the scale-1 volume after all (fp32; rounded in place for the fp16 entry), then the px kernel
-                rc = cv_frames_dispatch(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], (long long)ps.Hp[0] * ps.Wp[0], k, k, maxh, maxw, (float *)ss.cost[0]);
+                if (filt) rc = dfe_spatial_matching_dispatch(ctx, feat0[0], feat0[1], fK, H, W, maxh, maxw, (float *)ss.cost[0]);
+                else rc = cv_frames_dispatch(ctx, ps.p0[0], ps.p1[0], C, ps.Hp[0], ps.Wp[0], (long long)ps.Hp[0] * ps.Wp[0], k, k, maxh, maxw, (float *)ss.cost[0]);
                 if (rc) return rc;
                 if (f16_scale != 0.f) {
                     const long long n = ss.P[0] * N;

@@ -223,7 +223,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.4"
+#define DFE_CV_KERNEL_REV "cv-r3.5"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -367,150 +367,7 @@ __device__ __forceinline__ int wave_min1(int c) {
     return min((int)q[0], (int)q[1]);
 }
 
-// Eight wave reductions at once, "transposed": v[x] is pixel x's value in this lane's cell; the butterfly's first three steps pair
-// up REGISTERS as well as lanes (v_permlane32_swap / v_permlane16_swap exchange half-waves / rows between two registers, so one swap
-// + one op serves two pixels), halving the live registers at every step, and the last three run on one register.  The result for
-// pixel g ends up in lane 8 g.  Partners at distance 32, 16, 8, 4, 2, 1 and the lower lane's value on the left of every +: the sum
-// has the association of wave_sum_f32_ordered / px_softmin64 bit for bit.  18 VALU operations instead of 8 x 12.
-// OP 0: fp32 sum; 1 / 2: minimum / maximum of NON-NEGATIVE floats, taken on their bit patterns as integers (the same order, and no
-// canonicalising v_max x, x, x in front of every operand the way fminf / fmaxf compile).
-template <int OP>
-__device__ __forceinline__ int wave_reduce8_op(int a, int b) {
-#pragma clang fp contract(off)
-    return OP == 0 ? __float_as_int(__int_as_float(a) + __int_as_float(b)) : OP == 1 ? min(a, b) : max(a, b);
-}
-template <int OP>
-__device__ __forceinline__ int wave_reduce8_transposed(const float (&v)[8], int lane) {
-    int r1[4], r2[2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) {        // lanes < 32: pixel x, lanes >= 32: pixel x + 4
-        const auto q = __builtin_amdgcn_permlane32_swap(__float_as_int(v[x]), __float_as_int(v[x + 4]), false, false);
-        r1[x] = wave_reduce8_op<OP>((int)q[0], (int)q[1]);
-    }
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {        // rows 0..3: pixels x, x + 2, x + 4, x + 6
-        const auto q = __builtin_amdgcn_permlane16_swap(r1[x], r1[x + 2], false, false);
-        r2[x] = wave_reduce8_op<OP>((int)q[0], (int)q[1]);
-    }
-    const bool up = (lane & 8) != 0;     // from here on lane L works for pixel L >> 3
-    const int keep = up ? r2[1] : r2[0], send = up ? r2[0] : r2[1];
-    int r = wave_reduce8_op<OP>(keep, __builtin_amdgcn_update_dpp(0, send, 0x128, 0xf, 0xf, true));                  // row_ror:8
-    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0x104, 0xf, 0xf, true));                           // row_shl:4 (lane j reads lane j + 4)
-    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0x4E, 0xf, 0xf, true));                            // quad_perm [2,3,0,1]
-    r = wave_reduce8_op<OP>(r, __builtin_amdgcn_update_dpp(0, r, 0xB1, 0xf, 0xf, true));                            // quad_perm [1,0,3,2]
-    return r;                             // lane 8 g: pixel g (other lanes: partial results)
-}
-
-// The finest scale of the multiscale matcher, consumed where it is produced: a task row is 8 pixels x the 64 cells of their 8 x 8
-// windows, lane <-> cell.  Per pixel: soft-min over the wave (wave minimum of the costs, exponential, wave sum in the association
-// order of every other soft-min on the device, e * (1 / sum)), cascade add of the parent pixel's window (cell (a, b) reads the
-// parent's cell (2 + a/2, 2 + b/2): one ds_bpermute of the parent value every lane holds for its own cell), arg-max over the 64
-// classes of this scale (wave maximum, lowest lane attaining it) against the coarser chain's running best (this scale wins ties:
-// its class ids are smaller), centre override, decode -- the operations of cascade_px_kernel<FINEST> in the lane <-> cell form, on
-// the same values in the same order: bit-identical results, and the scale-1 volume (84 % of the pyramid's bytes) is never written
-// or read.  The three reductions run for the 8 pixels together (wave_reduce8_transposed); lane 8 g finishes pixel g and stores it.
-//   (-c) - max(-c) == min(c) - c bit for bit; costs are sums of squares (>= +0) and the cascaded values sums of probabilities, so the
-//   integer order of the bit patterns is the float order (frames with NaN / Inf give garbage on either path, not the same garbage).
-//   Centre override (bv == centre value): the centre is one of the 64 cells, so centre <= fv; if the coarser chain's best wins
-//   (pbv > fv) it is larger than the centre, otherwise bv = fv and the test is "the centre cell attains the maximum" = its bit in
-//   the ballot the arg-max needs anyway.
-//   MID (a scale > 1 with a coarser one above it, cascade_px_kernel<false>): the cascaded window is stored for the next finer scale, and
-//   the arg-max runs over the 48 ring cells in CLASS order (top two rows, left 4 x 2, right 4 x 2, bottom two rows): cells outside
-//   the ring take the most negative integer before the maximum; among the cells that attain it the class order is "first non-empty
-//   group, lowest cell in it" -- scalar arithmetic on the ballot.
-template <int TX, bool F16, bool MID>
-__device__ __forceinline__ void fine_epilogue(const float (&vrow)[TX], int lane, int y, int xt, int Wo, const CvFineArgs &fa) {
-#pragma clang fp contract(off)
-    static_assert(TX == 8, "8 fine pixels = 4 parent pixels");
-    const int a = lane >> 3, b = lane & 7;
-    const int gsrc = (((2 + (a >> 1)) << 3) + 2 + (b >> 1)) << 2;          // byte address for ds_bpermute: the parent cell this cell adds
-    const bool has_parent = fa.pcasc != nullptr;                            // (launch-uniform)
-    float par[4];
-    float2 pb = make_float2(0.f, 0.f);
-    if (has_parent) {
-        const long long pp = (long long)(y >> 1) * (Wo >> 1) + (xt >> 1);
-        const float *pc = fa.pcasc + pp * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) par[j] = pc[j * 64];
-        pb = fa.pbest[pp + (lane >> 4)];                                    // lane 8 g: the running best of pixel g's parent
-    }
-    float v[TX];
-#pragma unroll
-    for (int x = 0; x < TX; ++x) v[x] = F16 ? (float)(_Float16)(vrow[x] * fa.f16_scale) * fa.f16_inv : vrow[x];   // what a stored fp16 volume would hold
-    const int mn = wave_reduce8_transposed<1>(v, lane);
-    int bc[TX];
-#define DFE_BCAST8(src)                                                                                                          \
-    _Pragma("unroll") for (int x = 0; x < TX; ++x) bc[x] = __builtin_amdgcn_readlane(src, 8 * x);                                \
-    asm volatile("" : "+s"(bc[0]), "+s"(bc[1]), "+s"(bc[2]), "+s"(bc[3]), "+s"(bc[4]), "+s"(bc[5]), "+s"(bc[6]), "+s"(bc[7]))   // (all eight read before the first use: no wait states between a v_readlane and its consumer)
-    DFE_BCAST8(mn);
-#pragma unroll
-    for (int x = 0; x < TX; ++x) v[x] = dfe_exp_nonpos(__int_as_float(bc[x]) - v[x]);
-    const int rs = __float_as_int(1.0f / __int_as_float(wave_reduce8_transposed<0>(v, lane)));
-    DFE_BCAST8(rs);
-#undef DFE_BCAST8
-#pragma unroll
-    for (int x = 0; x < TX; ++x) v[x] = v[x] * __int_as_float(bc[x]);
-    if (has_parent) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float g = __int_as_float(__builtin_amdgcn_ds_bpermute(gsrc, __float_as_int(par[j])));
-            v[2 * j] = v[2 * j] + g;
-            v[2 * j + 1] = v[2 * j + 1] + g;
-        }
-    }
-    if constexpr (MID) {
-        float *cq = fa.casc + ((long long)y * Wo + xt) * 64 + lane;
-        const bool ring = !(a >= 2 && a <= 5 && b >= 2 && b <= 5);
-#pragma unroll
-        for (int x = 0; x < TX; ++x) {
-            cq[x * 64] = v[x];
-            v[x] = ring ? v[x] : __int_as_float(0x80000000);
-        }
-    }
-    const int fvp = wave_reduce8_transposed<2>(v, lane);
-    const int mbit = (fa.middle - 1) & 63;
-    unsigned long long codes = 0;                                           // byte x: pixel x's first maximal cell | centre-is-maximal << 6
-#pragma unroll
-    for (int x = 0; x < TX; ++x) {
-        const unsigned long long hit = __builtin_amdgcn_ballot_w64(__float_as_int(v[x]) == __builtin_amdgcn_readlane(fvp, 8 * x));
-        unsigned long long code;
-        if constexpr (MID) {                                                // (byte x: the class rank 0..47 of pixel x's first maximal ring cell)
-            const unsigned long long top = hit & 0xffffull, left = hit & 0x0000030303030000ull, right = hit & 0x0000c0c0c0c00000ull;
-            const int cell = __builtin_ctzll(top ? top : left ? left : right ? right : hit);
-            const int side = 16 + ((cell >> 3) - 2) * 2 + (cell & 7);      // left columns 0, 1 -> ranks 16..23; right columns 6, 7 -> 24..31
-            code = (unsigned long long)(cell < 16 ? cell : cell >= 48 ? cell - 16 : (cell & 7) < 2 ? side : side + 2);
-        } else {
-            code = (unsigned long long)__builtin_ctzll(hit) | (((hit >> mbit) & 1ull) << 6);
-        }
-        codes |= code << (8 * x);
-    }
-    if constexpr (MID) {
-        if ((lane & 7) == 0) {
-            const int g = lane >> 3;
-            float bv = __int_as_float(fvp);
-            int bi = ((int)(codes >> (8 * g)) & 0xff) + fa.cls_base;
-            if (has_parent && !(bv >= pb.x)) { bv = pb.x; bi = __float_as_int(pb.y); }      // the scale wins ties against the coarser chain
-            fa.best[(long long)y * Wo + xt + g] = make_float2(bv, __int_as_float(bi));
-        }
-        return;
-    }
-    if ((lane & 7) == 0) {
-        const int g = lane >> 3;
-        const int code = (int)(codes >> (8 * g)) & 0xff;
-        int bi = code & 63;
-        bool centre = (code & 64) != 0;
-        if (has_parent && !(__int_as_float(fvp) >= pb.x)) { bi = __float_as_int(pb.y); centre = false; }   // the scale wins ties against the coarser chain
-        int id = bi + 1;
-        if (fa.middle > 0 && centre) id = fa.middle;
-        const long long p = (long long)y * Wo + xt + g;
-        if (fa.idx) fa.idx[p] = id;
-        if (fa.fy) {
-            const int d = fa.dec[id - 1];
-            fa.fy[p] = (float)(d >> 16);
-            fa.fx[p] = (float)(short)(d & 0xffff);
-        }
-    }
-}
+// (wave_reduce8_transposed and fine_epilogue -- the fused pyramid scales' epilogue, shared with the feature matcher -- live in dfe_internal.h)
 
 // Rows are swept in groups of U (the unroll that makes every ring index static):
 //   K == 7: U = 6, vertical sum as the fixed tree ((H0+H1)+(H2+H3))+((H4+H5)+H6) kept as a ring of six

@@ -795,6 +795,32 @@ def test_learned_multiscale_prefiltered_and_focus(dfe, cuda):
     assert float((o.reshape(-1) - fullr[16, 29]).abs().max()) <= 1e-6
 
 
+@pytest.mark.parametrize("share", [True, False])
+@pytest.mark.parametrize("ratios,H,W,sc", [([1, 2, 4], 96, 136, None), ([1, 2, 4, 8], 192, 256, None), ([1, 2], 64, 96, None), ([1], 64, 96, None),
+                                           ([1, 2, 4], 96, 128, 1.0)])
+def test_learned_multiscale_fused_finest_scale_bitwise(dfe, cuda, monkeypatch, share, ratios, H, W, sc):
+    """Learned filters: the finest scale consumed inside the feature matcher (feat_matching_win64_fine_kernel, no scale-1 volume) == its
+    volume written and read by cascade_px_kernel<FINEST>, bit for bit (fp32 and half-rounded volumes; shared and per-scale stacks)."""
+    gen = torch.Generator().manual_seed(11)
+    geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, layers=LEARNED_LAYERS, share_filters=share, hImg=H, wImg=W, output_extraction_method="max")
+    model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H, max_flow=min(10, 2 * ratios[-1]), noise_sigma=2.0)
+    t0, t1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
+    ctx = dfe.get_ctx(0)
+    monkeypatch.setenv("DFE_FINE_FUSE", "1")
+    monkeypatch.setenv("DFE_MID_FUSE", "1")                 # (the second scale too where there are >= 3 ratios)
+    a = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+    assert ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
+    monkeypatch.setenv("DFE_MID_FUSE", "0")
+    m = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+    assert ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
+    monkeypatch.setenv("DFE_FINE_FUSE", "0")
+    b = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+    assert not ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
+    for r in (a, m):
+        assert torch.equal(r["index"], b["index"]) and torch.equal(r["y"], b["y"]) and torch.equal(r["x"], b["x"])
+
+
 def test_learned_multiscale_f16_and_full_vga(dfe, cuda):
     """the bench workload `vga-pyramid-learned` (640x480, {1,2,4}, layers of tests/time_matching.lua): one call == staged bit for
     bit, with fp32 and with half-rounded volumes; the planted flow is found."""
