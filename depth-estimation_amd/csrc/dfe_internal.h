@@ -195,15 +195,21 @@ struct CvFuseArgs {
     int row_off;           // output-row offset of this launch inside the pair
     float *rec;            // the role-split row-image kernels leave their per-pixel results here instead of in the planes above:
                            // [column group = tile column][output row of the pair][DFE_REC floats] -- one 128-B line per TILE ROW:
-                           // 8 x (minimum, first index as int bits) | 8 x centre cost | 8 x 0 -- written whole by ONE store of one wave,
+                           // 8 x (minimum, first index as int bits) | 8 x centre cost | 8 x 0 | lead cells -- whole lines, written by ONE store of one wave,
                            // a block sweeping down its column writes consecutive lines.  (The planes took four partial-line stores per
                            // PIXEL and row step -- 8 B + 8 B + 64 B + 4 B, lines shared with neighbouring blocks on other XCDs -- and made
                            // the fused 1080p kernel take 1.78 .. 2.21 ms depending on the process; a 128-B record per pixel, 251 MB at
-                           // 1080p, cost 0.8 ms: DESIGN section 5.)  The pixel's first DFE_LEAD cells are read back from the volume.
+                           // 1080p, cost 0.8 ms: DESIGN section 5.)  Behind the first line: [pixel][DFE_REC_NLEAD] the pixels' first cells
+                           // (extractOutput's input; read back from the volume at first -- that doubled the finalize kernel and, at 1080p,
+                           // left volume lines in the memory-side cache that slowed the next launch's stores by 10 %).
     int rec_rows;          // output rows of the pair (the record's row pitch)
 };
-#define DFE_REC 32         // floats per tile-row record
-#define DFE_REC_CENTRE 16  // (entries 0..15: (minimum, index) of the 8 pixels; 16..23: their centre costs)
+#ifndef DFE_REC_NLEAD
+#define DFE_REC_NLEAD 8    // a pixel's first cells kept in its tile row's record (0: none, extractOutput reads them from the volume)
+#endif
+#define DFE_REC (32 + 8 * DFE_REC_NLEAD)   // floats per tile-row record (1 or 3 whole 128-B lines)
+#define DFE_REC_CENTRE 16  // (entries 0..15: (minimum, index) of the 8 pixels; 16..23: their centre costs; 24..31: 0)
+#define DFE_REC_LEAD 32    // (entries 32..: [pixel][DFE_REC_NLEAD] the pixels' first cells)
 // frame mode of dfe_flow_finalize (one band only): finalize also zeroes the frame border and makes depth / confidence
 struct DfePairDepth { int H, W; float cx, cy; float *depth, *conf; };
 // (rec != nullptr: part / centre / lead are ignored -- minimum / index / centre come from the tile-row records [col group][rec_rows][DFE_REC],

@@ -287,26 +287,38 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
                 //  bytes is 4-B aligned only: scalar loads)
                 float4 q4;
                 if (rec) {
-                    const float *lv = vol + p * N + 4 * g4;
-                    q4 = make_float4(__builtin_nontemporal_load(lv), __builtin_nontemporal_load(lv + 1), __builtin_nontemporal_load(lv + 2), __builtin_nontemporal_load(lv + 3));
+                    if (4 * g4 < DFE_REC_NLEAD) {          // the record's copy of the pixel's first cells (32 B, whole-line reads across the tile row)
+                        const int ncols = (o.Wo + 7) >> 3;
+                        const int g = min(x >> 3, ncols - 1), xb = g == ncols - 1 ? o.Wo - 8 : g << 3;
+                        const float *lv = rec + ((long long)g * rec_rows + y) * DFE_REC + DFE_REC_LEAD + (x - xb) * DFE_REC_NLEAD + 4 * g4;
+                        q4 = make_float4(__builtin_nontemporal_load(lv), __builtin_nontemporal_load(lv + 1), __builtin_nontemporal_load(lv + 2), __builtin_nontemporal_load(lv + 3));
+                    } else if (DFE_REC_NLEAD == 0) {
+                        const float *lv = vol + p * N + 4 * g4;
+                        q4 = make_float4(__builtin_nontemporal_load(lv), __builtin_nontemporal_load(lv + 1), __builtin_nontemporal_load(lv + 2), __builtin_nontemporal_load(lv + 3));
+                    } else {
+                        q4 = make_float4(0.f, 0.f, 0.f, 0.f);   // (not looked at: nlead below)
+                    }
                 }
                 else q4 = reinterpret_cast<const float4 *>(lead + pg * DFE_LEAD)[g4];
                 qq[4 * g4] = q4.x; qq[4 * g4 + 1] = q4.y; qq[4 * g4 + 2] = q4.z; qq[4 * g4 + 3] = q4.w;
             }
+            // (record mode with lead cells in the record: only the first DFE_REC_NLEAD are at hand; the walk through the volume below
+            //  takes over behind them -- the same cells in the same order)
+            const int nlead = (rec && DFE_REC_NLEAD > 0) ? DFE_REC_NLEAD : DFE_LEAD;
 #pragma unroll
             for (int kk = 0; kk < DFE_LEAD; ++kk) qq[kk] = kk < N ? qq[kk] : 0.f;
 #pragma unroll
             for (int kk = 0; kk < DFE_LEAD; ++kk) {
-                if (kk < N && n < M && (double)qq[kk] > threshold) {
+                if (kk < nlead && kk < N && n < M && (double)qq[kk] > threshold) {
 #pragma unroll
                     for (int j = 0; j < M; ++j)
                         if (j == n) { hv[j] = qq[kk]; hi[j] = (float)(kk + 1); }
                     ++n;
                 }
             }
-            if (n < M && N > DFE_LEAD) {   // rare: keep scanning the volume itself
+            if (n < M && N > nlead) {   // rare: keep scanning the volume itself
                 const float *v = vol + p * N;
-                for (int kk = DFE_LEAD; kk < N && n < M; ++kk) {
+                for (int kk = nlead; kk < N && n < M; ++kk) {
                     const float t = v[kk];
                     if ((double)t > threshold) {
 #pragma unroll

@@ -223,7 +223,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.5"
+#define DFE_CV_KERNEL_REV "cv-r3.6"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -1193,6 +1193,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 rb[2 * xx] = __int_as_float(vmin);
                 rb[2 * xx + 1] = __int_as_float(idx);
                 rb[DFE_REC_CENTRE + xx] = cen;
+                if constexpr (DFE_REC_NLEAD >= 4) {      // lane 0 holds the run's cells 0..8 already: the first 4 / 8 ride along (16-B LDS writes)
+                    static_assert(DFE_REC_NLEAD == 4 || DFE_REC_NLEAD == 8, "one or two 16-B pieces");
+                    typedef int i4_t __attribute__((ext_vector_type(4)));
+                    i4_t *lp4 = reinterpret_cast<i4_t *>(rb + DFE_REC_LEAD + DFE_REC_NLEAD * xx);
+                    lp4[0] = i4_t{c0[0], c0[1], c0[2], c0[3]};
+                    if constexpr (DFE_REC_NLEAD == 8) lp4[1] = i4_t{c0[4], c0[5], c0[6], c0[7]};
+                }
             }
         }
     };
@@ -1203,7 +1210,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     auto write_record = [&](int rpar, const float *rb) {
         int lw = lane;
         asm volatile("" : "+v"(lw));
-        if (lw < 8 && !(DFE_ABLATE & 192)) {
+        if (lw < DFE_REC / 4 && !(DFE_ABLATE & 192)) {
             const f4_t v = *reinterpret_cast<const f4_t *>(recbuf + rpar * DFE_REC + 4 * lw);
             asm volatile("global_store_dwordx4 %0, %1, %2" DFE_REC_ST_FLAGS ::"v"((unsigned)lw * 16u), "v"(v), "s"(rb) : "memory");
         }
