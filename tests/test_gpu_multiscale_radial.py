@@ -1267,13 +1267,17 @@ def test_epipole_and_foe_from_dense_flow(dfe, cuda):
         dfe.sfm2.getFOEFromFlow(T(par, cuda), None)
 
 
-def test_multiscale_one_call_graph_replay_equals_direct_launches(dfe, cuda):
-    """With DFE_GRAPHS=1 the one-call matcher replays its launches as a hipGraph from the third call with the same buffers on
+@pytest.mark.parametrize("fused", [False, True])
+def test_multiscale_one_call_graph_replay_equals_direct_launches(dfe, cuda, monkeypatch, fused):
+    """(fused: the finest two scales inside the volume kernel -- what frames from 1080p up get by default -- captured and replayed too.)
+    With DFE_GRAPHS=1 the one-call matcher replays its launches as a hipGraph from the third call with the same buffers on
     (the second captures): every call gives the result of the direct launches, also after the frames were overwritten in
     place, and a call with other buffers drops the graph.  (Off by default: the replay measured slower.)"""
     from depth_estimation_amd._lib import ratios_array
 
     H, W, k, mh, ratios = 96, 128, 7, 8, [1, 2, 4]
+    monkeypatch.setenv("DFE_FINE_FUSE", "1" if fused else "0")
+    monkeypatch.setenv("DFE_MID_FUSE", "1" if fused else "0")
     fa0, fa1, _, _ = rp.synth_pair(H, W, C=3, seed=21)
     fb0, fb1, _, _ = rp.synth_pair(H, W, C=3, seed=22)
     want_a = _one_call(dfe, cuda, fa0, fa1, k, mh, mh, ratios)      # default (legacy) stream: cannot be captured, direct launches
