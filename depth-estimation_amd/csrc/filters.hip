@@ -109,7 +109,9 @@ extern __shared__ __attribute__((aligned(16))) float conv_smem[];
 template <int KW, int NT, bool TANH>
 __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, int nOut, int kH, int groups) {
 #pragma clang fp contract(off)
-    constexpr int PITCH = CB_TW + 8;                       // (KW - 1 <= 8 halo columns; rows stay 16-B aligned)
+    constexpr int HALO = (KW - 1 + 3) / 4 * 4;             // halo columns, rounded so that rows stay 16-B aligned
+    constexpr int PITCH = CB_TW + (HALO < 8 ? 8 : HALO);
+    static_assert(PITCH <= 192, "three 64-lane passes stage a tile row");
     int ent = 0;
     while (ent + 1 < cb.n && (int)blockIdx.x >= cb.blk0[ent + 1]) ++ent;       // (block-uniform; at most 10 entries)
     const int H = cb.H[ent], W = cb.W[ent];
@@ -169,8 +171,10 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
     for (int i = 0; i < nIn; ++i)
         for (int u = 0; u < kH; ++u) {
             const float4 *row = reinterpret_cast<const float4 *>(conv_smem + (i * trows + ty + u) * PITCH + CB_PX * tx);
-            const float4 t0 = row[0], t1 = row[1], t2 = row[2];
-            const float v[12] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w, t2.x, t2.y, t2.z, t2.w};
+            constexpr int NV4 = (CB_PX + KW - 1 + 3) / 4;                                  // 16-B pieces of the tile row this strip reads
+            float v[4 * NV4];
+#pragma unroll
+            for (int j = 0; j < NV4; ++j) { const float4 t = row[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
             f2 pr[KW][2];
 #pragma unroll
             for (int k = 0; k < KW; ++k) { pr[k][0] = f2{v[k], v[k + 1]}; pr[k][1] = f2{v[k + 2], v[k + 3]}; }
@@ -204,7 +208,8 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
 template <int KW, int NT>
 static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn, int nOut, int kH, int tanh_after, int maxblocks) {
     const int groups = nOut / NT;
-    const size_t lds = (size_t)nIn * (CB_TH + kH - 1) * (CB_TW + 8) * sizeof(float);
+    constexpr int halo = (KW - 1 + 3) / 4 * 4;
+    const size_t lds = (size_t)nIn * (CB_TH + kH - 1) * (CB_TW + (halo < 8 ? 8 : halo)) * sizeof(float);
     if (lds > 64 * 1024) return false;
     auto kern = tanh_after ? conv_batch_kernel<KW, NT, true> : conv_batch_kernel<KW, NT, false>;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
@@ -219,9 +224,8 @@ static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn,
 
 // n inputs through ONE layer (full connection): in[e] [nIn][H[e]][W[e]] -> out[e]; per-entry weights (the scales may have their own).
 // Falls back to one dfe_filter_layer_forward launch per entry for shapes without a batched instantiation.
-int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
-                                   float *const *out) {
-    DFE_REQUIRE(ctx, n >= 1 && n <= 2 * DFE_MAX_RATIOS, DFE_E_ARG, "filter layer batch: n=%d", n);
+static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, float *const *out, bool *done_out) {
+    *done_out = false;
     const dfe_filter_layer &L0 = *L[0];
     bool same = true;
     for (int e = 1; e < n; ++e)
@@ -246,12 +250,22 @@ int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, 
         else if (nt == 4) done = launch_conv_batch<KWV, 4>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
     }
         if (ok && nt) { DFE_CB(3) DFE_CB(5) DFE_CB(7) }
+        if (ok && nt == 8 && L0.kW == 17) done = launch_conv_batch<17, 8>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);   // version2/network.lua's 17 x 17 x 32
 #undef DFE_CB
         if (done) {
             DFE_LAUNCH_CHECK(ctx);
-            return DFE_OK;
+            *done_out = true;
         }
     }
+    return DFE_OK;
+}
+
+int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
+                                   float *const *out) {
+    DFE_REQUIRE(ctx, n >= 1 && n <= 2 * DFE_MAX_RATIOS, DFE_E_ARG, "filter layer batch: n=%d", n);
+    bool done = false;
+    int rc0 = conv_batch_try(ctx, n, in, L, H, W, out, &done);
+    if (rc0 != DFE_OK || done) return rc0;
     for (int e = 0; e < n; ++e) {
         int rc = dfe_filter_layer_forward(ctx, in[e], *L[e], H[e], W[e], out[e]);
         if (rc) return rc;
@@ -280,6 +294,16 @@ int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weig
     DFE_REQUIRE(ctx, in && weight && out, DFE_E_ARG, "dfe_spatial_convolution_f32: NULL tensor");
     DFE_REQUIRE(ctx, nIn > 0 && nOut > 0 && kH > 0 && kW > 0 && H >= kH && W >= kW, DFE_E_SHAPE,
                 "dfe_spatial_convolution_f32: %d->%d planes, %dx%d kernel on %dx%d", nIn, nOut, kH, kW, H, W);
+    // the LDS-tiled kernel where it has an instantiation (same accumulation order, separately rounded multiply and add: bit-identical
+    // to conv_kernel -- 17 x 17, 3 -> 32 planes at VGA: 1.84 -> 0.36 ms)
+    if (ctx->cv_mode != 1 && !getenv("DFE_NO_CONV_BATCH")) {
+        dfe_filter_layer L{};
+        L.weight = weight; L.bias = bias; L.nIn = nIn; L.nOut = nOut; L.kH = kH; L.kW = kW;
+        const dfe_filter_layer *Lp = &L;
+        bool done = false;
+        int rc = conv_batch_try(ctx, 1, &in, &Lp, &H, &W, &out, &done);
+        if (rc != DFE_OK || done) return rc;
+    }
     hipLaunchKernelGGL(conv_kernel, dim3(grid_n((long long)nOut * (H - kH + 1) * (W - kW + 1))), dim3(256), 0, ctx->stream, in, weight, bias,
                        nIn, nOut, H, W, kH, kW, out);
     DFE_LAUNCH_CHECK(ctx);
