@@ -241,11 +241,12 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
             const int b = dfe_cdiv(W[e] - L0.kW + 1, CB_TW) * dfe_cdiv(H[e] - L0.kH + 1, CB_TH);
             if (b > maxblocks) maxblocks = b;
         }
-        const int nt = L0.nOut % 8 == 0 ? 8 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
+        const int nt = L0.nOut % 8 == 0 ? 8 : (L0.nOut % 10 == 0 && !getenv("DFE_CONV_NT5")) ? 10 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
         bool done = false;
 #define DFE_CB(KWV)                                                                                                                       \
     if (L0.kW == KWV) {                                                                                                                   \
         if (nt == 8) done = launch_conv_batch<KWV, 8>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                      \
+        else if (nt == 10) done = launch_conv_batch<KWV, 10>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);               \
         else if (nt == 5) done = launch_conv_batch<KWV, 5>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
         else if (nt == 4) done = launch_conv_batch<KWV, 4>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
     }
