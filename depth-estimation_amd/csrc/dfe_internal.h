@@ -213,7 +213,7 @@ struct CvFuseArgs {
 // frame mode of dfe_flow_finalize (one band only): finalize also zeroes the frame border and makes depth / confidence
 struct DfePairDepth { int H, W; float cx, cy; float *depth, *conf; };
 // (rec != nullptr: part / centre / lead are ignored -- minimum / index / centre come from the tile-row records [col group][rec_rows][DFE_REC],
-//  the lead cells from the volume itself)
+//  the lead cells from the records too (DFE_REC_NLEAD per pixel), further cells -- rarely needed -- from the volume itself)
 int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
                       float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
                                                             int wWin, int middle, double threshold, TailOut o, const float *__restrict__ rec,
                                                             int rec_rows) {
     // rec != nullptr (launch-uniform): minimum / first index / centre cost of a pixel come from its tile row's record
-    // [column group][rec_rows][DFE_REC] (CvFuseArgs::rec), its lead cells from the volume; else from the three planes
+    // [column group][rec_rows][DFE_REC] (CvFuseArgs::rec), its first DFE_REC_NLEAD lead cells from the record too; else from the three planes
     const long long nthreads_work = o.frame_H ? (long long)o.frame_H * o.frame_W : Pband;
     for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nthreads_work; q += (long long)gridDim.x * blockDim.x) {
         long long p = q;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
             float qq[DFE_LEAD];
 #pragma unroll
             for (int g4 = 0; g4 < DFE_LEAD / 4; ++g4) {                                   // pixel-major [P][DFE_LEAD]: 4 x 16 B
-                // (record mode: the pixel's first cells straight from the volume -- N is a multiple of nothing in particular, but p * N * 4
-                //  bytes is 4-B aligned only: scalar loads)
+                // (record mode: the pixel's first DFE_REC_NLEAD cells from its tile row's record; DFE_REC_NLEAD = 0 builds read them straight
+                //  from the volume -- p * N * 4 bytes is 4-B aligned only: scalar loads)
                 float4 q4;
                 if (rec) {
                     if (4 * g4 < DFE_REC_NLEAD) {          // the record's copy of the pixel's first cells (32 B, whole-line reads across the tile row)

@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         // stored its pixel's entries into three planes itself: two 8-B entries, 64 B of lead cells, 4 B of centre per pixel and row
         // step -- partial lines that neighbouring blocks on other XCDs complete, and the reason the fused 1080p kernel took
         // 1.78 .. 2.21 ms depending on where the process' arena had landed (without them: 1.78 .. 1.81 ms in every process).
-        // The lead cells are not kept at all any more: finalize reads them back from the volume.
+        // The pixel's first DFE_REC_NLEAD cells follow in the same record (lane 0 holds them already).
         static_assert(!ROLES || DC == 1089, "centre cell 544");
         if (!(DFE_ABLATE & 192)) {
             const float cen = stp[xx * D + 544];
