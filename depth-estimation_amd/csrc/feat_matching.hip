@@ -111,19 +111,34 @@ __global__ __launch_bounds__(1024) void feat_matching_rows_kernel(const float *_
     for (int q = 0; q < PX; ++q)
 #pragma unroll
         for (int d = 0; d < MW; ++d) acc[q][d] = 0.f;
-    auto stage = [&](int k, int buf) {
-        float *t = tile + buf * p.maxh * TC;
-        for (int e = threadIdx.x; e < p.maxh * TC; e += nthr) {
+    // Staging of plane k+1 in two halves around the arithmetic of plane k: its global loads are issued BEFORE (into NS registers per
+    // thread: maxh * TC / (64 maxh) <= 5 tile elements + one of the in1 row), the LDS writes come AFTER -- the first version did both
+    // in front of the arithmetic, i.e. waited out a memory round trip per plane with nothing to overlap it (16 waves, one block per CU).
+    constexpr int NS = (TC + 63) / 64 + 1;
+    float sv[NS];
+    auto stage_load = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) {
+            const int e = min((int)threadIdx.x + j * nthr, p.maxh * TC - 1);
             const int r = e / TC, c = e - r * TC;
-            const int x = min(x0 + c, p.W2 - 1);
-            t[e] = in2[k * plane2 + (long long)(y + r) * p.W2 + x];
+            sv[j] = in2[k * plane2 + (long long)(y + r) * p.W2 + min(x0 + c, p.W2 - 1)];
         }
-        for (int e = threadIdx.x; e < SEG; e += nthr) arow[buf * SEG + e] = in1[k * plane1 + (long long)y * p.W1 + min(x0 + e, p.W1 - 1)];
+        sv[NS - 1] = in1[k * plane1 + (long long)y * p.W1 + min(x0 + min((int)threadIdx.x, SEG - 1), p.W1 - 1)];
     };
-    stage(0, 0);
+    auto stage_commit = [&](int buf) {
+        float *t = tile + buf * p.maxh * TC;
+#pragma unroll
+        for (int j = 0; j < NS - 1; ++j) {
+            const int e = threadIdx.x + j * nthr;
+            if (e < p.maxh * TC) t[e] = sv[j];
+        }
+        if ((int)threadIdx.x < SEG) arow[buf * SEG + threadIdx.x] = sv[NS - 1];
+    };
+    stage_load(0);
+    stage_commit(0);
     for (int k = 0; k < p.K; ++k) {
         __syncthreads();                                           // plane k is staged; plane k-1's buffer is free
-        if (k + 1 < p.K) stage(k + 1, (k + 1) & 1);
+        if (k + 1 < p.K) stage_load(k + 1);
         const float4 *br = reinterpret_cast<const float4 *>(tile + ((k & 1) * p.maxh + dy) * TC + PX * lane);
         const float4 a4 = *reinterpret_cast<const float4 *>(arow + (k & 1) * SEG + PX * lane);
         float b[4 * NB];
@@ -140,6 +155,7 @@ __global__ __launch_bounds__(1024) void feat_matching_rows_kernel(const float *_
                 const float df = a[q] - b[q + d];
                 acc[q][d] = acc[q][d] + df * df;
             }
+        if (k + 1 < p.K) stage_commit((k + 1) & 1);
     }
     // Copy-out through LDS: a pixel's window (maxh x MW cells) is one contiguous run of the output, but its rows sit in maxh
     // different waves.  For each of the lane's PX pixels in turn, every wave deposits its row into [lane][dy][MW]; after a
@@ -378,11 +394,12 @@ int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int
         if (rc != DFE_OK || *handled) return rc;
     }
     // The row kernel pays a barrier and a tile refill per plane and only fills its 256-column blocks on wide frames: measured
-    // K = 32, 625 x 465, 16 x 16: 0.46 ms against 0.54 ms for the chunk kernel below; K = 10, 293 x 153: 0.064 against 0.039 ms.
+    // 625 x 465, 16 x 16: K = 32 0.37 ms against 0.55 ms for the chunk kernel below, K = 10 0.168 against 0.194 (with the next plane's
+    // loads in flight behind the arithmetic; 0.46 / 0.23 before); K = 10, 293 x 153: 0.064 against 0.039 ms.
     // (W1 == 1: the patch-mode call of the trainers, any K -- the chunk kernel needs 8 x 8 pixels.)
-    bool rows_pays = (K >= 24 && W1 >= 400) || W1 < FM_TX || H1 < FM_TY;
+    bool rows_pays = (K >= 8 && W1 >= 400) || W1 < FM_TX || H1 < FM_TY;
     if (const char *e = getenv("DFE_FM_ROWS")) rows_pays = atoi(e) != 0;   // tuning
-    if (rows_pays && (maxw == 16 || maxw == 8) && maxh >= 2 && maxh <= 16 && ctx->cv_mode != 2 && ((uintptr_t)out & 15) == 0) {
+    if (rows_pays && (maxw == 16 || maxw == 8) && maxh >= 4 && maxh <= 16 && ctx->cv_mode != 2 && ((uintptr_t)out & 15) == 0) {
         FmArgs a{};
         a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.maxw = maxw; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;
         const int TC = 256 + maxw;

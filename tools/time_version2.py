@@ -35,3 +35,10 @@ f0 = conv.forward(n0).clone(); f1 = conv.forward(n1).clone()
 hc, wc = f0.shape[1] - 16, f0.shape[2] - 16
 f0c = f0[:, 8:8 + hc, 8:8 + wc].contiguous()
 print("SpatialMatching(17,17) on 32 planes %dx%d: %.3f ms" % (hc, wc, timed(lambda: match.forward([f0c, f1]))))
+
+# the rows matcher's own shape: 16 x 16 window, K = 32 (and tests/time_matching.lua's K = 10)
+m16 = dnn.SpatialMatching(16, 16, False)
+for K in (32, 10):
+    a = torch.rand((K, H - 15, W - 15), generator=g).to(dev)
+    b = torch.rand((K, H, W), generator=g).to(dev)
+    print("SpatialMatching(16,16) on %d planes %dx%d: %.3f ms (%s)" % (K, H - 15, W - 15, timed(lambda: m16.forward([a, b])), dfe.get_ctx(0).last_kernel()))
