@@ -651,6 +651,42 @@ def test_fused_finest_scale_equals_volume_path_bitwise(dfe, cuda, monkeypatch, r
         assert np.array_equal(mi, wi) and np.array_equal(mf, wf)
 
 
+def test_fused_scales_equal_volume_path_on_random_shapes(dfe, cuda, monkeypatch):
+    """Seeded sweep over frame shapes (every multiple of the coarsest ratio from one tile up, ragged tiles in both directions), ratio sets
+    and volume precisions: both fused forms == the volume path, bit for bit.  Shapes the fused kernels cannot take (scale narrower than a
+    tile, odd scale sizes) must fall back by themselves and still agree."""
+    rng = np.random.default_rng(2024)
+    ctx = dfe.get_ctx(0)
+    nfused = 0
+    for it in range(24):
+        n = int(rng.integers(1, 6))
+        ratios = [1 << s for s in range(n)]
+        top = ratios[-1]
+        H = int(rng.integers(max(1, 24 // top), 200 // top + 1)) * top
+        W = int(rng.integers(max(1, 32 // top), 232 // top + 1)) * top
+        f16 = bool(rng.integers(0, 2))
+        f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=it, max_flow=min(10, 2 * top), noise_sigma=1.5)
+        f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
+
+        def run():
+            if f16:
+                gi, gf, kern = _one_call_f16(dfe, cuda, f0, f1, 7, 8, 8, ratios, 1.0)
+            else:
+                gi, gf = _one_call(dfe, cuda, f0, f1, 7, 8, 8, ratios)
+                kern = ctx.last_kernel()
+            return gi, gf, kern
+
+        monkeypatch.setenv("DFE_FINE_FUSE", "0")
+        wi, wf, _ = run()
+        for mid in ("1", "0"):
+            monkeypatch.setenv("DFE_FINE_FUSE", "1")
+            monkeypatch.setenv("DFE_MID_FUSE", mid)
+            gi, gf, kern = run()
+            nfused += kern.startswith("ssd_cv_tiled_fine_kernel")
+            assert np.array_equal(gi, wi) and np.array_equal(gf, wf), "shape %dx%d ratios %s f16 %s mid %s (%s)" % (H, W, ratios, f16, mid, kern)
+    assert nfused >= 30          # (most shapes do take the fused kernels)
+
+
 def test_one_call_multiscale_f16_equals_staged_bitwise(dfe, cuda):
     """one-call fp16 (real half volumes through ssd_cv_tiled_multi_kernel + cascade_px_kernel<H16>) == the staged HIP path with its
     fp32 volumes rounded to half on the host side, bit for bit (same volume kernel arithmetic, same soft-min / cascade)."""
@@ -819,6 +855,36 @@ def test_learned_multiscale_fused_finest_scale_bitwise(dfe, cuda, monkeypatch, s
     assert not ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
     for r in (a, m):
         assert torch.equal(r["index"], b["index"]) and torch.equal(r["y"], b["y"]) and torch.equal(r["x"], b["x"])
+
+
+def test_learned_fused_scales_on_random_shapes(dfe, cuda, monkeypatch):
+    """The same sweep for the learned-filter matcher (feat_matching_win64_fine_kernel <1> / <2>): fused == volume path, bit for bit."""
+    rng = np.random.default_rng(77)
+    ctx = dfe.get_ctx(0)
+    nfused = 0
+    for it in range(10):
+        n = int(rng.integers(1, 5))
+        ratios = [1 << s for s in range(n)]
+        top = ratios[-1]
+        H = int(rng.integers(max(1, 24 // top), 160 // top + 1)) * top
+        W = int(rng.integers(max(1, 32 // top), 200 // top + 1)) * top
+        sc = 1.0 if rng.integers(0, 2) else None
+        share = bool(rng.integers(0, 2))
+        gen = torch.Generator().manual_seed(it)
+        geo = dict(maxh=8, maxw=8, ratios=ratios, multiscale=True, layers=LEARNED_LAYERS, share_filters=share, hImg=H, wImg=W, output_extraction_method="max")
+        model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
+        f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=it, max_flow=min(10, 2 * top), noise_sigma=1.5)
+        t0, t1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
+        monkeypatch.setenv("DFE_FINE_FUSE", "0")
+        b = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+        for mid in ("1", "0"):
+            monkeypatch.setenv("DFE_FINE_FUSE", "1")
+            monkeypatch.setenv("DFE_MID_FUSE", mid)
+            a = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
+            nfused += ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
+            assert torch.equal(a["index"], b["index"]) and torch.equal(a["y"], b["y"]) and torch.equal(a["x"], b["x"]), \
+                "shape %dx%d ratios %s f16 %s share %s mid %s" % (H, W, ratios, sc, share, mid)
+    assert nfused >= 12
 
 
 def test_learned_multiscale_f16_and_full_vga(dfe, cuda):
