@@ -217,13 +217,16 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 #ifndef DFE_ABLATE
 #define DFE_ABLATE 0
 #endif
+#ifndef DFE_A32
+#define DFE_A32 1
+#endif
 #ifndef DFE_NQW
 // waves that share the 17th chunk of a 33 x 33 window.  Measured at VGA: 8 waves x 1 column (shorter critical path, but 7
 // squared differences per output instead of 4) 0.3124 / 0.2529 ms fused / unfused against 0.3079 / 0.2407 ms for 4 x 2;
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.6"
+#define DFE_CV_KERNEL_REV "cv-r3.7"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             // (G0 = ((long long)y * p.Wo + x0) * D, the global float index of the run, and pg_run, the row's first entry of the
             //  fused per-pixel planes, are carried from row to row: one 64-bit add each instead of two 64-bit multiplies)
             const long long G0 = G0_run;
-            G0_run += (long long)p.Wo * D;
+            G0_run += (long long)p.Wo * D;     // (tried as a 32-bit unsigned step, one scalar fewer: the allocator answered with a vector spill reloaded in every row)
             const long long pg_run = pg_next;
             if constexpr (FUSE) pg_next += p.Wo;
             const int a0 = (int)(G0 & LM);
@@ -1257,8 +1260,17 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars (requested behind the last squared difference instead --
                                                            // inside the task row, in front of the sums -- the 42 scalars are live across the
                                                            // sums as well and the 3-channel sweeps spill: 62 / 99 scalars, 104 / 124 B of scratch)
+#if DFE_A32
+                        // (32-bit unsigned row / plane offsets next to ONE 64-bit base: the scalar loads take them as soffset, and the
+                        //  sweep keeps 3 scalars fewer than with a running 64-bit pointer and two 64-bit plane offsets)
+                        const char *ab = reinterpret_cast<const char *>(I0 + a_base);
+                        const unsigned roff = (unsigned)rn * (unsigned)p.W * 4u, hwb = (unsigned)HW * 4u;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) uload<NE>((cfptr)(ab + (unsigned long long)(roff + (unsigned)c * hwb)), av[c]);
+#else
 #pragma unroll
                         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)rn * p.W + c * HW), av[c]);
+#endif
                     }
                     // deposit at once (image (r&1) was last read for row r-2, before the barrier of row r-1)
                     if (store_row && valid) {
