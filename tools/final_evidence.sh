@@ -19,3 +19,5 @@ tail -1 gpurun_out/${tag}_bench_default.log | cut -c1-600
 bash tools/bench_all.sh $tag || exit $?
 bash tools/kstats.sh $tag vga vga-f16 720p-radial vga-pyramid-learned 1080p-pyramid-learned 1080p-pyramid-f16 > gpurun_out/${tag}_kstats.log 2>&1 || { tail -5 gpurun_out/${tag}_kstats.log; exit 1; }
 cat gpurun_out/${tag}_kstats.log
+timeout -k 10 300 python tools/time_version2.py > gpurun_out/${tag}_time_version2.log 2>&1 || { tail -5 gpurun_out/${tag}_time_version2.log; exit 1; }
+grep -v amdgpu.ids gpurun_out/${tag}_time_version2.log
