@@ -9,6 +9,10 @@ LIB_PATH = os.environ.get("DFE_LIB") or os.path.join(_HERE, "libdfe.so")  # DFE_
 DFE_OK = 0
 DFE_MAX_RATIOS = 10
 
+# keys of dfe_set_option / dfe_get_option (include/dfe.h)
+OPTION_KEYS = ("cascade_px", "fine_fuse", "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10",
+               "fm64", "fm_rows", "sweep_ovh", "sweep_blocks", "debug_arena", "flow_finalize", "fm_flat", "graphs")
+
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int)
@@ -44,6 +48,8 @@ PROTOTYPES = {
     "dfe_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "dfe_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),
     "dfe_ssd_cost_volume_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]),
     "dfe_ssd_cost_volume_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, C.c_void_p]),
@@ -71,6 +77,7 @@ PROTOTYPES = {
     "dfe_set_scratch_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "dfe_profile_read_each": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int]),
     "dfe_flow_tail": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 6 + [C.c_int] * 4,

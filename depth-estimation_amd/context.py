@@ -35,6 +35,33 @@ class Context:
         """0 = tile height chosen per shape; 2..5 forces it (tuning / tests)."""
         self.check(lib().dfe_set_cost_volume_tile(self.handle, int(tyq)))
 
+    def set_option(self, key, value):
+        """dfe_set_option: force (>= 0) or release (-1 / None) one of the launchers' behaviour switches (include/dfe.h)."""
+        self.check(lib().dfe_set_option(self.handle, str(key).encode(), -1 if value is None else int(value)))
+
+    def get_option(self, key):
+        v = C.c_int()
+        self.check(lib().dfe_get_option(self.handle, str(key).encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """with ctx.options(fine_fuse=1, mid_fuse=0): ...  -- the switches are restored on exit."""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_s):
+                self_s.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_s, *exc):
+                for k, v in self_s.old.items():
+                    ctx.set_option(k, v)
+                return False
+
+        return _Scope()
+
     def last_kernel(self):
         return lib().dfe_last_kernel(self.handle).decode()
 

@@ -5,6 +5,16 @@
 
 static thread_local char g_create_err[512] = "";
 
+// key (dfe_set_option) | environment variable read once by dfe_ctx_create | the variable's mere presence means 0 (the old DFE_NO_* switches)
+const DfeOptName dfe_opt_names[DFE_NOPT] = {
+    {"cascade_px", "DFE_CASCADE_PX", false},   {"fine_fuse", "DFE_FINE_FUSE", false},         {"mid_fuse", "DFE_MID_FUSE", false},
+    {"fine_nq", "DFE_FINE_NQ", false},         {"mid_nq", "DFE_MID_NQ", false},               {"prep_tiles", "DFE_NO_PREP_TILES", true},
+    {"xpose", "DFE_NO_XPOSE", true},           {"xpose_nt", "DFE_XPOSE_NT", false},           {"soft_epilogue", "DFE_SOFT_EPILOGUE", false},
+    {"conv_batch", "DFE_NO_CONV_BATCH", true}, {"conv_nt10", "DFE_CONV_NT5", true},           {"fm64", "DFE_NO_FM64", true},
+    {"fm_rows", "DFE_FM_ROWS", false},         {"sweep_ovh", "DFE_SWEEP_OVH", false},         {"sweep_blocks", "DFE_SWEEP_BLOCKS", false},
+    {"debug_arena", "DFE_DEBUG_ARENA", false}, {"flow_finalize", "DFE_FLOW_FINALIZE", false}, {"fm_flat", "DFE_FM_FLAT", false},
+};
+
 int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...) {
     char *dst = ctx ? ctx->err : g_create_err;
     va_list ap;
@@ -26,7 +36,7 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
         if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         ctx->scratch_bytes = bytes;
         // DFE_DEBUG_ARENA=1: where the arena landed (the 1080p step time is bimodal per PROCESS; DESIGN section 5 ties it to this)
-        if (getenv("DFE_DEBUG_ARENA")) fprintf(stderr, "[dfe] scratch arena %p .. %p (%zu bytes, %s2 MiB-aligned)\n", ctx->scratch, (char *)ctx->scratch + bytes,
+        if (ctx->opt[DFE_OPT_DEBUG_ARENA] > 0) fprintf(stderr, "[dfe] scratch arena %p .. %p (%zu bytes, %s2 MiB-aligned)\n", ctx->scratch, (char *)ctx->scratch + bytes,
                                                bytes, ((uintptr_t)ctx->scratch & ((1u << 21) - 1)) ? "not " : "");
     }
     *out = ctx->scratch;
@@ -34,7 +44,7 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
 }
 
 int dfe_graph_lookup(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, const void *key, size_t bytes) {
-    if (!ctx->graphs || !ctx->stream || ctx->profile) return 0;
+    if (!ctx->graphs || !ctx->stream || ctx->profile || ctx->stage_timers) return 0;   // (event records must not become graph nodes)
     const unsigned char *k = (const unsigned char *)key;
     if (slot.key.size() == bytes && memcmp(slot.key.data(), k, bytes) == 0) {
         if (slot.exec) return 2;
@@ -94,6 +104,9 @@ int dfe_ctx_create(int device, void *stream, int own_stream, dfe_ctx **out) {
     dfe_ctx *ctx = new dfe_ctx();
     ctx->device = device;
     ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // tuning switches: the environment is read here, once; afterwards only dfe_set_option changes them
+    for (int i = 0; i < DFE_NOPT; ++i)
+        if (const char *e = getenv(dfe_opt_names[i].env)) ctx->opt[i] = dfe_opt_names[i].env_presence_means_zero ? 0 : atoi(e);
     if (const char *e = getenv("DFE_GRAPHS")) ctx->graphs = atoi(e) != 0;
     if (const char *e = getenv("DFE_CV_MODE")) { int m = atoi(e); if (m >= 0 && m <= 3) ctx->cv_mode = m; }   // tuning: initial kernel mode
     if (const char *e = getenv("DFE_CV_TILE")) { int t = atoi(e); if ((t >= 0 && t <= 7) || (t > 100 && t <= 164)) ctx->cv_tyq = t; }   // tuning: initial tile code
@@ -217,6 +230,33 @@ int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq) {
 
 const char *dfe_last_kernel(const dfe_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
+static int dfe_opt_find(const char *key) {
+    if (!key) return -1;
+    for (int i = 0; i < DFE_NOPT; ++i)
+        if (strcmp(key, dfe_opt_names[i].key) == 0) return i;
+    return -1;
+}
+
+int dfe_set_option(dfe_ctx *ctx, const char *key, int value) {
+    DFE_ENTER(ctx);
+    if (key && strcmp(key, "graphs") == 0) { ctx->graphs = value > 0; return DFE_OK; }
+    const int o = dfe_opt_find(key);
+    DFE_REQUIRE(ctx, o >= 0, DFE_E_ARG, "dfe_set_option: unknown key '%s'", key ? key : "(null)");
+    DFE_REQUIRE(ctx, value >= -1, DFE_E_ARG, "dfe_set_option: %s = %d (>= 0, or -1 for automatic)", key, value);
+    ctx->opt[o] = value;
+    return DFE_OK;
+}
+
+int dfe_get_option(dfe_ctx *ctx, const char *key, int *value) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, value, DFE_E_ARG, "dfe_get_option: value is NULL");
+    if (key && strcmp(key, "graphs") == 0) { *value = ctx->graphs ? 1 : 0; return DFE_OK; }
+    const int o = dfe_opt_find(key);
+    DFE_REQUIRE(ctx, o >= 0, DFE_E_ARG, "dfe_get_option: unknown key '%s'", key ? key : "(null)");
+    *value = ctx->opt[o];
+    return DFE_OK;
+}
+
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes) {
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, bytes >= ((size_t)1 << 20), DFE_E_ARG, "scratch limit %zu below 1 MiB", bytes);
@@ -252,8 +292,10 @@ int dfe_profile_enable(dfe_ctx *ctx, int on) {
     return DFE_OK;
 }
 
-int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches) {
-    DFE_REQUIRE(ctx, ctx && total_ms && launches, DFE_E_ARG, "dfe_profile_read: NULL argument");
+int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches) { return dfe_profile_read_each(ctx, total_ms, launches, nullptr, 0); }
+
+int dfe_profile_read_each(dfe_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap) {
+    DFE_REQUIRE(ctx, ctx && total_ms && launches && (each_ms || cap <= 0), DFE_E_ARG, "dfe_profile_read: NULL argument");
     DfeDeviceGuard guard(ctx);
     DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double sum = 0;
@@ -262,6 +304,7 @@ int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches) {
         float ms = 0.f;
         DFE_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_events[i], ctx->prof_events[i + 1]));
         sum += ms;
+        if (n < cap) each_ms[n] = ms;
         ++n;
     }
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);

@@ -7,7 +7,37 @@
 #include <vector>
 #include "../../include/dfe.h"
 
+// Behaviour switches of the launchers (dfe_set_option / dfe_get_option, include/dfe.h).  -1 = automatic: the launcher's own choice
+// per shape.  The environment is read ONCE, in dfe_ctx_create (tuning scripts), never inside a launcher.
+enum DfeOpt {
+    DFE_OPT_CASCADE_PX = 0,   // lane <-> pixel cascade kernels (0: keep the lane <-> cell kernels)
+    DFE_OPT_FINE_FUSE,        // finest pyramid scale inside its volume / matcher kernel (0 / 1 forces)
+    DFE_OPT_MID_FUSE,         // the second scale the same way
+    DFE_OPT_FINE_NQ,          // tile-height code of the fused finest kernel
+    DFE_OPT_MID_NQ,           // ... of the fused second scale
+    DFE_OPT_PREP_TILES,       // every scale from one read of the frames (0: one launch per scale set)
+    DFE_OPT_XPOSE,            // 1-KB transposed stores of one-chunk windows (0: 256-B pieces)
+    DFE_OPT_XPOSE_NT,         // their non-temporal hint (0 / 1 forces)
+    DFE_OPT_SOFT_EPILOGUE,    // soft-min inside the pyramid's volume kernel (0 / 1 forces)
+    DFE_OPT_CONV_BATCH,       // batched LDS-tiled convolution (0: one direct launch per layer and input)
+    DFE_OPT_CONV_NT10,        // 10 output planes per thread where nOut % 10 == 0 (0: two groups of 5)
+    DFE_OPT_FM64,             // one-chunk feature matcher (0: chunk kernel per scale)
+    DFE_OPT_FM_ROWS,          // feature matcher: the row kernels (0 / 1 forces)
+    DFE_OPT_SWEEP_OVH,        // cost model of the persistent column sweep: per-piece overhead in rows
+    DFE_OPT_SWEEP_BLOCKS,     // ... number of blocks
+    DFE_OPT_DEBUG_ARENA,      // print where the scratch arena lands
+    DFE_OPT_FLOW_FINALIZE,
+    DFE_OPT_FM_FLAT,          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)    // 1: per-pixel results finished by flow_finalize_kernel also where the sweep could finish them itself
+    DFE_NOPT
+};
+struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };
+extern const DfeOptName dfe_opt_names[DFE_NOPT];
+
 struct dfe_ctx {
+    int opt[DFE_NOPT];
+    dfe_ctx() { for (int i = 0; i < DFE_NOPT; ++i) opt[i] = -1; }
+    // the launcher's own choice `autov` unless the option was set (>= 0)
+    bool opt_bool(int o, bool autov) const { return opt[o] < 0 ? autov : opt[o] != 0; }
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -69,11 +99,12 @@ struct DfeProfScope {
 
 // brackets the launches of one pipeline stage (DFE_STAGE_*) with events when the stage timers are on
 struct DfeStageScope {
+    static constexpr size_t kMaxStageEvents = 4096;   // event pairs kept until dfe_stage_timers_read collects them
     dfe_ctx *ctx;
     bool rec = false;
     dfe_ctx::StageEvent ev{};
     DfeStageScope(dfe_ctx *c, int stage) : ctx(c) {
-        if (ctx->stage_timers && ctx->stage_depth++ == 0) {
+        if (ctx->stage_timers && ctx->stage_depth++ == 0 && ctx->stage_events.size() < kMaxStageEvents) {   // (unread regions beyond the cap are dropped)
             ev.stage = stage;
             rec = hipEventCreate(&ev.a) == hipSuccess && hipEventCreate(&ev.b) == hipSuccess;
             if (rec) (void)hipEventRecord(ev.a, ctx->stream);
@@ -222,6 +253,9 @@ int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W
                           float cy, float *depth, float *conf);
 int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,
                            bool *handled);
+// 16- / 17-wide windows on feature maps: flat tiles, persistent blocks, LDS-DMA staging (feat_matching_flat.hip)
+int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled);
+bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw);   // the ctx / window conditions of the launcher below
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
                                   int maxw, float *const *out, float f16_scale, bool *handled, const struct CvFineArgs *fine = nullptr);
 int cv_frames_dispatch_fused(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, long long plane, int k, int hWin,

@@ -7,7 +7,6 @@
 // TX x TY pixels and deals its TY * ceil(D/64) (row, chunk) tasks to 8 waves, which keep the 8 accumulators of each of their
 // tasks in registers across the slabs.  Stores are the tiled kernel's 256-B pieces (same store-pattern bound).
 #include "dfe_internal.h"
-#include <cstdlib>
 
 namespace {
 
@@ -331,6 +330,18 @@ __global__ __launch_bounds__(512) void feat_matching_win64_fine_kernel(FmBatch f
 
 }  // namespace
 
+// The ctx- and window-level conditions of dfe_feat_matching_win64_batch (everything but the per-pair sizes): the multiscale launcher
+// plans its fused scales with the SAME predicate the launcher applies, so a plan never meets a refusal (round-3 advisor: with
+// dfe_set_cost_volume_kernel(1) or fm64 = 0 the fused second scale was planned and then refused).
+bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw) {
+    if (maxh * maxw != 64 || K < 1 || K > 16 || ctx->cv_mode == 1 || ctx->opt[DFE_OPT_FM64] == 0) return false;
+    const int tcols = FM_TX + maxw - 1, trows = F64_TY + maxh - 1;
+    if (tcols > 16) return false;                          // (the staging deals 16 columns per tile row)
+    int pitch = tcols;
+    while ((pitch - maxw) % 32 != 0) ++pitch;
+    return (size_t)K * trows * pitch * sizeof(float) <= 64 * 1024;
+}
+
 // n pairs (pyramid scales) of K-plane features through one launch of the one-chunk matcher; out[i] [H1][W1][64] f32, or half volumes
 // (half(cost * f16_scale)) when f16_scale != 0.  *handled = false: not this kernel's shape (the caller launches pair by pair).
 // fine != NULL (n == 1, 8 x 8 windows): no volume -- the pair's task rows go through the fused pyramid epilogue (fine->casc == NULL: the
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(512) void feat_matching_win64_fine_kernel(FmBatch f
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
                                   int maxw, float *const *out, float f16_scale, bool *handled, const CvFineArgs *fine) {
     *handled = false;
-    if (maxh * maxw != 64 || K < 1 || K > 16 || n < 1 || n > DFE_MAX_RATIOS || ctx->cv_mode == 1 || getenv("DFE_NO_FM64")) return DFE_OK;
+    if (!dfe_feat_matching_win64_ok(ctx, K, maxh, maxw) || n < 1 || n > DFE_MAX_RATIOS) return DFE_OK;
     if (fine && (n != 1 || maxh != 8 || maxw != 8 || (fine->pcasc && ((H1[0] | W1[0]) & 1)))) return DFE_OK;
     FmBatch fb;
     int gx = 0, gy = 0;
@@ -393,12 +404,16 @@ int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int
         int rc = dfe_feat_matching_win64_batch(ctx, 1, &in1, &in2, K, &H1, &W1, maxh, maxw, &out, 0.f, handled);
         if (rc != DFE_OK || *handled) return rc;
     }
+    {   // 16- / 17-wide windows on frames at least 253 pixels wide: the flat-tile kernel (feat_matching_flat.hip)
+        int rc = dfe_feat_matching_flat(ctx, in1, in2, K, H1, W1, maxh, maxw, out, handled);
+        if (rc != DFE_OK || *handled) return rc;
+    }
     // The row kernel pays a barrier and a tile refill per plane and only fills its 256-column blocks on wide frames: measured
     // 625 x 465, 16 x 16: K = 32 0.37 ms against 0.55 ms for the chunk kernel below, K = 10 0.168 against 0.194 (with the next plane's
     // loads in flight behind the arithmetic; 0.46 / 0.23 before); K = 10, 293 x 153: 0.064 against 0.039 ms.
     // (W1 == 1: the patch-mode call of the trainers, any K -- the chunk kernel needs 8 x 8 pixels.)
     bool rows_pays = (K >= 8 && W1 >= 400) || W1 < FM_TX || H1 < FM_TY;
-    if (const char *e = getenv("DFE_FM_ROWS")) rows_pays = atoi(e) != 0;   // tuning
+    rows_pays = ctx->opt_bool(DFE_OPT_FM_ROWS, rows_pays);   // tuning
     if (rows_pays && (maxw == 16 || maxw == 8) && maxh >= 4 && maxh <= 16 && ctx->cv_mode != 2 && ((uintptr_t)out & 15) == 0) {
         FmArgs a{};
         a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.maxw = maxw; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;

@@ -1,0 +1,408 @@
+// feat_matching_flat.hip -- nn.SpatialMatching on K-plane FEATURE maps with 16- and 17-wide windows: the matcher behind every trained
+// single-scale model (version2/network.lua:30 SpatialMatching(17, 17) on 32 planes; opticalflow_model.lua:93; tests/time_matching.lua:18
+// SpatialMatching(16, 16) on 10 planes).
+//   out[y][x][dy][dx] = sum_k (in1[k][y][x] - in2[k][y+dy][x+dx])^2,  accumulated over k in order with a separate multiply and add --
+// the arithmetic of the CPU restatement and of every other matcher here: results are bit-identical.
+//
+// Round 3's row kernel (feat_matching.hip: one block = one output row x 256 columns, wave <-> dy, lane <-> 4 pixels x the window row's
+// cells) had the right register tile -- 0.09 LDS reads per output and plane -- and lost its time around it (profiles/r04_a_fm_*.txt:
+// 1.57e8 vector instructions for a minimum of 1.12e8, 45 % of all wave cycles waiting): a third of the lanes idle at 625 columns
+// (3 x 256), a staging loop of per-element index arithmetic, __syncthreads() draining the store queue in front of every barrier of
+// the copy-out, a new block (and an exposed memory round trip) per tile.  This kernel keeps the register tile and changes the rest:
+//   * FLAT TILES: the pixels of the frame are taken in row-major order in groups of PX = 4, a tile is 64 consecutive groups (lane <->
+//     group) and may run over the end of an image row: 1141 tiles instead of 1395 at 625 x 465, no idle lanes.  A tile touches at most
+//     two output rows (frames at least 64 groups wide); the in2 rows it needs sit in LDS as two column pieces per row (A: the end of
+//     row y, B: the start of row y+1), and a lane's window row is at one precomputed offset in them.
+//   * PERSISTENT blocks (one per CU) walk a contiguous range of tiles: the output of consecutive tiles is one contiguous run of memory.
+//   * STAGING by LDS-DMA (global_load_lds_dword): wave <-> tile row, 5 loads per wave and plane with per-lane source offsets that are
+//     computed once per tile; no staging registers, no LDS write pass; plane k+1 is requested before the arithmetic of plane k.
+//   * ONE LDS-only barrier per plane (s_waitcnt lgkmcnt(0); s_barrier) -- never a vmcnt(0) in front of a barrier except for the
+//     plane that was requested a whole plane of arithmetic earlier.
+//   * COPY-OUT through a double-buffered LDS image of 32 pixels' windows (a contiguous run of the output, congruent to the global float
+//     index mod 32): whole 128-B lines, fire-and-forget, one LDS-only barrier per phase; the stores of a tile drain behind the
+//     arithmetic of the next.
+//   * 17 WINDOW ROWS on 16 waves (version2's 17 x 17): wave w sweeps window row w for its lanes' 4 pixels (68 accumulators) and, as an
+//     EXTRA task, row 16 for the 16 pixels of lanes 4w .. 4w+3 (lane <-> (pixel, 4-cell group): 5 accumulators, 15 vector
+//     instructions a plane next to the main task's 204) -- the seventeenth row costs 7 % instead of a second round.
+#include "dfe_internal.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int FF_PX = 4;                     // pixels per lane
+constexpr int FF_GROUPS = 64;                // groups (lanes) per tile
+constexpr int FF_PHL = 8;                    // lanes per copy-out phase
+constexpr int FF_NPH = FF_GROUPS / FF_PHL;   // copy-out phases per tile
+#ifndef FF_ABLATE
+#define FF_ABLATE 0   // tuning (side builds only): 1 no staging requests, 2 no barrier in the plane loop, 4 no copy-out stores, 8 no copy-out at all,
+                      // 16 no arithmetic
+#endif
+#ifndef FF_BATCH
+#define FF_BATCH 8                           // (pixel, cell) pairs whose differences / squares / adds are issued as three groups
+#endif
+template <int I, int N, class F> __device__ __forceinline__ void static_for_q(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_q<I + 1, N>(f);
+    }
+}
+
+typedef float ff_f4 __attribute__((ext_vector_type(4)));
+// LDS pointers keep their address space (32-bit arithmetic, ds_ instructions with immediate offsets): through generic pointers the
+// compiler carried 64-bit lane addresses across the plane loop
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(3))) ff_f4 lds_f4;
+typedef __attribute__((address_space(3))) void *ff_lds_ptr;
+typedef const __attribute__((address_space(1))) void *ff_gbl_ptr;
+
+struct FfArgs {
+    const float *in1, *in2;
+    float *out;
+    int K, H1, W1, maxh, H2, W2;
+    int G;            // groups per image row = ceil(W1 / PX)
+    int NG;           // H1 * G
+    int ntiles;       // ceil(NG / 64)
+};
+
+template <int MW> struct FfGeom {
+    static constexpr int PITCH = (64 * FF_PX + 2 * (MW - 1) + 8 + 3) / 4 * 4;   // floats per LDS tile row (piece A | piece B)
+    static constexpr int NLOAD = (PITCH + 63) / 64;                             // LDS-DMA loads per tile row
+    static constexpr int NB4 = (FF_PX + MW - 1 + 3) / 4;                        // b128 reads of a lane's window row
+};
+
+extern __shared__ __attribute__((aligned(128))) float ff_smem[];
+
+// One LDS-DMA load of 64 floats: lane l fetches the float at sbase + voff (bytes; its own offset) into LDS at lds_dst + 4 l.
+// Written as assembly for the addressing form: scalar base + 32-bit vector offset -- through the builtin the compiler built a 64-bit
+// address per lane and load (two more registers live at every request, in a kernel that has none to spare).  M0 (the destination
+// base) is the compiler's: saved and restored around the instruction (cdna_hip_programming.md, LDS-DMA recipe).
+__device__ __forceinline__ void ff_glds16(unsigned voff, const void *sbase, const lds_f *lds_dst) {   // 16 bytes per lane: LDS at lds_dst + 16 l
+    const unsigned la = (unsigned)(size_t)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
+}
+__device__ __forceinline__ void ff_glds4(unsigned voff, const void *sbase, const lds_f *lds_dst) {
+    const unsigned la = (unsigned)(size_t)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
+}
+
+// maxh <= 16: waves 0 .. maxh-1 each sweep one window row.  EXTRA (maxh == 17): 16 waves, row 16 as the extra task.
+template <int MW, bool EXTRA>
+__global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
+#pragma clang fp contract(off)
+    constexpr int PX = FF_PX;
+    constexpr int PITCH = FfGeom<MW>::PITCH, NLOAD = FfGeom<MW>::NLOAD, NB4 = FfGeom<MW>::NB4;
+    const int NW = EXTRA ? 16 : p.maxh;                    // waves of the block = blockDim.x / 64
+    const int nrows = p.maxh + 1;                          // in2 rows of a tile: y_first .. y_first + maxh
+    const int WN = p.maxh * MW;                            // floats per window
+    // LDS: [3][nrows][PITCH] tile | [3][256] in1 pieces | [64] lane offsets (extra task) | [64] pixel index of a group | [2][IMG] images
+    lds_f *tile = (lds_f *)ff_smem;
+    lds_f *abuf = tile + 3 * nrows * PITCH;
+    lds_i *gtab = (lds_i *)(abuf + 3 * 64 * PX);
+    lds_i *prtab = gtab + 64;
+    const int IMG = (FF_PHL * PX * WN + 32 + 31) / 32 * 32;
+    lds_f *img = (lds_f *)(prtab + 64);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dy = wave;
+    const long long plane1 = (long long)p.H1 * p.W1, plane2 = (long long)p.H2 * p.W2;
+    // Tiles of this block: tile (round r, virtual block vb) = r * gridDim.x + vb, where the virtual index puts the 32 blocks of an XCD
+    // (the hardware deals linear block ids round-robin to the 8 XCDs) on 32 CONSECUTIVE tiles -- about 13 output rows of the frame,
+    // all planes of whose in2 rows (2.4 MB) stay in that XCD's 4-MB L2 while its CUs, in step with each other, walk through the planes.
+    // (First version: a contiguous range of tiles per block -- the tiles in flight were spread over the whole frame, 76 % of the
+    //  L2 requests missed, 790 MB were fetched for 39 MB of in2 and every plane waited out a memory round trip: r04_g, r04_j.)
+    const int nbx = gridDim.x, per_xcd = nbx >> 3;
+    const int vb = (nbx & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+
+    for (int t = vb; t < p.ntiles; t += nbx) {
+        // ---- tile geometry (wave-uniform scalars, then per-lane offsets) ----
+        const int g0 = t * FF_GROUPS;
+        const int y_first = g0 / p.G, xgA0 = g0 - y_first * p.G, xA0 = xgA0 * PX;
+        const int nA = min(FF_GROUPS, p.G - xgA0);                        // groups of the tile in row y_first
+        const int LA = min(p.W2 - xA0, FF_GROUPS * PX + MW - 1);          // columns of piece A
+        const int LA_pad = (LA + 3) & ~3;
+        // (per-lane geometry is derived from a laundered lane id where it is used -- here for the LDS offsets, again in the copy-out --
+        //  so that nothing but boff and the five source offsets is live across the plane loop: the 17 x 17 kernel has no register to spare)
+        auto lane_fresh = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+        int boff;
+        unsigned voff16[2];     // byte offsets (from the start of an in2 row) of my 16-B pieces of a tile row: piece 4 (l + 64 m) .. + 3
+        {
+            const int l = lane_fresh();
+            const int isB = l >= nA ? 1 : 0;
+            const int x = isB ? (l - nA) * PX : xA0 + l * PX;             // first pixel column of my group
+            const int xin = isB ? LA_pad + x : x - xA0;                   // ... inside its tile row (piece A | piece B)
+            boff = (dy + isB) * PITCH + xin;                              // my window row in the LDS tile (floats)
+            if (wave == 0) {
+                gtab[l] = isB * PITCH + xin;
+                // pixel index of the group relative to the tile's first pixel (the output of a tile is one contiguous run)
+                prtab[l] = g0 + l < p.NG ? (isB ? p.W1 - xA0 + x : x - xA0) : -1;
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c = 4 * (l + 64 * m);                           // (LA_pad is a multiple of 4: a piece of 4 floats lies in A or in B)
+                voff16[m] = 4u * (unsigned)(c < LA_pad ? xA0 + c : c - LA_pad);
+            }
+        }
+        // Staging by LDS-DMA, wave <-> tile row (the rows behind the waves and the in1 piece are dealt to the first waves): 16 bytes per
+        // lane -- two instructions for a tile row of 296 floats, one for the in1 piece.  (First version: dword loads, five per row.)
+        // A 16-B piece is not clamped at the end of its image row: it may read up to 3 floats of the NEXT row, which no valid pixel
+        // uses.  Where that would leave the buffer -- the last row of the last plane -- the row is staged float by float, clamped.
+        // Everything a request needs is a per-tile scalar (row pointers of plane 0, LDS offsets) + k * plane size: the barrier puts the
+        // sixteen waves in phase, so scalar work at the top of a plane is not hidden behind other waves' arithmetic -- the first version
+        // recomputed its row pointers with 64-bit multiplies per plane, ~70 scalar instructions a wave, and a plane took 2900 cycles
+        // where arithmetic and requests by themselves take 2100 and 1650 (r04_n).
+        const int padpx = p.G * PX - p.W1;
+        const int j1 = wave + NW;                                         // my second task: a row, the in1 piece (j1 == nrows) or none
+        const int yr0 = min(y_first + wave, p.H2 - 1), yr1 = min(y_first + j1, p.H2 - 1);
+        const char *rp0 = reinterpret_cast<const char *>(p.in2) + (long long)yr0 * p.W2 * 4;
+        const char *rp1 = j1 < nrows ? reinterpret_cast<const char *>(p.in2) + (long long)yr1 * p.W2 * 4
+                                     : reinterpret_cast<const char *>(p.in1) + ((long long)y_first * p.W1 + xA0) * 4;
+        const long long pstep0 = plane2 * 4, pstep1 = (j1 < nrows ? plane2 : plane1) * 4;
+        const bool last0 = yr0 == p.H2 - 1, last1 = j1 < nrows ? yr1 == p.H2 - 1 : y_first + 2 >= p.H1;   // may end at the end of the buffer (plane K-1)
+        unsigned voff_a = 0;                                              // my 16-B piece of the in1 slots
+        if (j1 == nrows) { const int l = lane_fresh(); voff_a = 4u * (unsigned)(4 * l - (l >= nA ? padpx : 0)); }
+        auto stage_row = [&](const char *rowp, lds_f *dst, bool careful) {
+            if (careful) {                                                // (wave-uniform, once per frame)
+#pragma unroll
+                for (int m = 0; m < NLOAD; ++m) {
+                    const int c = lane_fresh() + 64 * m;
+                    if (c < PITCH) ff_glds4(4u * (unsigned)(c < LA_pad ? min(xA0 + c, p.W2 - 1) : min(c - LA_pad, p.W2 - 1)), rowp, dst + 64 * m);
+                }
+            } else {
+                ff_glds16(voff16[0], rowp, dst);
+                if (4 * (lane + 64) < PITCH) ff_glds16(voff16[1], rowp, dst + 256);
+            }
+        };
+        auto stage = [&](int k, int buf) {
+            lds_f *tb = tile + buf * nrows * PITCH;
+            stage_row(rp0 + k * pstep0, tb + wave * PITCH, last0 && k == p.K - 1);
+            if (j1 < nrows) {
+                stage_row(rp1 + k * pstep1, tb + j1 * PITCH, last1 && k == p.K - 1);
+            } else if (j1 == nrows) {
+                // the in1 values of the tile's 256 pixel slots (group l, pixel q at slot 4 l + q): row y_first from xA0, then row
+                // y_first + 1 from column 0 -- linear in memory except for the W1p - W1 padding slots at the end of row y_first
+                const char *src1 = rp1 + k * pstep1;
+                if (last1 && k == p.K - 1) {
+                    const int lim = (int)plane1 - 1 - (y_first * p.W1 + xA0);
+#pragma unroll
+                    for (int m = 0; m < PX; ++m) {
+                        const int e = lane_fresh() + 64 * m;
+                        ff_glds4(4u * (unsigned)min(e - (e >= nA * PX ? padpx : 0), lim), src1, abuf + buf * 64 * PX + 64 * m);
+                    }
+                } else {
+                    ff_glds16(voff_a, src1, abuf + buf * 64 * PX);
+                }
+            }
+        };
+
+        float acc[PX][MW];
+#pragma unroll
+        for (int q = 0; q < PX; ++q)
+#pragma unroll
+            for (int d = 0; d < MW; ++d) acc[q][d] = 0.f;
+        // extra task (EXTRA): lane e <-> pixel e >> 2 of the 16 pixels of groups 4 wave .. 4 wave + 3, cells 4 (e & 3) .. + 4 (cell 16 on e & 3 == 3)
+        float accx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        int xoff_b = 0;
+
+        // Three tile buffers, requests two planes ahead, and the LDS reads of plane k+1 issued BEHIND the arithmetic of plane k, in front
+        // of the barrier: with two buffers every wave read its operands right behind the barrier, i.e. all sixteen waited out the LDS
+        // latency together, once per plane, with nothing to cover it (first version: 3000 cycles per plane against 1920 of arithmetic).
+        // What crosses the barrier in registers is kept small: the in1 pixels and the first 16 floats of the window row (4 b128 reads);
+        // the row's last b128 and the extra task's six operands are read at the top of the plane and used by the arithmetic that comes
+        // last (the pairs q + d >= 16, then the extra task), behind ~150 instructions that cover their latency.
+        static_assert(NB4 == 5, "16- / 17-wide windows, 4 pixels per lane: 19 / 20 floats of the window row");
+        float b[4 * NB4], ax = 0.f, bx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        ff_f4 a4;
+        auto read_head = [&](int buf) {
+            a4 = *(const lds_f4 *)(abuf + buf * 64 * PX + PX * lane);
+            const lds_f4 *br = (const lds_f4 *)(tile + buf * nrows * PITCH + boff);
+#pragma unroll
+            for (int j = 0; j < NB4 - 1; ++j) {
+                const ff_f4 v = br[j];
+                b[4 * j] = v[0]; b[4 * j + 1] = v[1]; b[4 * j + 2] = v[2]; b[4 * j + 3] = v[3];
+            }
+        };
+        auto read_tail = [&](int buf) {
+            const lds_f *bt = tile + buf * nrows * PITCH;
+            const ff_f4 v = ((const lds_f4 *)(bt + boff))[NB4 - 1];
+            b[16] = v[0]; b[17] = v[1]; b[18] = v[2]; b[19] = v[3];
+            if constexpr (EXTRA) {
+                ax = abuf[buf * 64 * PX + 16 * wave + (lane >> 2)];     // (slot of pixel (lane >> 2) & 3 of group 4 wave + (lane >> 4))
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bx[j] = bt[xoff_b + j];
+            }
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tables are in LDS
+        if constexpr (EXTRA) {
+            const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), q = pp & 3, c = lane & 3;
+            xoff_b = gtab[lg] + 16 * PITCH + q + 4 * c;
+        }
+        // ONE loop over kk = 0 .. K+1: iteration kk requests plane kk, does the arithmetic of plane kk-2 and reads the operands of plane
+        // kk-1 (the two fill iterations included, so that the staging code exists once: inlined three times it cost 40 spilled scalars)
+        int bs = 0;                                                       // kk % 3
+        for (int kk = 0; kk < p.K + 2; ++kk) {
+            const int bc = bs == 2 ? 0 : bs + 1;                          // (kk - 2) % 3: the plane of this iteration's arithmetic
+            const int bp = bs == 0 ? 2 : bs - 1;                          // (kk - 1) % 3: complete since the previous barrier
+            read_tail(bc);                                                // (kk < 2: nothing there yet, nothing is computed from it)
+            if (kk < p.K && !(FF_ABLATE & 1)) stage(kk, bs);
+            __builtin_amdgcn_sched_barrier(0);
+            // the (pixel, cell) pairs in batches of FF_BATCH: all differences, then all squares, then all adds
+            auto pairs = [&](auto first_part) {
+                constexpr bool FIRST = decltype(first_part)::value;
+                static_for_q<0, PX>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr int dlo = FIRST ? 0 : (16 - q < MW ? 16 - q : MW), dhi = FIRST ? (16 - q < MW ? 16 - q : MW) : MW;
+                    static_for_q<0, (dhi - dlo + FF_BATCH - 1) / FF_BATCH>([&](auto bc) {
+                        constexpr int d0 = dlo + decltype(bc)::value * FF_BATCH, n = (dhi - d0 < FF_BATCH) ? dhi - d0 : FF_BATCH;
+                        float df[n > 0 ? n : 1];
+#pragma unroll
+                        for (int i = 0; i < n; ++i) df[i] = a4[q] - b[q + d0 + i];
+#pragma unroll
+                        for (int i = 0; i < n; ++i) df[i] = df[i] * df[i];
+#pragma unroll
+                        for (int i = 0; i < n; ++i) acc[q][d0 + i] = acc[q][d0 + i] + df[i];
+                    });
+                });
+            };
+            if (kk >= 2 && !(FF_ABLATE & 16)) {
+                pairs(std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                pairs(std::false_type{});
+                if constexpr (EXTRA) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        const float df = ax - bx[j];
+                        accx[j] = accx[j] + df * df;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_head(bp);     // (unconditional -- in the first and the last iteration the values are not used -- so that the operands stay
+                               //  in ONE register set: with the read under a condition the compiler kept two sets and 20 moves per plane)
+            // my requests of plane kk have landed; behind the barrier everyone's have, and every wave is past its reads of plane kk-3
+            if (FF_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            bs = bs == 2 ? 0 : bs + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // ---- copy-out: FF_NPH phases of FF_PHL lanes (32 pixel slots) through the double-buffered image ----
+        const long long tile_px0 = (long long)y_first * p.W1 + xA0;       // first pixel of the tile (row-major pixel index)
+        for (int ph = 0; ph < ((FF_ABLATE & 8) ? 0 : FF_NPH); ++ph) {
+            const int l0 = ph * FF_PHL;
+            const int pr0 = prtab[l0];                                    // wave-uniform (same address); -1: the phase is empty
+            if (pr0 < 0) break;                                           // (block-uniform: groups are valid up to NG)
+            int lastl = l0 + FF_PHL - 1;
+            // pixels of the phase: from group l0's first to the last valid pixel of its last valid group
+            int prl = prtab[lastl];
+            while (prl < 0) prl = prtab[--lastl];                         // (uniform; at most FF_PHL - 1 steps, last tile only)
+            const int lastx = (lastl >= nA ? (lastl - nA) * PX : xA0 + lastl * PX);
+            const int npx = prl - pr0 + min(PX, p.W1 - lastx);
+            const long long G0 = (tile_px0 + pr0) * WN;                   // global float index of the phase's run
+            const int a0 = (int)(G0 & 31);
+            lds_f *im = img + (ph & 1) * IMG + a0;
+            const int lc = lane_fresh();
+            const int prc = prtab[lc];
+            if (lc >= l0 && lc < l0 + FF_PHL && prc >= 0) {
+                const int x = lc >= nA ? (lc - nA) * PX : xA0 + lc * PX;
+                lds_f *w = im + (prc - pr0) * WN + dy * MW;
+#pragma unroll
+                for (int q = 0; q < PX; ++q)
+                    if (x + q < p.W1) {
+                        if constexpr (MW % 4 == 0) {
+                            // (WN, MW multiples of 4 and a0 a multiple of 4 when G0 is: 16-B aligned pieces)
+#pragma unroll
+                            for (int d = 0; d < MW; d += 4) *(lds_f4 *)(w + q * WN + d) = ff_f4{acc[q][d], acc[q][d + 1], acc[q][d + 2], acc[q][d + 3]};
+                        } else {
+#pragma unroll
+                            for (int d = 0; d < MW; ++d) w[q * WN + d] = acc[q][d];
+                        }
+                    }
+            }
+            if constexpr (EXTRA) {
+                // window row 16 of the phase's pixels: the extra tasks of waves 2 ph, 2 ph + 1 (groups 4 wave .. 4 wave + 3)
+                if ((wave >> 1) == ph) {
+                    const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), q = pp & 3, c = lane & 3;
+                    const int prg = prtab[lg];
+                    const int xg = lg >= nA ? (lg - nA) * PX : xA0 + lg * PX;
+                    if (prg >= 0 && xg + q < p.W1) {
+                        lds_f *w = im + (prg + q - pr0) * WN + 16 * MW + 4 * c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = accx[j];
+                        if (c == 3) w[4] = accx[4];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // whole 128-B lines as dwordx4 bursts; the run's partial head / tail lines float by float (completed by the neighbouring
+            // phase, which this block writes next or has just written, or by the block that owns the neighbouring tile)
+            const int nfl = npx * WN;
+            const int head = min((32 - a0) & 31, nfl);
+            const int nbody4 = (nfl - head) >> 2 & ~7;                    // float4 pieces in whole lines
+            float *gout = p.out + G0;
+            const lds_f4 *sb = (const lds_f4 *)(im + head);
+            const char *gb = reinterpret_cast<const char *>(gout + head);
+            const int nthr = NW * 64;
+            for (int i0 = 0; i0 < nbody4; i0 += 4 * nthr) {
+                ff_f4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = sb[min(i0 + u * nthr + (int)threadIdx.x, nbody4 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * nthr + (int)threadIdx.x;
+                    if (i < nbody4 && !(FF_ABLATE & 4)) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"((unsigned)i * 16u), "v"(v[u]), "s"(gb) : "memory");
+                }
+            }
+            const int tail0 = head + (nbody4 << 2);
+            if (wave == 0 && lane < head) gout[lane] = im[lane];
+            if (wave == NW - 1) {
+                for (int i = tail0 + lane; i < nfl; i += 64) gout[i] = im[i];
+            }
+        }
+        // the next tile's tables and first plane overwrite what the last phases may still read: every wave is past its reads here
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+}  // namespace
+
+// *handled stays false when the shape is not this kernel's (the caller goes on to the round-3 kernels)
+int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled) {
+    *handled = false;
+    if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || ctx->opt[DFE_OPT_FM_FLAT] == 0) return DFE_OK;
+    if (maxw != 16 && maxw != 17) return DFE_OK;
+    if (maxh < 4 || maxh > 17 || (maxh == 17 && maxw != 17)) return DFE_OK;
+    const int G = dfe_cdiv(W1, FF_PX);
+    if (G < FF_GROUPS || K < 1 || H1 < 1) return DFE_OK;                   // (a tile must not touch more than two image rows)
+    if (((uintptr_t)in1 | (uintptr_t)in2 | (uintptr_t)out) & 3) return DFE_OK;
+    const long long NGl = (long long)H1 * G;
+    if (NGl > (1ll << 30) || (long long)H1 * W1 * maxh * maxw >= (1ll << 40)) return DFE_OK;
+    FfArgs a{};
+    a.in1 = in1; a.in2 = in2; a.out = out;
+    a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;
+    a.G = G; a.NG = (int)NGl; a.ntiles = dfe_cdiv(NGl, FF_GROUPS);
+    const bool extra = maxh == 17;
+    const int NW = extra ? 16 : maxh;
+    const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
+    const int WN = maxh * maxw;
+    const int IMG = (FF_PHL * FF_PX * WN + 32 + 31) / 32 * 32;
+    const size_t lds = ((size_t)3 * (maxh + 1) * PITCH + 3 * 64 * FF_PX + 128 + (size_t)2 * IMG) * sizeof(float);
+    if (lds > 160 * 1024) return DFE_OK;
+    void (*kern)(FfArgs) = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
+                                      : feat_matching_flat_kernel<16, false>;
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), lds, ctx->stream, a);
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = "feat_matching_flat_kernel";
+    *handled = true;
+    return DFE_OK;
+}

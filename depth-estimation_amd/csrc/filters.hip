@@ -230,7 +230,7 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
     bool same = true;
     for (int e = 1; e < n; ++e)
         same = same && L[e]->nIn == L0.nIn && L[e]->nOut == L0.nOut && L[e]->kH == L0.kH && L[e]->kW == L0.kW && L[e]->tanh_after == L0.tanh_after && !L[e]->conn;
-    if (same && !L0.conn && !getenv("DFE_NO_CONV_BATCH")) {
+    if (same && !L0.conn && ctx->opt[DFE_OPT_CONV_BATCH] != 0) {
         ConvBatch cb;
         int maxblocks = 0;
         bool ok = true;
@@ -241,7 +241,7 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
             const int b = dfe_cdiv(W[e] - L0.kW + 1, CB_TW) * dfe_cdiv(H[e] - L0.kH + 1, CB_TH);
             if (b > maxblocks) maxblocks = b;
         }
-        const int nt = L0.nOut % 8 == 0 ? 8 : (L0.nOut % 10 == 0 && !getenv("DFE_CONV_NT5")) ? 10 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
+        const int nt = L0.nOut % 8 == 0 ? 8 : (L0.nOut % 10 == 0 && ctx->opt[DFE_OPT_CONV_NT10] != 0) ? 10 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
         bool done = false;
 #define DFE_CB(KWV)                                                                                                                       \
     if (L0.kW == KWV) {                                                                                                                   \
@@ -297,7 +297,7 @@ int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weig
                 "dfe_spatial_convolution_f32: %d->%d planes, %dx%d kernel on %dx%d", nIn, nOut, kH, kW, H, W);
     // the LDS-tiled kernel where it has an instantiation (same accumulation order, separately rounded multiply and add: bit-identical
     // to conv_kernel -- 17 x 17, 3 -> 32 planes at VGA: 1.84 -> 0.36 ms)
-    if (ctx->cv_mode != 1 && !getenv("DFE_NO_CONV_BATCH")) {
+    if (ctx->cv_mode != 1 && ctx->opt[DFE_OPT_CONV_BATCH] != 0) {
         dfe_filter_layer L{};
         L.weight = weight; L.bias = bias; L.nIn = nIn; L.nOut = nOut; L.kH = kH; L.kW = kW;
         const dfe_filter_layer *Lp = &L;

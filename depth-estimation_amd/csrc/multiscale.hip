@@ -1069,7 +1069,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     bool px_path = fast && maxh == 8 && maxw == 8;
     for (int s = 0; s < nratios; ++s)
         if (ratios[s] != (1 << s) || (s > 0 && g.d[s] != 2)) px_path = false;   // (ring width 2: the kernel's compile-time class order)
-    if (const char *e = getenv("DFE_CASCADE_PX")) px_path = px_path && atoi(e) != 0;
+    px_path = px_path && ctx->opt[DFE_OPT_CASCADE_PX] != 0;
     // raw patches, 3 channels, 7 x 7, on the lane <-> pixel path: the finest scale is fused into its volume kernel (no volume)
     // -- where it pays: the fused kernel is VALU-bound (three 64-lane reductions per pixel), the volume it saves is HBM traffic that the
     // small frames hide behind the coarse scales' launches.  Measured, volume path -> fused: VGA 0.076 -> 0.099 ms, 720p 0.213 ->
@@ -1081,12 +1081,12 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     bool fine_shape = C == 3 && k == 7;
     if (filt) {
         fK = filt->layers[filt->nlayers - 1].nOut;
-        fine_shape = fK >= 1 && fK <= 16;
+        fine_shape = dfe_feat_matching_win64_ok(ctx, fK, maxh, maxw);   // the launcher's own conditions (cv_mode, fm64, K, LDS)
         for (int s = 1; s < nratios && !filt->share; ++s) fine_shape = fine_shape && filt->layers[s * filt->nlayers + filt->nlayers - 1].nOut == fK;
     }
     // (learned filters, volume path -> fused: VGA 0.193 -> 0.183 ms, 1080p 1.064 -> 0.912: the matcher's launch is long enough at VGA already)
     bool try_fine = px_path && fine_shape && (long long)H * W >= (filt ? 250000ll : f16_scale != 0.f ? 3000000ll : 600000ll);
-    if (const char *e = getenv("DFE_FINE_FUSE")) try_fine = px_path && fine_shape && atoi(e) != 0;
+    if (ctx->opt[DFE_OPT_FINE_FUSE] >= 0) try_fine = px_path && fine_shape && ctx->opt[DFE_OPT_FINE_FUSE] != 0;
     // the second scale the same way (its volume, 21 % of the rest, is otherwise written by the volume kernel and read back by its
     // cascade launch): wherever the finest scale is fused and a coarser scale exists above it.  DFE_MID_FUSE=0 / 1 forces the choice.
     // Measured, finest scale fused -> both: 1080p 0.363 -> 0.346 ms, 4K 1.40 -> 1.29; 720p 0.179 -> 0.205 (230 k pixels: one partial round
@@ -1094,7 +1094,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     const bool mid_shape = nratios >= 3 && (filt ? (H / ratios[1] >= 16 && W / ratios[1] >= 8 && ((H / ratios[1]) | (W / ratios[1])) % 2 == 0)
                                                  : cv_finest_plan_ok(ctx, H / ratios[1] + k - 1 + maxh - 1, W / ratios[1] + k - 1 + maxw - 1, maxh, maxw));
     bool try_mid = try_fine && f16_scale == 0.f && (long long)H * W >= 1500000ll && mid_shape;
-    if (const char *e = getenv("DFE_MID_FUSE")) try_mid = try_fine && atoi(e) != 0 && mid_shape;
+    if (ctx->opt[DFE_OPT_MID_FUSE] >= 0) try_mid = try_fine && ctx->opt[DFE_OPT_MID_FUSE] != 0 && mid_shape;
     const int s0 = try_mid ? 2 : try_fine ? 1 : 0;      // the first scale whose volume is materialised
     if (!filt) {
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
@@ -1105,7 +1105,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         // (tried: the finest scale's padded frames made on a second stream next to the coarse scales' chain, forked here and joined in
         //  front of the fused kernel, which alone reads them -- 720p 0.178 -> 0.190 ms, 1080p 0.347 -> 0.348, 4K 1.27 -> 1.31: the
         //  frames are read twice and the cross-stream waits cost more than the overlap gives)
-        if (pow2 && (long long)H * W >= 1500000 && !getenv("DFE_NO_PREP_TILES")) {       // every scale from one read of the frames
+        if (pow2 && (long long)H * W >= 1500000 && ctx->opt[DFE_OPT_PREP_TILES] != 0) {       // every scale from one read of the frames
             PrepTile pq;
             pq.ns = nratios;
             for (int s = 0; s < nratios; ++s) { pq.r[s] = ps.r[s]; pq.Hp[s] = ps.Hp[s]; pq.Wp[s] = ps.Wp[s]; pq.p[0][s] = ps.p0[s]; pq.p[1][s] = ps.p1[s]; }

@@ -226,7 +226,7 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 // 2 waves x 4 columns spill (24 registers of ring state).
 #define DFE_NQW 4
 #endif
-#define DFE_CV_KERNEL_REV "cv-r3.7"
+#define DFE_CV_KERNEL_REV "cv-r4.1"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
 #endif
@@ -245,6 +245,13 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #else
 #define DFE_TL(i) do { } while (0)
 #endif
+// -DDFE_MARKERS=1 (tools/isa_regions.py, no product build): assembler comments at the phase boundaries of the row loop, so that the ISA
+// between them can be counted by class (VALU / v_readlane / LDS / ...) per phase
+#if defined(DFE_MARKERS) && DFE_MARKERS
+#define DFE_MARK(name) asm volatile("; DFE_MARK " name)
+#else
+#define DFE_MARK(name) do { } while (0)
+#endif
 #ifndef DFE_LEAD_FROM_IMAGE
 #define DFE_LEAD_FROM_IMAGE 1
 #endif
@@ -262,6 +269,14 @@ __device__ unsigned long long dfe_tl[2][16][256][8];
 #endif
 #ifndef DFE_SCAN_AFTER_COPY
 #define DFE_SCAN_AFTER_COPY 0   // tuning: the fused arg-min scan behind the copy-out instead of in front of it
+#endif
+#ifndef DFE_SCAN_SIDX
+#define DFE_SCAN_SIDX 0   // fused scan: the winning lane's first cell found on the scalar unit (1) or by per-lane select chains + v_readlane (0).
+                          // Measured in one call (r04_c): 1 is 0.5 % SLOWER at VGA and 0.3 % at 1080p -- 8 fewer vector instructions, but a serial
+                          // chain of 8 compare -> scalar test pairs on the scan waves' path to the barrier
+#endif
+#ifndef DFE_COPY_FAST
+#define DFE_COPY_FAST 1   // copy-out of whole runs: unclamped pieces addressed by one lane offset + scalar bases (0: every piece clamped and compared)
 #endif
 #ifndef DFE_CW0
 #define DFE_CW0 5    // row-image kernel: first wave that takes part in the copy-out (0 = all waves)
@@ -905,6 +920,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     constexpr bool ROLES = FUSE && (SWEEP || DFE_ROLES_STATIC) && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
     // the last wave neither scans nor copies: in the column sweep it refills the rings, with roles it carries the mini task
     constexpr bool HAS_XW = SWEEP || ROLES;
+    // (Which SIMD carries what, wave w on SIMD w % 4: every SIMD has one quarter-task + scan wave (0 .. 3) and one plain scan wave (4 .. 7);
+    //  SIMD 3 also has wave 15 with the mini task and the ring refill, ~93 vector instructions a row on top of its main task
+    //  (tools/isa_regions.py).  Round 4 tried pixel 7's scan on wave 8 (SIMD 0) with wave 7 copying instead: no difference, r04_d.)
     constexpr int QW0 = 0;                       // first wave with a quarter task (on the copy waves, 8..11, instead: 265 against 258 us)
     static_assert(NE <= 16, "row_newbcast reaches 16 positions");
     static_assert(TX % NQW == 0, "whole columns per quarter task");
@@ -1169,6 +1187,24 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         // any of its lanes attains it
         const unsigned long long m0 = __builtin_amdgcn_ballot_w64(b0 == vmin);
         int idx;
+#if DFE_SCAN_SIDX
+        // The first cell of the first lane that attains the minimum.  Only that lane's answer is wanted, so the search is scalar: one
+        // compare per cell into a lane mask, bit f of it tested on the scalar unit -- 8 vector instructions instead of 8 compares + 8
+        // selects + a v_readlane (round 4: the scan waves are as close to the row's critical path as the copy waves).
+        if (m0) {
+            const int f = __builtin_ctzll(m0);
+            int i0 = CPL - 1;
+#pragma unroll
+            for (int i = CPL - 2; i >= 0; --i) i0 = ((__builtin_amdgcn_ballot_w64(c0[i] == vmin) >> f) & 1) ? i : i0;
+            idx = f * CPL + i0;
+        } else {
+            const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == vmin));
+            int i1 = CPL - 1;
+#pragma unroll
+            for (int i = CPL - 2; i >= 0; --i) i1 = ((__builtin_amdgcn_ballot_w64(c1[i] == vmin) >> f) & 1) ? i : i1;
+            idx = (64 + f) * CPL + i1;
+        }
+#else
         if (m0) {
             int i0 = CPL - 1;
 #pragma unroll
@@ -1182,6 +1218,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(b1 == vmin));
             idx = (64 + f) * CPL + __builtin_amdgcn_readlane(i1, f);
         }
+#endif
         // The pixel's minimum, first index and centre cost go into the tile row's RECORD in LDS (8 x (min, idx) | 8 x centre | 0 ...);
         // behind the NEXT barrier one wave writes the 128-B record out whole (write_record below).  Until round 3 every scan wave
         // stored its pixel's entries into three planes itself: two 8-B entries, 64 B of lead cells, 4 B of centre per pixel and row
@@ -1354,10 +1391,14 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             };
             // (order of a wave's tasks within a row: the latency-bound extra tasks in front of the main task -- so that they run
             //  while the SIMD's other waves are busy, instead of alone behind them -- measured +-1 %)
+            DFE_MARK("main");
             do_main();
             DFE_TL(2);
+            DFE_MARK("quarter");
             do_quarter();
+            DFE_MARK("mini");
             do_mini();
+            DFE_MARK("barrier");
             DFE_TL(3);
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
@@ -1367,6 +1408,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // (The column sweep needs it in the warm-up rows too: it also frees the tile row the sweep has just left.)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 DFE_TL(4);
+                DFE_MARK("refill");
                 if constexpr (SWEEP) {
                     if (wave == LW && !(DFE_ABLATE & 131072)) {
                         // Stream the rings: the pixels requested one row step ago go into the slots of the rows the sweep
@@ -1398,6 +1440,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         }
                     }
                 }
+                DFE_MARK("record+scan");
                 if constexpr (ROLES) {
                     // (row r-1's record is complete: every scan wave has passed this barrier; its buffer is rewritten by the scan of
                     //  row r+1, behind the next barrier)
@@ -1409,6 +1452,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     if (store_row) scan_row(st, pg_run);
                 }
                 DFE_TL(5);
+                DFE_MARK("copy");
                 // Copy-out by the waves WITHOUT an extra task (DFE_CW0.., 10 or 11 of them): a CU's vector-memory path takes 64 B
                 // per clock, i.e. ~545 cycles for the 34 848 B of a row, and every wave that stores waits its turn in it.  With all
                 // waves copying, the four quarter-task waves -- the critical path of the sweep -- started the next row up to 0.2 us
@@ -1466,6 +1510,29 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     // these (scan arithmetic after the stores: +3 %; before them: no change).
                     constexpr int NPC = ((TX * 1096 + 32) / 4 + STR - 1) / STR;   // pieces per thread (3 with 15 copier waves, 4 with 10)
                     constexpr int GP = NPC <= 4 ? NPC : 6;                        // pieces in flight per thread
+                    // A run that is stored whole (every tile but a shifted last one) has at least ((8 * 1089 - 31) >> 5) << 3 = 2168 pieces in whole
+                    // lines: the first NFULL pieces of every thread are inside whatever the run's alignment.  Those need no clamp, no compare and
+                    // no execution mask, and their addresses are ONE per-lane offset (16 tj) next to per-piece LDS immediates and per-piece scalar
+                    // bases (SALU) -- 2 vector instructions per thread and row instead of 5 per piece (round 4: the copy waves' address
+                    // arithmetic was 30 of their 55 VALU per row, tools/isa_regions.py).
+                    constexpr int NFULL = (DFE_COPY_FAST && CG && !F16) ? ((2168 / STR < NPC - 1) ? 2168 / STR : NPC - 1) : 0;
+                    if (NFULL > 0 && nover == 0) {   // block-uniform
+                        const unsigned vo = (unsigned)tj * 16u;
+                        const char *sbb = reinterpret_cast<const char *>(sb) + vo;
+                        const char *gbb = reinterpret_cast<const char *>(gb);
+                        f4_t val[NPC];
+#pragma unroll
+                        for (int i = 0; i < NFULL; ++i) val[i] = *reinterpret_cast<const f4_t *>(sbb + i * STR * 16);
+#pragma unroll
+                        for (int i = NFULL; i < NPC; ++i) val[i] = sb[min(tj + i * STR, nbody4 - 1)];
+#pragma unroll
+                        for (int i = 0; i < NFULL; ++i)
+                            asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"(vo), "v"(val[i]), "s"(gbb + (size_t)i * STR * 16) : "memory");
+#pragma unroll
+                        for (int i = NFULL; i < NPC; ++i)
+                            if (tj + i * STR < nbody4)
+                                asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + i * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
+                    } else
 #pragma unroll
                     for (int g0 = 0; g0 < NPC; g0 += GP) {
                         f4_t val[GP];
@@ -1496,6 +1563,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 }
                 DFE_TL(6);
             }
+            DFE_MARK("rowend");
             if constexpr (ROLES) rec_prev += DFE_REC;
         });
     }
@@ -1622,8 +1690,8 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     a.sw_ovh = kSweepOvh; a.sw_min = kSweepMin;
     int nblk = sweep_blocks(ctx, ncols, Ho);
     if (const int k = FUSE ? 0 : sweep_aligned_k(ctx, ncols, Ho)) { nblk = k * ncols; a.sw_ovh = 0; }
-    if (const char *e = getenv("DFE_SWEEP_OVH")) a.sw_ovh = atoi(e);   // tuning
-    if (const char *e = getenv("DFE_SWEEP_BLOCKS")) nblk = atoi(e);    // tuning
+    if (ctx->opt[DFE_OPT_SWEEP_OVH] >= 0) a.sw_ovh = ctx->opt[DFE_OPT_SWEEP_OVH];      // tuning
+    if (ctx->opt[DFE_OPT_SWEEP_BLOCKS] >= 0) nblk = ctx->opt[DFE_OPT_SWEEP_BLOCKS];    // tuning
     if (nblk < 1 || (long long)(Ho + a.sw_ovh) * ncols * nblk >= (1ll << 31)) return DFE_OK;   // sweep_cut works in 32 bits
     size_t tile_bytes = (size_t)a.lrows * a.pitch * sizeof(px_t);
     a.tile0_off = (int)((tile_bytes + 127) / 128 * 128);
@@ -1769,7 +1837,7 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
         if (m.gy[i] > gym) gym = m.gy[i];
         if (pl.lds_bytes > lds) lds = pl.lds_bytes;
     }
-    const bool xpose = hWin * wWin == 64 && !getenv("DFE_NO_XPOSE");
+    const bool xpose = hWin * wWin == 64 && ctx->opt[DFE_OPT_XPOSE] != 0;
     if (f16_scale != 0.f && !xpose) return DFE_OK;   // (the fp16 store path is the transposed one; the caller converts otherwise)
     if (xpose) {   // a 2-KB transpose scratch per wave behind the largest tile (see the kernel's store path)
         const size_t xoff = (lds + 255) / 256 * 256;
@@ -1779,7 +1847,7 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
             if (f16_scale != 0.f) { m.p[i].f16 = 1; m.p[i].scale = f16_scale; }
         }
         int nt = vol_bytes > kXposeNtBytes;
-        if (const char *e = getenv("DFE_XPOSE_NT")) nt = atoi(e) != 0;   // tuning
+        if (ctx->opt[DFE_OPT_XPOSE_NT] >= 0) nt = ctx->opt[DFE_OPT_XPOSE_NT] != 0;   // tuning
         for (int i = 0; i < n; ++i) { m.p[i].stage_off = (int)xoff; m.p[i].stage_len = nt; }
         lds = xoff + (size_t)NW * TX * 64 * sizeof(float);
     }
@@ -1787,7 +1855,7 @@ static int launch_cv_tiled_multi_one(dfe_ctx *ctx, int n, const float *const *I0
     // other pairs' few long ones behind (1080p: 3600 blocks, -5.5 % on the step; 720p: 1600 blocks, -5.6 %); at VGA (540
     // blocks) those long blocks set the launch time and the separate soft-min launch is faster (0.119 against 0.134 ms).
     bool use_prob = prob && m.gx[0] * m.gy[0] >= 1000 && f16_scale == 0.f;
-    if (const char *e = getenv("DFE_SOFT_EPILOGUE")) use_prob = prob && atoi(e) != 0;   // tuning / tests: force on (1) or off (0)
+    if (ctx->opt[DFE_OPT_SOFT_EPILOGUE] >= 0) use_prob = prob && ctx->opt[DFE_OPT_SOFT_EPILOGUE] != 0;   // tuning / tests: force on (1) or off (0)
     if (!use_prob)
         for (int i = 0; i < n; ++i) m.prob[i] = nullptr;
     if (prob_used) *prob_used = use_prob;
@@ -1841,8 +1909,7 @@ int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int
     if (C != 3 || k != 7 || maxh != 8 || maxw != 8 || ctx->cv_mode == 1 || ctx->cv_mode == 3) return DFE_OK;
     const int Ho = Hp - 7 + 1 - maxh + 1, Wo = Wp - 7 + 1 - maxw + 1;
     if (fine.pcasc && ((Wo | Ho) & 1)) return DFE_OK;
-    const char *e = getenv(fine.casc ? "DFE_MID_NQ" : "DFE_FINE_NQ");
-    if (e && atoi(e) == 5) return launch_cv_fine<5>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
+    if (ctx->opt[fine.casc ? DFE_OPT_MID_NQ : DFE_OPT_FINE_NQ] == 5) return launch_cv_fine<5>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
     return launch_cv_fine<4>(ctx, I0p, I1p, Hp, Wp, maxh, maxw, fine, handled);
 }
 

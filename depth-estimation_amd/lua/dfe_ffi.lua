@@ -25,10 +25,13 @@ int dfe_host_alloc(dfe_ctx *ctx, size_t bytes, void **hptr);
 int dfe_host_free(dfe_ctx *ctx, void *hptr);
 int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
+int dfe_set_option(dfe_ctx *ctx, const char *key, int value);
+int dfe_get_option(dfe_ctx *ctx, const char *key, int *value);
 const char *dfe_last_kernel(const dfe_ctx *ctx);
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
+int dfe_profile_read_each(dfe_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap);
 int dfe_stage_timers_enable(dfe_ctx *ctx, int on);
 int dfe_stage_timers_read(dfe_ctx *ctx, double *ms , int *regions );
 int dfe_ssd_cost_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int kh, int kw, int hWin, int wWin, float *out);

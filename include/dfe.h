@@ -75,6 +75,15 @@ int dfe_set_cost_volume_kernel(dfe_ctx *ctx, int mode);
  * NQ groups of 6 image rows at k = 7: 6 NQ - 6 output rows); 100 + ty (101..164) = row-image tiles of ty output
  * rows (ty a multiple of 6 at k = 7); 1 = force the row-image kernel's column sweep (unfused build only).  For tuning and for testing. */
 int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
+/* Behaviour switches of the launchers (tuning and tests; none is needed for correct results -- every choice has a parity test or is
+ * a pure scheduling choice).  value >= 0 forces, -1 restores the launcher's own choice per shape.  Keys: "cascade_px", "fine_fuse",
+ * "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10", "fm64", "fm_rows",
+ * "sweep_ovh", "sweep_blocks", "debug_arena", "flow_finalize", "fm_flat", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
+ * (DFE_<KEY> variables of the tuning scripts) -- never inside an op, so an op's behaviour depends on its ctx only.
+ * replaces: the option tables the reference's drivers pass down (opticalflow.lua:138-198 `geometry`), for the switches that have no
+ * counterpart there.  Unknown key: DFE_E_ARG. */
+int dfe_set_option(dfe_ctx *ctx, const char *key, int value);
+int dfe_get_option(dfe_ctx *ctx, const char *key, int *value);
 /* name of the kernel the last cost-volume call launched (static string) */
 const char *dfe_last_kernel(const dfe_ctx *ctx);
 
@@ -85,6 +94,9 @@ int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
  * enable, run, then read the summed kernel time and launch count (read synchronises and resets) */
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
+/* the same, and the first `cap` launches' durations one by one (each_ms[cap], in launch order): where inside a timed region the time went
+ * (bench.py reports minimum / median / maximum next to the average) */
+int dfe_profile_read_each(dfe_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap);
 
 /* Stage timers with the reference's names -- `load / filter / match / extract` printed per frame by the dense driver
  * (depth_estimation_opticalflow.lua:44-47,112-117,144-148): HIP events around the launches of each stage inside the

@@ -36,3 +36,18 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("a test marked gpu ran without a GPU (torch.cuda.is_available() is False)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _release_dfe_options():
+    """Behaviour switches a test forced through dfe_set_option do not leak into the next test."""
+    yield
+    ctxmod = sys.modules.get("depth-estimation_amd.context") or sys.modules.get("depth_estimation_amd.context")
+    if ctxmod is None:
+        return
+    from depth_estimation_amd._lib import OPTION_KEYS
+
+    for c in list(ctxmod._ctxs.values()):
+        if c.handle:
+            for k in OPTION_KEYS:
+                c.set_option(k, -1 if k != "graphs" else 0)

@@ -13,6 +13,11 @@ import torch
 from tests import oracle as orc
 from tests import refpath as rp
 
+
+def _opt(dfe, key, value):
+    """dfe_set_option on the default-stream ctx (tests/conftest.py releases every switch again after the test)."""
+    dfe.get_ctx(0).set_option(key, int(value))
+
 pytestmark = pytest.mark.gpu
 SOFT_ATOL = 1e-6
 
@@ -236,7 +241,7 @@ def test_multiscale_one_call_soft_epilogue_both_ways(dfe, cuda, monkeypatch, for
     f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
     model = dfe.getModelMultiscale(geo)
     staged = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=False)
-    monkeypatch.setenv("DFE_SOFT_EPILOGUE", force)
+    _opt(dfe, "soft_epilogue", force)
     one = model.forwardFlow([T(f0, cuda), T(f1, cuda)], False, one_call=True)
     for k in ("index", "y", "x"):
         assert torch.equal(staged[k], one[k]), (k, force)
@@ -508,7 +513,7 @@ def test_one_call_multiscale_equals_oracle_chain(dfe, cuda, monkeypatch, soft, r
     f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H + len(ratios) + mh, max_flow=min(10, 2 * ratios[-1]), noise_sigma=0)
     f0, f1 = f0 / np.float32(64), f1 / np.float32(64)
     ref = rp.multiscale_flow_oracle(f0, f1, 7, mh, mh, ratios)
-    monkeypatch.setenv("DFE_SOFT_EPILOGUE", soft)
+    _opt(dfe, "soft_epilogue", soft)
     gi, gflow = _one_call(dfe, cuda, f0, f1, 7, mh, mh, ratios)
     _assert_matches_oracle(gi, gflow, ref, mh, mh, ratios)
 
@@ -635,17 +640,17 @@ def test_fused_finest_scale_equals_volume_path_bitwise(dfe, cuda, monkeypatch, r
             kern = ctx.last_kernel()
         return gi, gf, kern
 
-    monkeypatch.setenv("DFE_FINE_FUSE", "1")
-    monkeypatch.setenv("DFE_MID_FUSE", "1")
+    _opt(dfe, "fine_fuse", "1")
+    _opt(dfe, "mid_fuse", "1")
     gi, gf, kern = run()                                    # finest scale fused, and the second one too where there are >= 3 ratios
     assert kern.startswith("ssd_cv_tiled_fine_kernel")
-    monkeypatch.setenv("DFE_FINE_FUSE", "0")
+    _opt(dfe, "fine_fuse", "0")
     wi, wf, kern2 = run()
     assert not kern2.startswith("ssd_cv_tiled_fine_kernel")
     assert np.array_equal(gi, wi) and np.array_equal(gf, wf)
     if len(ratios) >= 3:
-        monkeypatch.setenv("DFE_FINE_FUSE", "1")
-        monkeypatch.setenv("DFE_MID_FUSE", "0")             # the second scale through its volume and cascade_px_kernel<false>
+        _opt(dfe, "fine_fuse", "1")
+        _opt(dfe, "mid_fuse", "0")             # the second scale through its volume and cascade_px_kernel<false>
         mi, mf, kern3 = run()
         assert kern3.startswith("ssd_cv_tiled_fine_kernel")
         assert np.array_equal(mi, wi) and np.array_equal(mf, wf)
@@ -676,11 +681,11 @@ def test_fused_scales_equal_volume_path_on_random_shapes(dfe, cuda, monkeypatch)
                 kern = ctx.last_kernel()
             return gi, gf, kern
 
-        monkeypatch.setenv("DFE_FINE_FUSE", "0")
+        _opt(dfe, "fine_fuse", "0")
         wi, wf, _ = run()
         for mid in ("1", "0"):
-            monkeypatch.setenv("DFE_FINE_FUSE", "1")
-            monkeypatch.setenv("DFE_MID_FUSE", mid)
+            _opt(dfe, "fine_fuse", "1")
+            _opt(dfe, "mid_fuse", mid)
             gi, gf, kern = run()
             nfused += kern.startswith("ssd_cv_tiled_fine_kernel")
             assert np.array_equal(gi, wi) and np.array_equal(gf, wf), "shape %dx%d ratios %s f16 %s mid %s (%s)" % (H, W, ratios, f16, mid, kern)
@@ -843,14 +848,14 @@ def test_learned_multiscale_fused_finest_scale_bitwise(dfe, cuda, monkeypatch, s
     f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=H, max_flow=min(10, 2 * ratios[-1]), noise_sigma=2.0)
     t0, t1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
     ctx = dfe.get_ctx(0)
-    monkeypatch.setenv("DFE_FINE_FUSE", "1")
-    monkeypatch.setenv("DFE_MID_FUSE", "1")                 # (the second scale too where there are >= 3 ratios)
+    _opt(dfe, "fine_fuse", "1")
+    _opt(dfe, "mid_fuse", "1")                 # (the second scale too where there are >= 3 ratios)
     a = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
     assert ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
-    monkeypatch.setenv("DFE_MID_FUSE", "0")
+    _opt(dfe, "mid_fuse", "0")
     m = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
     assert ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
-    monkeypatch.setenv("DFE_FINE_FUSE", "0")
+    _opt(dfe, "fine_fuse", "0")
     b = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
     assert not ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
     for r in (a, m):
@@ -875,11 +880,11 @@ def test_learned_fused_scales_on_random_shapes(dfe, cuda, monkeypatch):
         model = dfe.getModelMultiscale(geo, True, False, device=cuda, generator=gen)
         f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=it, max_flow=min(10, 2 * top), noise_sigma=1.5)
         t0, t1 = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
-        monkeypatch.setenv("DFE_FINE_FUSE", "0")
+        _opt(dfe, "fine_fuse", "0")
         b = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
         for mid in ("1", "0"):
-            monkeypatch.setenv("DFE_FINE_FUSE", "1")
-            monkeypatch.setenv("DFE_MID_FUSE", mid)
+            _opt(dfe, "fine_fuse", "1")
+            _opt(dfe, "mid_fuse", mid)
             a = model.forwardFlow([t0, t1], False, one_call=True, f16_scale=sc)
             nfused += ctx.last_kernel().startswith("feat_matching_win64_fine_kernel")
             assert torch.equal(a["index"], b["index"]) and torch.equal(a["y"], b["y"]) and torch.equal(a["x"], b["x"]), \
@@ -1342,8 +1347,8 @@ def test_multiscale_one_call_graph_replay_equals_direct_launches(dfe, cuda, monk
     from depth_estimation_amd._lib import ratios_array
 
     H, W, k, mh, ratios = 96, 128, 7, 8, [1, 2, 4]
-    monkeypatch.setenv("DFE_FINE_FUSE", "1" if fused else "0")
-    monkeypatch.setenv("DFE_MID_FUSE", "1" if fused else "0")
+    _opt(dfe, "fine_fuse", "1" if fused else "0")
+    _opt(dfe, "mid_fuse", "1" if fused else "0")
     fa0, fa1, _, _ = rp.synth_pair(H, W, C=3, seed=21)
     fb0, fb1, _, _ = rp.synth_pair(H, W, C=3, seed=22)
     want_a = _one_call(dfe, cuda, fa0, fa1, k, mh, mh, ratios)      # default (legacy) stream: cannot be captured, direct launches
@@ -1351,11 +1356,10 @@ def test_multiscale_one_call_graph_replay_equals_direct_launches(dfe, cuda, monk
     rr, n = ratios_array(ratios)
     side = torch.cuda.Stream(device=cuda)
     with torch.cuda.stream(side):                                   # a ctx on a real stream: its launches can be captured
-        os.environ["DFE_GRAPHS"] = "1"                              # read when the ctx is created (a new one: new stream)
-        try:
-            ctx = dfe.get_ctx(0)
-        finally:
-            del os.environ["DFE_GRAPHS"]
+        ctx = dfe.get_ctx(0)                                        # (a new ctx: new stream)
+        ctx.set_option("graphs", 1)
+        ctx.set_option("fine_fuse", int(fused))
+        ctx.set_option("mid_fuse", int(fused))
         t0, t1 = T(fa0, cuda), T(fa1, cuda)
         flow = torch.empty((2, H, W), device=cuda)
         idx = torch.empty((H, W), dtype=torch.int64, device=cuda)

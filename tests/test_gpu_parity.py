@@ -253,6 +253,60 @@ def test_spatial_matching_module_bit_exact(dfe, cuda):
         m.forward([T(in1, cuda).double(), T(in2, cuda).double()])
 
 
+@pytest.mark.parametrize("K,H1,W1,mh,mw", [
+    (3, 5, 253, 16, 16),     # the narrowest frame the flat-tile kernel takes (64 groups of 4 pixels per row), ragged last group
+    (4, 7, 256, 16, 16),     # rows of exactly one tile
+    (5, 9, 301, 17, 17),     # 17 window rows on 16 waves (row 16 = the extra task), tiles running over the row ends, W1 % 4 = 1
+    (2, 3, 608, 17, 17),     # version2's width (640 - 32)
+    (6, 11, 625, 16, 16),    # VGA minus the window: the verdict's shape, few rows
+    (3, 6, 290, 8, 16),      # fewer window rows than waves: 8 x 16
+    (3, 6, 327, 12, 17),     # 17 wide, 12 high (no extra task)
+    (1, 1, 260, 16, 16),     # a single output row, one plane
+])
+def test_spatial_matching_flat_kernel_bit_exact(dfe, cuda, K, H1, W1, mh, mw):
+    """nn.SpatialMatching with 16- / 17-wide windows on wide feature maps (opticalflow_model.lua:93, version2/network.lua:30,
+    tests/time_matching.lua:18): the flat-tile kernel (csrc/feat_matching_flat.hip) -- bit-exact against the oracle's k-ordered,
+    separately rounded sum, equal to the round-3 kernels (fm_flat = 0) bit for bit, every output element written exactly once
+    (the buffer is pre-filled with NaN)."""
+    rng = np.random.default_rng(K * 1000 + W1 + mh)
+    in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    ctx = dfe.get_ctx(0)
+    out = torch.full((H1, W1, mh, mw), float("nan"), device=cuda)
+    t1, t2 = T(in1, cuda), T(in2, cuda)
+    ctx.check(dfe.lib().dfe_spatial_matching_f32(ctx.handle, t1.data_ptr(), t2.data_ptr(), K, H1, W1, mh, mw, out.data_ptr()))
+    torch.cuda.synchronize()
+    assert ctx.last_kernel() == "feat_matching_flat_kernel", ctx.last_kernel()
+    ref = orc.spatial_matching(in1, in2, mh, mw)
+    got = out.cpu().numpy()
+    assert not np.isnan(got).any(), "cells left unwritten: %d" % int(np.isnan(got).sum())
+    assert np.array_equal(got, ref)
+    with ctx.options(fm_flat=0):
+        old = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
+        assert ctx.last_kernel() != "feat_matching_flat_kernel"
+    assert torch.equal(old, out)
+
+
+def test_spatial_matching_flat_kernel_output_is_bounded(dfe, cuda):
+    """The flat-tile kernel writes nothing outside its output: guard floats in front of and behind an (unaligned) output buffer stay
+    untouched, and an output that starts 4 bytes off a 16-B boundary (partial head / tail lines everywhere) is still bit-exact."""
+    rng = np.random.default_rng(77)
+    K, H1, W1, mh, mw = 3, 4, 270, 17, 17
+    in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    n = H1 * W1 * mh * mw
+    buf = torch.full((n + 64 + 1,), -7.0, device=cuda)
+    view = buf[33 : 33 + n]                                  # 4-B aligned only
+    ctx = dfe.get_ctx(0)
+    t1, t2 = T(in1, cuda), T(in2, cuda)
+    ctx.check(dfe.lib().dfe_spatial_matching_f32(ctx.handle, t1.data_ptr(), t2.data_ptr(), K, H1, W1, mh, mw, view.data_ptr()))
+    torch.cuda.synchronize()
+    assert ctx.last_kernel() == "feat_matching_flat_kernel"
+    h = buf.cpu().numpy()
+    assert (h[:33] == -7.0).all() and (h[33 + n :] == -7.0).all()
+    assert np.array_equal(h[33 : 33 + n].reshape(H1, W1, mh, mw), orc.spatial_matching(in1, in2, mh, mw))
+
+
 def test_spatial_radial_matching_module_bit_exact(dfe, cuda):
     rng = np.random.default_rng(1)
     K, H1, W, hWin = 10, 40, 64, 15   # radial/train_radial_opticalflow.lua:27-29 defaults: 10 features, hWin=15

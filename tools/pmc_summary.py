@@ -6,8 +6,10 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")[:70]
         rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import re
+filt = re.compile(sys.argv[2]) if len(sys.argv) > 2 else re.compile("tiled|ref_kernel|tail|rowimg|finalize|border")
 for k, cs in rows.items():
-    if not any(t in k for t in ("tiled", "ref_kernel", "tail", "rowimg", "finalize", "border")): continue
+    if not filt.search(k): continue
     print("kernel:", k)
     for c in sorted(cs):
         v = cs[c]

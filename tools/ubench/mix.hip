@@ -88,7 +88,7 @@ template <int VAR> __global__ __launch_bounds__(1024) void k(const float *__rest
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef f2 f2u __attribute__((aligned(4)));
 extern __shared__ float ldsf[];
-template <int VAR> __global__ __launch_bounds__(1024) void kp(const float *__restrict__ a0, float *out, int iters) {
+template <int VAR, bool HYB = false> __global__ __launch_bounds__(1024) void kp(const float *__restrict__ a0, float *out, int iters) {
     constexpr int PP = 75, RS = 3 * PP;
     for (int i = threadIdx.x; i < 64 * RS; i += blockDim.x) ldsf[i] = i * 0.5f;
     __syncthreads();
@@ -111,6 +111,7 @@ template <int VAR> __global__ __launch_bounds__(1024) void kp(const float *__res
         for (int m = 0; m < 6; ++m) {
             const float *lr = lr0 + ((it * 6 + m) & 15) * RS;
             f2 e2[7];
+            float eh[14];       // HYB: only the subtraction is packed (21 instead of 42 slow-path issues); the squares stay plain fast-path ops
             f2 b[2][7];
 #pragma unroll
             for (int j = 0; j < 7; ++j) b[0][j] = *reinterpret_cast<const f2u *>(lr + 2 * j);
@@ -128,13 +129,19 @@ template <int VAR> __global__ __launch_bounds__(1024) void kp(const float *__res
                 for (int j = 0; j < 7; ++j) asm("v_pk_add_f32 %0, %1, %0 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(b[c & 1][j]) : "s"(av[c][j]));
 #pragma unroll
                 for (int j = 0; j < 7; ++j) {
-                    if (c == 0) asm("v_pk_mul_f32 %0, %1, %1" : "=v"(e2[j]) : "v"(b[c & 1][j]));
-                    else asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(e2[j]) : "v"(b[c & 1][j]));
+                    if constexpr (HYB) {
+                        const float d0 = b[c & 1][j][0], d1 = b[c & 1][j][1];
+                        if (c == 0) { asm("v_mul_f32 %0, %1, %1" : "=v"(eh[2 * j]) : "v"(d0)); asm("v_mul_f32 %0, %1, %1" : "=v"(eh[2 * j + 1]) : "v"(d1)); }   // (asm: the compiler would re-pack the pair)
+                        else { eh[2 * j] = fmaf(d0, d0, eh[2 * j]); eh[2 * j + 1] = fmaf(d1, d1, eh[2 * j + 1]); }
+                    } else {
+                        if (c == 0) asm("v_pk_mul_f32 %0, %1, %1" : "=v"(e2[j]) : "v"(b[c & 1][j]));
+                        else asm("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(e2[j]) : "v"(b[c & 1][j]));
+                    }
                 }
             }
             float e[14];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) { e[2 * j] = e2[j][0]; e[2 * j + 1] = e2[j][1]; }
+            for (int j = 0; j < 7; ++j) { e[2 * j] = HYB ? eh[2 * j] : e2[j][0]; e[2 * j + 1] = HYB ? eh[2 * j + 1] : e2[j][1]; }
             float sa[7], pb[7], h[8];
             sa[6] = e[6];
 #pragma unroll
@@ -159,16 +166,16 @@ template <int VAR> __global__ __launch_bounds__(1024) void kp(const float *__res
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
-template <int VAR> void runp(const float *a0, float *d, int wps, const char *name) {
+template <int VAR, bool HYB = false> void runp(const float *a0, float *d, int wps, const char *name) {
     int iters = 512, blocks = 256, threads = 256 * wps;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipFuncSetAttribute((const void *)kp<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
-    hipLaunchKernelGGL(kp<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, 8);
+    (void)hipFuncSetAttribute((const void *)kp<VAR, HYB>, hipFuncAttributeMaxDynamicSharedMemorySize, 140000);
+    hipLaunchKernelGGL((kp<VAR, HYB>), dim3(blocks), dim3(threads), 140000, 0, a0, d, 8);
     (void)hipDeviceSynchronize();
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(kp<VAR>, dim3(blocks), dim3(threads), 140000, 0, a0, d, iters);
+        hipLaunchKernelGGL((kp<VAR, HYB>), dim3(blocks), dim3(threads), 140000, 0, a0, d, iters);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
@@ -202,5 +209,6 @@ int main() {
     (void)hipMemset(a0, 0, 64 * 4);
     for (int w : {4, 2, 1}) { run<0>(a0, d, w, "arithmetic only"); run<3>(a0, d, w, "+ 14 ds_read_b128"); run<4>(a0, d, w, "+ reads + 8 ds_write_b32"); run<5>(a0, d, w, "+ reads, writes, barrier"); }
     for (int w : {4, 2, 1}) { runp<0>(a0, d, w, "PACKED planar: reads + arith"); runp<1>(a0, d, w, "PACKED + 8 ds_write_b32"); runp<2>(a0, d, w, "PACKED + writes, barrier"); }
+    for (int w : {4, 2, 1}) { runp<0, true>(a0, d, w, "HYBRID (pk sub only): reads + arith"); runp<1, true>(a0, d, w, "HYBRID + 8 ds_write_b32"); runp<2, true>(a0, d, w, "HYBRID + writes, barrier"); }
     return 0;
 }
