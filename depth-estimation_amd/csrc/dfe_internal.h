@@ -27,7 +27,8 @@ enum DfeOpt {
     DFE_OPT_SWEEP_BLOCKS,     // ... number of blocks
     DFE_OPT_DEBUG_ARENA,      // print where the scratch arena lands
     DFE_OPT_FLOW_FINALIZE,
-    DFE_OPT_FM_FLAT,          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)    // 1: per-pixel results finished by flow_finalize_kernel also where the sweep could finish them itself
+    DFE_OPT_FM_FLAT,
+    DFE_OPT_FM_STAGGER,       // flat-tile feature matcher: start delay per XCD index in tenths of a microsecond (0: none)          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)    // 1: per-pixel results finished by flow_finalize_kernel also where the sweep could finish them itself
     DFE_NOPT
 };
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };

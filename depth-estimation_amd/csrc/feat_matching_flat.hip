@@ -31,11 +31,23 @@ namespace {
 
 constexpr int FF_PX = 4;                     // pixels per lane
 constexpr int FF_GROUPS = 64;                // groups (lanes) per tile
-constexpr int FF_PHL = 8;                    // lanes per copy-out phase
-constexpr int FF_NPH = FF_GROUPS / FF_PHL;   // copy-out phases per tile
 #ifndef FF_ABLATE
 #define FF_ABLATE 0   // tuning (side builds only): 1 no staging requests, 2 no barrier in the plane loop, 4 no copy-out stores, 8 no copy-out at all,
                       // 16 no arithmetic
+#endif
+#ifndef FF_TIMELINE
+#define FF_TIMELINE 0   // tuning (side builds only): s_memtime stamps of block 0's second tile, printed by the launcher (DFE_FF_TIMELINE=1)
+#endif
+#if FF_TIMELINE
+#define FF_STAMP(i) do { if (dbg_on && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FF_STAMP(i) do { } while (0)
+#endif
+#ifndef FF_ST_FLAGS
+#define FF_ST_FLAGS " nt"   // cache policy of the copy-out stores
+#endif
+#ifndef FF_DEEP
+#define FF_DEEP 1     // 1: requests stay in flight for TWO planes (counted vmcnt), operands are read behind the barrier
 #endif
 #ifndef FF_BATCH
 #define FF_BATCH 8                           // (pixel, cell) pairs whose differences / squares / adds are issued as three groups
@@ -63,6 +75,8 @@ struct FfArgs {
     int G;            // groups per image row = ceil(W1 / PX)
     int NG;           // H1 * G
     int ntiles;       // ceil(NG / 64)
+    int stagger;      // start delay per XCD index, in ticks of the 100-MHz constant clock (s_memrealtime)
+    unsigned long long *dbg;   // FF_TIMELINE builds: stamps of block 0's second tile
 };
 
 template <int MW> struct FfGeom {
@@ -72,6 +86,13 @@ template <int MW> struct FfGeom {
 };
 
 extern __shared__ __attribute__((aligned(128))) float ff_smem[];
+
+// floats per window slot of the copy-out image: a multiple of 4 with room for the alignment shift (<= 3 floats) of a window whose
+// place in the output is not 16-B aligned, and not a multiple of 8 (the 64 lanes' 16-B writes then fall on different banks)
+__host__ __device__ inline int ff_wnp(int WN) {
+    int w = (WN + 3 + 3) & ~3;
+    return (w & 7) ? w : w + 4;
+}
 
 // One LDS-DMA load of 64 floats: lane l fetches the float at sbase + voff (bytes; its own offset) into LDS at lds_dst + 4 l.
 // Written as assembly for the addressing form: scalar base + 32-bit vector offset -- through the builtin the compiler built a 64-bit
@@ -99,13 +120,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     const int NW = EXTRA ? 16 : p.maxh;                    // waves of the block = blockDim.x / 64
     const int nrows = p.maxh + 1;                          // in2 rows of a tile: y_first .. y_first + maxh
     const int WN = p.maxh * MW;                            // floats per window
-    // LDS: [3][nrows][PITCH] tile | [3][256] in1 pieces | [64] lane offsets (extra task) | [64] pixel index of a group | [2][IMG] images
+    // LDS: [3][nrows][PITCH] tile | [3][256] in1 pieces | [64] lane offsets (extra task) | [64][WNP] image
     lds_f *tile = (lds_f *)ff_smem;
     lds_f *abuf = tile + 3 * nrows * PITCH;
     lds_i *gtab = (lds_i *)(abuf + 3 * 64 * PX);
-    lds_i *prtab = gtab + 64;
-    const int IMG = (FF_PHL * PX * WN + 32 + 31) / 32 * 32;
-    lds_f *img = (lds_f *)(prtab + 64);
+    lds_f *img = (lds_f *)(gtab + 64);                    // [64][WNP]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,7 +138,21 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     const int nbx = gridDim.x, per_xcd = nbx >> 3;
     const int vb = (nbx & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 
+    // STAGGER: the tiles all cost the same, so the CUs would reach their copy-outs together, round after round -- 64 MB at once, which the
+    // memory takes at ~6 TB/s while every CU waits in its stores (10 us of a 50-us tile), and nothing in between.  The blocks of XCD x
+    // start x * stagger later: the bursts of the XCDs (8 MB each) come one after the other at full speed, behind other XCDs' arithmetic.
+    // (The XCDs with the highest index have the tiles of the last, partial round to spare: their delay is free.)
+    if (p.stagger > 0 && !(nbx & 7)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned)p.stagger;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+
     for (int t = vb; t < p.ntiles; t += nbx) {
+#if FF_TIMELINE
+        const bool dbg_on = p.dbg && blockIdx.x == 0 && t == vb + nbx;
+#endif
+        FF_STAMP(0);
         // ---- tile geometry (wave-uniform scalars, then per-lane offsets) ----
         const int g0 = t * FF_GROUPS;
         const int y_first = g0 / p.G, xgA0 = g0 - y_first * p.G, xA0 = xgA0 * PX;
@@ -139,8 +172,6 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             boff = (dy + isB) * PITCH + xin;                              // my window row in the LDS tile (floats)
             if (wave == 0) {
                 gtab[l] = isB * PITCH + xin;
-                // pixel index of the group relative to the tile's first pixel (the output of a tile is one contiguous run)
-                prtab[l] = g0 + l < p.NG ? (isB ? p.W1 - xA0 + x : x - xA0) : -1;
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -238,6 +269,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             }
         };
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tables are in LDS
+        FF_STAMP(1);
         if constexpr (EXTRA) {
             const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), q = pp & 3, c = lane & 3;
             xoff_b = gtab[lg] + 16 * PITCH + q + 4 * c;
@@ -248,6 +280,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         for (int kk = 0; kk < p.K + 2; ++kk) {
             const int bc = bs == 2 ? 0 : bs + 1;                          // (kk - 2) % 3: the plane of this iteration's arithmetic
             const int bp = bs == 0 ? 2 : bs - 1;                          // (kk - 1) % 3: complete since the previous barrier
+            if (FF_DEEP) read_head(bc);
             read_tail(bc);                                                // (kk < 2: nothing there yet, nothing is computed from it)
             if (kk < p.K && !(FF_ABLATE & 1)) stage(kk, bs);
             __builtin_amdgcn_sched_barrier(0);
@@ -282,90 +315,100 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            read_head(bp);     // (unconditional -- in the first and the last iteration the values are not used -- so that the operands stay
+            if (!FF_DEEP) read_head(bp);     // (unconditional -- in the first and the last iteration the values are not used -- so that the operands stay
                                //  in ONE register set: with the read under a condition the compiler kept two sets and 20 moves per plane)
             // my requests of plane kk have landed; behind the barrier everyone's have, and every wave is past its reads of plane kk-3
-            if (FF_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (FF_DEEP) {
+                // all but THIS iteration's requests have landed: the plane of the next iteration's arithmetic
+                const bool plain = kk < p.K && !((last0 || last1) && kk == p.K - 1);
+                const int nld = 2 + (j1 < nrows ? 2 : j1 == nrows ? 1 : 0);
+                if (plain && nld == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                else if (plain && nld == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+                else if (plain && nld == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else if (FF_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             bs = bs == 2 ? 0 : bs + 1;
+            if (kk == 1) FF_STAMP(2);
+            if (kk == 11) FF_STAMP(3);
         }
+        FF_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-        // ---- copy-out: FF_NPH phases of FF_PHL lanes (32 pixel slots) through the double-buffered image ----
+        // ---- copy-out: one phase per pixel q of the groups -- ALL lanes deposit their pixel q's window row (an LDS instruction costs its
+        // issue slot whatever its execution mask: the first version, 8 phases of 8 lanes each, spent 43 of a tile's 124 kilocycles here,
+        // most of it in 2048 write instructions with 8 active lanes), then wave w copies the windows of lanes 4w .. 4w+3 out: a window is
+        // one contiguous run of the output (1 KB, line-aligned, at 16 x 16).  The image is [lane][WNP]; WNP = WN + 4 where WN is a multiple
+        // of 8 keeps the 64 lanes' 16-B writes on different banks.
         const long long tile_px0 = (long long)y_first * p.W1 + xA0;       // first pixel of the tile (row-major pixel index)
-        for (int ph = 0; ph < ((FF_ABLATE & 8) ? 0 : FF_NPH); ++ph) {
-            const int l0 = ph * FF_PHL;
-            const int pr0 = prtab[l0];                                    // wave-uniform (same address); -1: the phase is empty
-            if (pr0 < 0) break;                                           // (block-uniform: groups are valid up to NG)
-            int lastl = l0 + FF_PHL - 1;
-            // pixels of the phase: from group l0's first to the last valid pixel of its last valid group
-            int prl = prtab[lastl];
-            while (prl < 0) prl = prtab[--lastl];                         // (uniform; at most FF_PHL - 1 steps, last tile only)
-            const int lastx = (lastl >= nA ? (lastl - nA) * PX : xA0 + lastl * PX);
-            const int npx = prl - pr0 + min(PX, p.W1 - lastx);
-            const long long G0 = (tile_px0 + pr0) * WN;                   // global float index of the phase's run
-            const int a0 = (int)(G0 & 31);
-            lds_f *im = img + (ph & 1) * IMG + a0;
-            const int lc = lane_fresh();
-            const int prc = prtab[lc];
-            if (lc >= l0 && lc < l0 + FF_PHL && prc >= 0) {
+        const int WNP = ff_wnp(WN);
+        static_for_q<0, ((FF_ABLATE & 8) ? 0 : PX)>([&](auto qphase) {
+            constexpr int q = decltype(qphase)::value;
+            {
+                const int lc = lane_fresh();
                 const int x = lc >= nA ? (lc - nA) * PX : xA0 + lc * PX;
-                lds_f *w = im + (prc - pr0) * WN + dy * MW;
+                if (g0 + lc < p.NG && x + q < p.W1) {
+                    // (the window's image is shifted by its output address mod 16 B, so that 16-B pieces are aligned on both sides)
+                    const int prl = lc * PX - (lc >= nA ? padpx : 0);
+                    const int ash = (int)(((uintptr_t)(p.out + (tile_px0 + prl + q) * WN) >> 2) & 3);
+                    lds_f *w = img + lc * WNP + ash + dy * MW;
+                    if constexpr (MW % 4 == 0) {
 #pragma unroll
-                for (int q = 0; q < PX; ++q)
-                    if (x + q < p.W1) {
-                        if constexpr (MW % 4 == 0) {
-                            // (WN, MW multiples of 4 and a0 a multiple of 4 when G0 is: 16-B aligned pieces)
+                        for (int d = 0; d < MW; d += 4) *(lds_f4 *)(w + d) = ff_f4{acc[q][d], acc[q][d + 1], acc[q][d + 2], acc[q][d + 3]};
+                    } else {
 #pragma unroll
-                            for (int d = 0; d < MW; d += 4) *(lds_f4 *)(w + q * WN + d) = ff_f4{acc[q][d], acc[q][d + 1], acc[q][d + 2], acc[q][d + 3]};
-                        } else {
-#pragma unroll
-                            for (int d = 0; d < MW; ++d) w[q * WN + d] = acc[q][d];
-                        }
+                        for (int d = 0; d < MW; ++d) w[d] = acc[q][d];
                     }
+                }
             }
             if constexpr (EXTRA) {
-                // window row 16 of the phase's pixels: the extra tasks of waves 2 ph, 2 ph + 1 (groups 4 wave .. 4 wave + 3)
-                if ((wave >> 1) == ph) {
-                    const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), q = pp & 3, c = lane & 3;
-                    const int prg = prtab[lg];
-                    const int xg = lg >= nA ? (lg - nA) * PX : xA0 + lg * PX;
-                    if (prg >= 0 && xg + q < p.W1) {
-                        lds_f *w = im + (prg + q - pr0) * WN + 16 * MW + 4 * c;
+                // window row 16: the extra task's lanes that hold pixel q of their group
+                const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), c = lane & 3;
+                const int xg = lg >= nA ? (lg - nA) * PX : xA0 + lg * PX;
+                if ((pp & 3) == q && g0 + lg < p.NG && xg + q < p.W1) {
+                    const int prl = lg * PX - (lg >= nA ? padpx : 0);
+                    const int ash = (int)(((uintptr_t)(p.out + (tile_px0 + prl + q) * WN) >> 2) & 3);
+                    lds_f *w = img + lg * WNP + ash + 16 * MW + 4 * c;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w[j] = accx[j];
-                        if (c == 3) w[4] = accx[4];
-                    }
+                    for (int j = 0; j < 4; ++j) w[j] = accx[j];
+                    if (c == 3) w[4] = accx[4];
                 }
             }
+            if (q == 0) FF_STAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            // whole 128-B lines as dwordx4 bursts; the run's partial head / tail lines float by float (completed by the neighbouring
-            // phase, which this block writes next or has just written, or by the block that owns the neighbouring tile)
-            const int nfl = npx * WN;
-            const int head = min((32 - a0) & 31, nfl);
-            const int nbody4 = (nfl - head) >> 2 & ~7;                    // float4 pieces in whole lines
-            float *gout = p.out + G0;
-            const lds_f4 *sb = (const lds_f4 *)(im + head);
-            const char *gb = reinterpret_cast<const char *>(gout + head);
-            const int nthr = NW * 64;
-            for (int i0 = 0; i0 < nbody4; i0 += 4 * nthr) {
-                ff_f4 v[4];
+            if (q == 0) FF_STAMP(6);
+            // the block's waves share the 64 windows: wave w takes lanes w, w + NW, ...
+            for (int ll = wave; ll < 64; ll += NW) {
+                const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
+                if (g0 + ll >= p.NG || xg + q >= p.W1) continue;         // (wave-uniform)
+                const int prl = ll * PX - (ll >= nA ? padpx : 0);        // pixel index of the group relative to the tile's first pixel
+                float *gw = p.out + (tile_px0 + prl + q) * WN;
+                const int ash = (int)(((uintptr_t)gw >> 2) & 3), head = (4 - ash) & 3;
+                const lds_f *sw = img + ll * WNP + ash;
+                const int nb4 = (WN - head) >> 2, tail0 = head + 4 * nb4;
+                const lds_f4 *sb = (const lds_f4 *)(sw + head);
+                const float *gb = gw + head;
+                constexpr int NJ4 = (17 * MW / 4 + 63) / 64;              // 16-B pieces per lane and window (2)
+                ff_f4 v[NJ4];
+                float vh = 0.f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = sb[min(i0 + u * nthr + (int)threadIdx.x, nbody4 - 1)];
+                for (int j = 0; j < NJ4; ++j) v[j] = sb[min(lane + 64 * j, nb4 - 1)];
+                if (lane < 8) vh = sw[lane < 4 ? min(lane, WN - 1) : min(tail0 + lane - 4, WN - 1)];   // lanes 0..3: head floats, 4..7: tail floats
+                if (!(FF_ABLATE & 4)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * nthr + (int)threadIdx.x;
-                    if (i < nbody4 && !(FF_ABLATE & 4)) asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"((unsigned)i * 16u), "v"(v[u]), "s"(gb) : "memory");
+                    for (int j = 0; j < NJ4; ++j)
+                        if (lane + 64 * j < nb4)
+                            asm volatile("global_store_dwordx4 %0, %1, %2" FF_ST_FLAGS ::"v"((unsigned)(lane + 64 * j) * 16u), "v"(v[j]), "s"(gb) : "memory");
+                    if (lane < head) gw[lane] = vh;
+                    if (lane >= 4 && lane < 8 && tail0 + lane - 4 < WN) gw[tail0 + lane - 4] = vh;
                 }
             }
-            const int tail0 = head + (nbody4 << 2);
-            if (wave == 0 && lane < head) gout[lane] = im[lane];
-            if (wave == NW - 1) {
-                for (int i = tail0 + lane; i < nfl; i += 64) gout[i] = im[i];
-            }
-        }
-        // the next tile's tables and first plane overwrite what the last phases may still read: every wave is past its reads here
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q == 0) FF_STAMP(7);
+            // every wave is past its reads of the image before the next phase (or the next tile's tables / first plane) overwrites it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (q == 2) FF_STAMP(8);
+        });
+        FF_STAMP(9);
     }
 }
 
@@ -390,18 +433,36 @@ int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int
     const int NW = extra ? 16 : maxh;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
     const int WN = maxh * maxw;
-    const int IMG = (FF_PHL * FF_PX * WN + 32 + 31) / 32 * 32;
-    const size_t lds = ((size_t)3 * (maxh + 1) * PITCH + 3 * 64 * FF_PX + 128 + (size_t)2 * IMG) * sizeof(float);
+    const int WNP = ff_wnp(WN);
+    const size_t lds = ((size_t)3 * (maxh + 1) * PITCH + 3 * 64 * FF_PX + 64 + (size_t)64 * WNP) * sizeof(float);
     if (lds > 160 * 1024) return DFE_OK;
     void (*kern)(FfArgs) = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
                                       : feat_matching_flat_kernel<16, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
+    // (2 us per XCD step by default, where there are several rounds of tiles to stagger; "fm_stagger": tenths of a microsecond)
+    a.stagger = ctx->opt[DFE_OPT_FM_STAGGER] >= 0 ? ctx->opt[DFE_OPT_FM_STAGGER] * 10 : (a.ntiles >= 2 * nblk ? 200 : 0);
+#if FF_TIMELINE
+    unsigned long long *dbg = nullptr, hdbg[16] = {0};
+    (void)hipMalloc((void **)&dbg, sizeof(hdbg));
+    (void)hipMemset(dbg, 0, sizeof(hdbg));
+    a.dbg = dbg;
+#endif
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), lds, ctx->stream, a);
     }
     DFE_LAUNCH_CHECK(ctx);
+#if FF_TIMELINE
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(hdbg, dbg, sizeof(hdbg), hipMemcpyDeviceToHost);
+    (void)hipFree(dbg);
+    static int printed = 0;
+    if (printed++ < 2) {
+        const char *nm[] = {"tile start", "tables", "fill done (kk=1)", "kk=11", "plane loop end", "phase 0 deposited", "phase 0 barrier", "phase 0 stored", "phase 3 end", "tile end"};
+        for (int i = 1; i < 10; ++i) fprintf(stderr, "[ff timeline] %-20s +%6lld  (total %lld)\n", nm[i], (long long)(hdbg[i] - hdbg[i - 1]), (long long)(hdbg[i] - hdbg[0]));
+    }
+#endif
     ctx->last_kernel = "feat_matching_flat_kernel";
     *handled = true;
     return DFE_OK;
