@@ -66,6 +66,18 @@ RADIALS = {
     "720p-radial": (720, 1280, 3, 720, 1280, 15, [[3, 1, 17, 5], [5, 17, 1, 10]]),
     "vga-radial": (480, 640, 3, 480, 640, 15, [[3, 1, 17, 5], [5, 17, 1, 10]]),
 }
+# The trained single-scale models (verdict r3 items 3 / 4):
+#   version2-*     version2/network.lua:5-39 + version2/test.lua:40-53 through dfe_version2_flow_pair_f32 (ONE call: contrastive
+#                  normalisation k = 17, 17 x 17 x 32 convolution, SpatialMatching(17, 17), first-min decode), random-init weights
+#   time-matching  tests/time_matching.lua:5-47 as written: getFilter({3,5,5,4},{4,5,5,4},{4,5,5,10}) on two randn 3 x 180 x 320 frames,
+#                  prepareInput's narrow, nn.SpatialMatching(16, 16), and the script's `output:min(1)` of the Reshape(256, 293, 153) view
+LEARNED_SINGLE = {
+    # name: (H, W, normalization_k, layers {nIn, kW, kH, nOut}, window)
+    "version2-vga": (480, 640, 17, [(3, 17, 17, 32)], 17),
+    "version2-180p": (180, 320, 17, [(3, 17, 17, 32)], 17),      # version2/test.lua's own datap: 320 x 180
+    "time-matching": (180, 320, 0, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
+}
+VALU_RATE_PER_CU = 1.6   # wave-instructions per cycle and CU for plain fp32 register ops (tools/ubench/valu2.hip), 256 CUs at 2.4 GHz
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -516,12 +528,127 @@ def main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp):
         dist.destroy_process_group()
 
 
+def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
+    """version2-* / time-matching: one pair per GPU per step.  `roofline` is the matcher (the dominant kernel): its algorithmic bytes
+    (both feature maps + the H1 x W1 x hWin x wWin volume) against HBM, and next to it the vector-ALU bound of its 3 K lane-operations
+    per output (subtract, multiply, add: the separately rounded k-ordered sum is the contract) -- the larger of the two is the bound."""
+    import numpy as np
+
+    H, W, nk, layers, win = LEARNED_SINGLE[args.workload]
+    lib = d.lib()
+    ctx = d.get_ctx(local_rank)
+    g = torch.Generator().manual_seed(rank)
+    tm = args.workload == "time-matching"
+    hk = 1 + sum(l[2] - 1 for l in layers)
+    wk = 1 + sum(l[1] - 1 for l in layers)
+    K = layers[-1][3]
+    if tm:
+        geometry = dict(maxh=win, maxw=win, layers=[list(l) for l in layers], multiscale=False, prefilter=True)
+        filt = d.getFilter(geometry, device=dev, generator=g)
+        matcher = d.nn.SpatialMatching(win, win, False)
+        im1 = torch.randn((3, H, W), generator=g).to(dev)
+        im2 = torch.randn((3, H, W), generator=g).to(dev)
+        H1, W1 = H - (hk - 1) - (win - 1), W - (wk - 1) - (win - 1)
+        mn = torch.empty((W1 * H1,), device=dev)
+        mi = torch.empty((W1 * H1,), dtype=torch.int64, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        stage = {"filter": 0.0, "match": 0.0, "min": 0.0, "n": 0}
+
+        def step(timed=False):
+            # tests/time_matching.lua:30-45 (the script filters im1 and im2 with the same module; prepareInput narrows the first)
+            if timed: ev[0].record()
+            f1 = filt.forward(im1).clone()
+            f2 = filt.forward(im2)
+            p1, p2 = d.prepareInput(geometry, f1, f2)
+            if timed: ev[1].record()
+            out = matcher.forward([p1, p2])
+            if timed: ev[2].record()
+            # matcher:add(nn.Reshape(wsize*wsize, w-wsize+1-12, h-wsize+1-12)); output:min(1): the minimum over the leading dimension of
+            # the [256][293 * 153] VIEW of the volume's memory (a reshape, not a transpose -- as the script has it)
+            ctx.check(lib.dfe_min_dim0_f32(ctx.handle, out.data_ptr(), win * win, W1 * H1, mn.data_ptr(), mi.data_ptr()))
+            if timed:
+                ev[3].record()
+                torch.cuda.synchronize()
+                stage["filter"] += ev[0].elapsed_time(ev[1]); stage["match"] += ev[1].elapsed_time(ev[2]); stage["min"] += ev[2].elapsed_time(ev[3]); stage["n"] += 1
+    else:
+        datap = d.version2.defaultDatap(wImg=W, hImg=H, normalization_k=nk, layers=layers, wWin=win, hWin=win)
+        net = d.version2.getNetwork(datap, device=dev, generator=g)
+        f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=rank, max_flow=6)
+        prev, cur = torch.from_numpy(f0 / np.float32(255)).to(dev), torch.from_numpy(f1 / np.float32(255)).to(dev)
+        from depth_estimation_amd.multiscale import filter_layers_array
+
+        stack = d.network.Sequential()
+        for m in net.modules[0].modules[0].modules[2:]:
+            stack.add(m)
+        arr, nl, keep = filter_layers_array([stack])
+        scn = net.modules[0].modules[0].modules[0]
+        kp = scn.kernel.numpy().ctypes.data_as(C.POINTER(C.c_float))
+        H1, W1 = H - (hk - 1) - (win - 1), W - (wk - 1) - (win - 1)
+        xf, yf = torch.empty((H1, W1), device=dev), torch.empty((H1, W1), device=dev)
+
+        def step(timed=False):
+            ctx.check(lib.dfe_version2_flow_pair_f32(ctx.handle, prev.data_ptr(), cur.data_ptr(), 3, H, W, kp, scn.kernel.numel(), scn.threshold, scn.thresval,
+                                                     arr, nl, win, win, xf.data_ptr(), yf.data_ptr(), None, None))
+
+    elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize,
+                           before_timed=lambda: ctx.check(lib.dfe_profile_enable(ctx.handle, 1)))
+    ms, n = C.c_double(), C.c_int()
+    ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(ms), C.byref(n)))
+    ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+    kernel = ctx.last_kernel() if tm else "feat_matching_flat_kernel"
+    stages = None
+    if tm:
+        for _ in range(10):
+            step(timed=True)
+        stages = {k: round(stage[k] / stage["n"], 4) for k in ("filter", "match", "min")}
+    else:
+        ctx.check(lib.dfe_stage_timers_enable(ctx.handle, 1))
+        for _ in range(10):
+            step()
+        sm, sr = (C.c_double * 4)(), (C.c_int * 4)()
+        ctx.check(lib.dfe_stage_timers_read(ctx.handle, sm, sr))
+        ctx.check(lib.dfe_stage_timers_enable(ctx.handle, 0))
+        stages = {nm: round(sm[i] / 10, 4) for i, nm in enumerate(("load", "filter", "match", "extract"))}
+    if rank == 0:
+        out_elems = H1 * W1 * win * win
+        balg = (K * H1 * W1 + K * (H1 + win - 1) * (W1 + win - 1) + out_elems) * 4
+        kern_s = ms.value / 1e3 / max(n.value, 1)
+        step_s = elapsed / args.steps
+        laneops = 3.0 * K * out_elems
+        valu_s = laneops / 64.0 / (VALU_RATE_PER_CU * 256 * 2.4e9)
+        hbm_s = balg / (HBM_PEAK_GBS * 1e9)
+        bound = "valu" if valu_s > hbm_s else "hbm"
+        print(json.dumps({
+            "metric": "Mpixels/s dense flow, %dx%d pair, learned single-scale model (%s), %dx%d window" % (
+                W, H, "tests/time_matching.lua" if tm else "version2/network.lua", win, win),
+            "value": round(world * args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("tests/time_matching.lua:5-47: getFilter %s (tanh between, random-init) on two randn 3x%dx%d frames, prepareInput narrow, "
+                                    "nn.SpatialMatching(%d,%d) on %d planes %dx%d, min over the script's Reshape(256, %d, %d) view" % (layers, H, W, win, win, K, W1, H1, W1, H1)) if tm else
+                                   ("version2/test.lua:40-53 in one call (dfe_version2_flow_pair_f32): SpatialContrastiveNormalization(3, gaussian1D(%d)) on both frames, crop, "
+                                    "SpatialConvolution %s (shared, random-init), SpatialMatching(%d,%d) on %d planes %dx%d, first-min decode" % (nk, layers, win, win, K, W1, H1)),
+                       "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single", "stage_ms": stages},
+            "roofline": {"bound": bound, "kernel": kernel, "kernel_ms": round(kern_s * 1e3, 5), "launches_timed": n.value,
+                         "achieved": round(balg / kern_s / 1e9, 2) if bound == "hbm" else round(laneops / kern_s / 1e12, 3),
+                         "peak": HBM_PEAK_GBS if bound == "hbm" else round(64 * VALU_RATE_PER_CU * 256 * 2.4e9 / 1e12, 2),
+                         "unit": "GB/s" if bound == "hbm" else "Tlane-op/s",
+                         "frac": round((hbm_s if bound == "hbm" else valu_s) / kern_s, 4) if kern_s > 0 else None,
+                         "traffic": None, "algorithmic_bytes_per_launch": balg,
+                         "hbm_bound_ms": round(hbm_s * 1e3, 5), "valu_bound_ms": round(valu_s * 1e3, 5),
+                         "note": "both bounds stated: bytes / 8 TB/s and 3 K lane-ops per output at %.1f plain fp32 wave-instructions per cycle and CU" % VALU_RATE_PER_CU},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS) + sorted(F16_WORKLOADS) + sorted(BAND_WORKLOADS))
+    ap.add_argument("--workload", default="vga", choices=sorted(WORKLOADS) + sorted(PYRAMIDS) + sorted(RADIALS) + sorted(F16_WORKLOADS) + sorted(BAND_WORKLOADS) + sorted(LEARNED_SINGLE))
     ap.add_argument("--bands", type=int, default=1, help="*-bands workloads: at least this many row bands (default: one per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed) gather of the results to rank 0")
@@ -556,6 +683,8 @@ def main():
         return main_radial(args, world, rank, local_rank, dev, torch, dist, d, rp)
     if args.workload in BAND_WORKLOADS:
         return main_bands(args, world, rank, local_rank, dev, torch, dist, d, rp)
+    if args.workload in LEARNED_SINGLE:
+        return main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp)
     f16 = args.workload in F16_WORKLOADS
     H, W, Cc, k, hWin, wWin = (F16_WORKLOADS if f16 else WORKLOADS)[args.workload]
     (pair_id,) = shard_pairs(world, world, rank)                              # a batch of `world` pairs, pair p on rank p

@@ -16,6 +16,8 @@ no CPU fallback -- a missing library or device raises.
     getC2PMask, getP2CMask, cartesian2polar, flow2depth (radial/cartesian2polar.lua, radial_opticalflow_display.lua)
     torch7_io.load / save, load_calibration             (Torch7 binary files: *.cal, saveModel / saveNetwork weights)
     saveModel, loadModel, loadWeightsFrom, saveNetwork, loadTesterNetwork, loadTrainerNetwork   (opticalflow_model_io.lua, radial_opticalflow_network.lua)
+    prepareInput, rgb2y                                 (opticalflow_model.lua:131-151)
+    version2.getNetwork, getTrainerNetwork, decodeFlow, flowPair   (version2/network.lua, version2/test.lua)
 """
 from ._lib import lib, DfeError, LIB_PATH  # noqa: F401
 from .context import Context, get_ctx  # noqa: F401
@@ -35,7 +37,10 @@ from .opticalflow_model import (  # noqa: F401
     getOutputConfidences,
     getOutputConfidences2,
     processOutput,
+    prepareInput,
+    rgb2y,
 )
+from . import version2  # noqa: F401
 from .multiscale import CascadingAddTable, MultiscaleModel, MultiscalePrefilter, getModelMultiscale, getMultiscalePrefilter  # noqa: F401
 from .network import getFilter, getFilterRadial, getModel, tables_random  # noqa: F401
 from .radial import (getRMax, getC2PMask, getP2CMask, cartesian2polar, flow2depth, getKOutput, getP2CMaskOF,  # noqa: F401

@@ -48,6 +48,13 @@ PROTOTYPES = {
     "dfe_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_set_cost_volume_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_set_cost_volume_tile": (C.c_int, [C.c_void_p, C.c_int]),
+    "dfe_version2_flow_pair_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float,
+                                             C.POINTER(FilterLayer), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dfe_u8_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
+    "dfe_min_dim0_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
+    "dfe_rgb2y_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dfe_flow_depth_pair_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_double, C.c_float] + [C.c_void_p] * 4),
+    "dfe_multiscale_flow_pair_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [c_i32p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "dfe_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dfe_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "dfe_last_kernel": (C.c_char_p, [C.c_void_p]),

@@ -131,6 +131,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (const dfe_ctx::StageEvent &e : ctx->stage_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ingest) (void)hipFree(ctx->ingest);
     if (ctx->dflag) (void)hipFree(ctx->dflag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

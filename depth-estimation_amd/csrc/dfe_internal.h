@@ -50,6 +50,8 @@ struct dfe_ctx {
     void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)
     size_t scratch_bytes = 0;
     size_t scratch_limit = (size_t)16 << 30;   // cost-volume bands are sized to fit (dfe_set_scratch_limit)
+    void *ingest = nullptr;           // grow-only fp32 copy of a uint8 frame pair (ingest.hip), freed with the ctx
+    size_t ingest_bytes = 0;
     int *dflag = nullptr;             // one device int for error flags raised by kernels
     char err[512] = {0};
     // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)
@@ -153,6 +155,9 @@ int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_lay
 // the same layer position of n independent inputs (both frames of every pyramid scale) in ONE launch where a batched kernel exists
 int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
                                    float *const *out);
+// nn.SpatialContrastiveNormalization with caller-provided scratch ((C + 3) * H * W floats): for the one-call pipelines (filters.hip)
+int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
+                                      float thresval, float *scratch, float *out);
 // nn.SpatialMatching on feature maps, fast kernels or the reference-order one (ssd_cost_volume.hip)
 int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 

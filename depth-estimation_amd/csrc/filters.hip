@@ -404,10 +404,10 @@ __global__ void cn_finish_kernel(const float *__restrict__ in, const float *__re
 
 }  // namespace
 
-extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
-                                                 float thresval, float *out) {
-    DFE_ENTER(ctx);
-    DFE_REQUIRE(ctx, in && kernel_host && out, DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
+// scratch: (C + 3) * H * W floats of device memory
+int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
+                                      float thresval, float *scratch, float *out) {
+    DFE_REQUIRE(ctx, in && kernel_host && out && scratch, DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
     DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && k > 0 && k <= CN_MAXK, DFE_E_SHAPE, "dfe_contrastive_normalization_f32: C=%d %dx%d kernel %d (max %d)", C, H,
                 W, k, CN_MAXK);
     CnKernel kk;
@@ -416,10 +416,7 @@ extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, 
     for (int i = 0; i < k; ++i) ks += kernel_host[i];
     for (int i = 0; i < k; ++i) kk.kn[i] = kernel_host[i] / (ks * (float)C);       // self.kernel:div(self.kernel:sum() * self.nInputPlane)
     const long long P = (long long)H * W;
-    void *scr = nullptr;
-    int rc = dfe_scratch(ctx, ((size_t)C * P + 3 * P) * sizeof(float), &scr);
-    if (rc) return rc;
-    float *tmp = (float *)scr, *coef = tmp + C * P, *est = coef + P, *est2 = est + P;
+    float *tmp = scratch, *coef = tmp + C * P, *est = coef + P, *est2 = est + P;
     const int g1 = grid_n(C * P), g2 = grid_n(P);
     hipLaunchKernelGGL(cn_rows_kernel<0>, dim3(g1), dim3(256), 0, ctx->stream, in, (const float *)nullptr, (const float *)nullptr, C, H, W, kk, 1, tmp);
     hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, coef);
@@ -430,4 +427,15 @@ extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, 
     hipLaunchKernelGGL(cn_finish_kernel, dim3(g1), dim3(256), 0, ctx->stream, in, est, est2, coef, C, P, threshold, thresval, out);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
+}
+
+extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
+                                                 float thresval, float *out) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, in && kernel_host && out, DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
+    DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0, DFE_E_SHAPE, "dfe_contrastive_normalization_f32: C=%d %dx%d", C, H, W);
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, ((size_t)C + 3) * H * W * sizeof(float), &scr);
+    if (rc) return rc;
+    return dfe_contrastive_normalization_run(ctx, in, C, H, W, kernel_host, k, threshold, thresval, (float *)scr, out);
 }

@@ -1,0 +1,141 @@
+// ingest.hip -- frames as the camera delivers them: uint8 planes at the C ABI (a quarter of the host-to-device bytes of fp32 frames;
+// SURVEY section 8(e) "upload frames as uint8, not fp32"), and image.rgb2y for prepareInput (opticalflow_model.lua:131-151).
+//   dfe_u8_to_f32                      [n] uint8 -> float(value) * scale
+//   dfe_rgb2y_f32                      [3][H][W] -> [1][H][W], 0.299 R + 0.587 G + 0.114 B accumulated in that order, each product and
+//                                      sum rounded separately (image.rgb2y's THTensor cadd chain; `image` is un-vendored: parity unpinned)
+//   dfe_flow_depth_pair_u8             dfe_flow_depth_pair_f32 on uint8 frames
+//   dfe_multiscale_flow_pair_u8        dfe_multiscale_flow_pair_f32 / _f16 on uint8 frames
+// The uint8 entries convert into a per-ctx frame buffer (one pass: 0.9 MB read, 3.7 MB written per VGA frame, ~2 us) and run the fp32
+// pipeline on it -- bit-identical to the fp32 entry called on float(frame) * scale.  The conversion is NOT folded into the cost-volume
+// kernel: its frame-0 operands are scalar loads of whole fp32 rows (42 SGPRs a row, requested a row ahead), and unpacking bytes on the
+// scalar unit would put ~60 more scalar instructions into every row of a kernel that has no scalar register left.
+#include "dfe_internal.h"
+
+namespace {
+
+__global__ void u8_to_f32_kernel(const unsigned char *__restrict__ src, long long n, float scale, float *__restrict__ dst) {
+    // 4 pixels per thread: one 32-bit load, one 16-B store
+    const long long n4 = n >> 2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x) {
+        const unsigned v = reinterpret_cast<const unsigned *>(src)[e];
+        reinterpret_cast<float4 *>(dst)[e] = make_float4((float)(v & 255u) * scale, (float)((v >> 8) & 255u) * scale, (float)((v >> 16) & 255u) * scale,
+                                                         (float)(v >> 24) * scale);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (float)src[(n4 << 2) + threadIdx.x] * scale;
+}
+__global__ void u8_to_f32_bytes_kernel(const unsigned char *__restrict__ src, long long n, float scale, float *__restrict__ dst) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e] * scale;
+}
+
+__global__ void rgb2y_kernel(const float *__restrict__ rgb, long long P, float *__restrict__ y) {
+#pragma clang fp contract(off)
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (long long)gridDim.x * blockDim.x) {
+        float v = 0.299f * rgb[e];
+        v = v + 0.587f * rgb[P + e];
+        v = v + 0.114f * rgb[2 * P + e];
+        y[e] = v;
+    }
+}
+
+// minimum over the leading dimension of an [n][M] view (first row attaining it), one thread per column: tests/time_matching.lua:41-43
+__global__ void min_dim0_kernel(const float *__restrict__ in, int n, long long M, float *__restrict__ val, long long *__restrict__ idx) {
+    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+        float best = in[m];
+        int bi = 0;
+        for (int r = 1; r < n; ++r) {
+            const float v = in[(long long)r * M + m];
+            if (v < best) { best = v; bi = r; }
+        }
+        if (val) val[m] = best;
+        if (idx) idx[m] = (long long)bi + 1;
+    }
+}
+
+int in_grid(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 8192 ? 8192 : b);
+}
+
+int launch_u8(dfe_ctx *ctx, const unsigned char *src, long long n, float scale, float *dst) {
+    if ((((uintptr_t)src) & 3) == 0 && (((uintptr_t)dst) & 15) == 0)
+        hipLaunchKernelGGL(u8_to_f32_kernel, dim3(in_grid(n >> 2)), dim3(256), 0, ctx->stream, src, n, scale, dst);
+    else
+        hipLaunchKernelGGL(u8_to_f32_bytes_kernel, dim3(in_grid(n)), dim3(256), 0, ctx->stream, src, n, scale, dst);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+// the per-ctx fp32 copy of a uint8 frame pair (grow-only, next to the scratch arena that the pipelines themselves use)
+int ingest_pair(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, long long n, float scale, float **f0, float **f1) {
+    const size_t bytes = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    if (2 * bytes > ctx->ingest_bytes) {
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ingest) DFE_HIP(ctx, hipFree(ctx->ingest));
+        ctx->ingest = nullptr;
+        ctx->ingest_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->ingest, 2 * bytes);
+        if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "frame buffer hipMalloc(%zu): %s", 2 * bytes, hipGetErrorString(e));
+        ctx->ingest_bytes = 2 * bytes;
+    }
+    *f0 = (float *)ctx->ingest;
+    *f1 = (float *)((char *)ctx->ingest + bytes);
+    DfeStageScope st(ctx, DFE_STAGE_LOAD);
+    int rc = launch_u8(ctx, I0, n, scale, *f0);
+    if (rc) return rc;
+    return launch_u8(ctx, I1, n, scale, *f1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dfe_u8_to_f32(dfe_ctx *ctx, const uint8_t *src, int64_t n, float scale, float *dst) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, n >= 0, DFE_E_SHAPE, "dfe_u8_to_f32: n=%lld", (long long)n);
+    if (n == 0) return DFE_OK;
+    DFE_REQUIRE(ctx, src && dst, DFE_E_ARG, "dfe_u8_to_f32: NULL tensor");
+    return launch_u8(ctx, src, n, scale, dst);
+}
+
+int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val, int64_t *idx) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, in && (val || idx), DFE_E_ARG, "dfe_min_dim0_f32: NULL tensor");
+    DFE_REQUIRE(ctx, n > 0 && M > 0, DFE_E_SHAPE, "dfe_min_dim0_f32: %d x %lld", n, (long long)M);
+    hipLaunchKernelGGL(min_dim0_kernel, dim3(in_grid(M)), dim3(256), 0, ctx->stream, in, n, (long long)M, val, (long long *)idx);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_rgb2y_f32(dfe_ctx *ctx, const float *rgb, int H, int W, float *y) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, rgb && y, DFE_E_ARG, "dfe_rgb2y_f32: NULL tensor");
+    DFE_REQUIRE(ctx, H > 0 && W > 0, DFE_E_SHAPE, "dfe_rgb2y_f32: %dx%d", H, W);
+    hipLaunchKernelGGL(rgb2y_kernel, dim3(in_grid((long long)H * W)), dim3(256), 0, ctx->stream, rgb, (long long)H * W, y);
+    DFE_LAUNCH_CHECK(ctx);
+    return DFE_OK;
+}
+
+int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x,
+                           float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth, float *depth_conf) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, I0 && I1, DFE_E_ARG, "dfe_flow_depth_pair_u8: NULL frame");
+    DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && scale > 0, DFE_E_ARG, "dfe_flow_depth_pair_u8: C=%d %dx%d scale=%g", C, H, W, (double)scale);
+    float *f0 = nullptr, *f1 = nullptr;
+    int rc = ingest_pair(ctx, I0, I1, (long long)C * H * W, scale, &f0, &f1);
+    if (rc) return rc;
+    return dfe_flow_depth_pair_f32(ctx, f0, f1, C, H, W, k, hWin, wWin, foe_x, foe_y, extract_threshold, flow, scores, depth, depth_conf);
+}
+
+int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, I0 && I1, DFE_E_ARG, "dfe_multiscale_flow_pair_u8: NULL frame");
+    DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && scale > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_u8: C=%d %dx%d scale=%g", C, H, W, (double)scale);
+    float *f0 = nullptr, *f1 = nullptr;
+    int rc = ingest_pair(ctx, I0, I1, (long long)C * H * W, scale, &f0, &f1);
+    if (rc) return rc;
+    if (f16_scale != 0.f) return dfe_multiscale_flow_pair_f16(ctx, f0, f1, C, H, W, k, maxh, maxw, ratios, nratios, f16_scale, flow, idx);
+    return dfe_multiscale_flow_pair_f32(ctx, f0, f1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx);
+}
+
+}  // extern "C"

@@ -108,6 +108,47 @@ def getMiddleIndex(geometry):
     return yx2x(geometry, y, x)
 
 
+def rgb2y(rgb):
+    """image.rgb2y: [3][H][W] -> [1][H][W] luminance (dfe_rgb2y_f32)."""
+    if rgb.dim() != 3 or rgb.shape[0] != 3:
+        raise ValueError("rgb2y: 3 x H x W expected")
+    rgb = rgb.contiguous()
+    y = torch.empty((1, rgb.shape[1], rgb.shape[2]), dtype=torch.float32, device=rgb.device)
+    ctx = get_ctx(rgb)
+    ctx.check(lib().dfe_rgb2y_f32(ctx.handle, ptr(rgb), rgb.shape[1], rgb.shape[2], ptr(y)))
+    return y
+
+
+def prepareInput(geometry, patch1, patch2, literal_rgb2y=False):
+    """opticalflow_model.lua:131-151: what the drivers feed the model with.
+      * prefilter: the patches must have the last layer's plane count (:133-134);
+      * else, when the first layer reads one plane and the patches are RGB, they are turned into luminance (:136-138).  The script
+        writes `patch1 = image.rgb2y(patch1, patch2)` -- image.rgb2y(src, dst) converts patch1 INTO patch2's storage and returns it, so
+        read literally both inputs become the luminance of patch1 and the flow is zero everywhere.  Default here: each patch becomes its
+        own luminance (what the model needs); literal_rgb2y=True reproduces the line as written;
+      * multiscale: {patch1, patch2} as they are (the multiscale model pads and crops itself, :143-144);
+      * single scale: patch1 narrowed to the model's output region -- rows ceil(maxh/2) .. + H - maxh + 1, columns ceil(maxw/2) ..
+        (1-based, :147-149; the script's own TODO notes that the ground truth uses floor)."""
+    if tuple(patch1.shape) != tuple(patch2.shape):
+        raise AssertionError("prepareInput: patches of different sizes")   # assert(sameSize(patch1, patch2))
+    layers = _g(geometry, "layers")
+    if _g(geometry, "prefilter"):
+        assert patch1.shape[0] == layers[-1][3]
+    else:
+        if layers[0][0] == 1 and patch1.shape[0] == 3:
+            if literal_rgb2y:
+                patch1 = patch2 = rgb2y(patch1)
+            else:
+                patch1, patch2 = rgb2y(patch1), rgb2y(patch2)
+        assert patch1.shape[0] == layers[0][0]
+    if _g(geometry, "multiscale"):
+        return [patch1, patch2]
+    maxh, maxw = _g(geometry, "maxh"), _g(geometry, "maxw")
+    y0, x0 = math.ceil(maxh / 2) - 1, math.ceil(maxw / 2) - 1                  # narrow(2, ceil(maxh/2), H - maxh + 1), 1-based
+    p1 = patch1[:, y0 : y0 + patch1.shape[1] - maxh + 1, x0 : x0 + patch1.shape[2] - maxw + 1].contiguous()
+    return [p1, patch2]
+
+
 def getOutputConfidences(geometry, input, threshold=None):
     """opticalflow_model.lua:153-169.  input H x W x N (probabilities).  Without threshold: arg-max
     with the centre tie-break, confidences = 1.  With threshold: extractOutput(input, 0.11) and

@@ -440,6 +440,40 @@ int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
  * in / out [C][H][W]. */
 int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k,
                                       float threshold, float thresval, float *out);
+/* ---- frames as the camera delivers them: uint8 planes ("upload frames as uint8, not fp32") ---------------------- */
+/* dst[i] = float(src[i]) * scale (scale = 1: the integer values; 1/255: image.load's [0, 1] range). */
+int dfe_u8_to_f32(dfe_ctx *ctx, const uint8_t *src, int64_t n, float scale, float *dst);
+/* replaces: image.rgb2y as prepareInput calls it (opticalflow_model.lua:136-138; un-vendored `image`, restated: parity unpinned).
+ *   rgb [3][H][W] -> y [1][H][W] = 0.299 R + 0.587 G + 0.114 B, accumulated in that order with separately rounded products and sums. */
+int dfe_rgb2y_f32(dfe_ctx *ctx, const float *rgb, int H, int W, float *y);
+/* replaces: tensor:min(1) on an n x M view (tests/time_matching.lua:41-43: `output:min(1)` of the matcher's output behind
+ *   nn.Reshape(wsize*wsize, ...)): val[m] = min_r in[r][m], idx[m] = the first r attaining it, 1-based; either may be NULL. */
+int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val, int64_t *idx);
+/* dfe_flow_depth_pair_f32 on uint8 frames [C][H][W]: float(frame) * scale is made on the device (one conversion pass into a per-ctx
+ * buffer) and the fp32 pipeline runs on it -- results are bit-identical to the fp32 entry on the same values.  A quarter of the
+ * host-to-device bytes. */
+int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int hWin, int wWin,
+                           float foe_x, float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth,
+                           float *depth_conf);
+/* dfe_multiscale_flow_pair_f32 (f16_scale == 0) or dfe_multiscale_flow_pair_f16 (f16_scale != 0: its `scale`) on uint8 frames. */
+int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx);
+
+/* ---- version2/: the single-scale learned model as ONE call -------------------------------------------------------------------- */
+/* replaces: version2/test.lua:40-53 on getNetwork(datap) of version2/network.lua:5-39 for one frame pair --
+ *   network:forward({prev, cur}) = ParallelTable{ Sequential{SpatialContrastiveNormalization(C, gaussian1D(normalization_k)),
+ *   SpatialPadding(-lWin, -tWin, -rWin, -bWin), conv stack}, Sequential{the same normalisation, the same conv stack (shared weights)} }
+ *   -> SpatialMatching(hWin, wWin, false); then `output:min(3)`, idx - 1, yflow = floor(idx / wWin) - tWin, xflow = idx - yflow' * wWin - lWin
+ *   with lWin = ceil(wWin/2) - 1, tWin = ceil(hWin/2) - 1 (test.lua:18-21).  The minimum is taken over the whole hWin x wWin window in
+ *   index order (first minimum), which is what the decode that follows it assumes.
+ *   prev, cur [C][H][W]; norm_kernel_host: the 1-D normalisation kernel (HOST, norm_k <= 33 taps); layers: HOST array of nlayers
+ *   convolution layers (version2 puts no Tanh between them: tanh_after = 0; the struct's other fields as in getFilter).
+ *   Outputs over the dense inference region H1 x W1 = (H - (hWin-1) - (hKernel-1)) x (W - (wWin-1) - (wKernel-1)):
+ *   xflow, yflow [H1][W1] float (may be NULL), idx [H1][W1] int64 1-based as torch's min returns it (may be NULL),
+ *   volume [H1][W1][hWin][wWin] (may be NULL: then it lives in the ctx scratch arena only). */
+int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const float *cur, int C, int H, int W, const float *norm_kernel_host,
+                               int norm_k, float threshold, float thresval, const dfe_filter_layer *layers, int nlayers, int hWin,
+                               int wWin, float *xflow, float *yflow, int64_t *idx, float *volume);
 /* nn.SpatialConvolution [+ nn.Tanh] as an implicit GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32
  * accumulate, an fmaf chain in the reference's (input plane, ky, kx) order).  Same layouts as dfe_spatial_convolution_f32;
  * results differ from it by the fusing of each multiply-add only (<= 1e-5 relative to sum |terms|).  kH x kW up to what

@@ -1357,3 +1357,18 @@ int orc_ego_motion_from_points(const float *p1, const float *p2, const float *w,
     free(mask);
     return 0;
 }
+
+/* image.rgb2y as prepareInput calls it (opticalflow_model.lua:136-138): y = 0.299 R + 0.587 G + 0.114 B, accumulated in that order
+ * (output:zero():add(0.299, R):add(0.587, G):add(0.114, B) -- THTensor cadd, float products and sums rounded separately).
+ * `image` is an un-vendored package: restated from recall, parity unpinned. */
+void orc_rgb2y(const float *rgb, int H, int W, float *y) {
+    const long long P = (long long)H * W;
+    for (long long e = 0; e < P; ++e) {
+        volatile float v = 0.299f * rgb[e];
+        volatile float t = 0.587f * rgb[P + e];
+        v = v + t;
+        t = 0.114f * rgb[2 * P + e];
+        v = v + t;
+        y[e] = v;
+    }
+}

@@ -57,6 +57,7 @@ void orc_spatial_convolution_fma(const float *in, const float *weight, const flo
 void orc_contrastive_normalization(const float *in, int C, int H, int W, const float *kernel, int k, float threshold,
                                    float thresval, float *out);
 void orc_tanh(const float *in, int64_t n, float *out);
+void orc_rgb2y(const float *rgb, int H, int W, float *y);
 void orc_spatial_convolution_grad_input(const float *go, const float *weight, const int *conn, int nConn, int nIn, int nOut,
                                         int H, int W, int kH, int kW, float *gi);
 void orc_spatial_convolution_acc_grad(const float *in, const float *go, const int *conn, int nConn, int nIn, int nOut, int H,

@@ -54,6 +54,7 @@ def lib():
             "orc_spatial_convolution_fma": (None, [f32p, f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f32p]),
             "orc_contrastive_normalization": (None, [f32p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_float, C.c_float, f32p]),
             "orc_tanh": (None, [f32p, C.c_int64, f32p]),
+            "orc_rgb2y": (None, [f32p, C.c_int, C.c_int, f32p]),
             "orc_spatial_convolution_grad_input": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [f32p]),
             "orc_spatial_convolution_acc_grad": (None, [f32p, f32p, C.c_void_p] + [C.c_int] * 7 + [C.c_float, f32p, C.c_void_p]),
             "orc_tanh_backward": (None, [f32p, f32p, C.c_int64, f32p]),
@@ -297,6 +298,14 @@ def gaussian1D(size, sigma=0.25, amplitude=1.0, normalize=False):
     if normalize:
         g = g / g.sum()
     return g.astype(np.float32)
+
+
+def rgb2y(rgb):
+    rgb = _f(rgb)
+    _, H, W = rgb.shape
+    y = np.empty((1, H, W), np.float32)
+    lib().orc_rgb2y(rgb, H, W, y)
+    return y
 
 
 def contrastive_normalization(inp, kernel, threshold=1e-4, thresval=1e-4):

@@ -249,3 +249,30 @@ def radial_path_oracle(prev_img, img, e2, networkp, w1, b1, w2, b2, tanh_between
     infty = math.floor(math.sqrt(max(max(cx * cx + cy * cy, (wImg - cx) ** 2 + cy * cy), max(cx * cx + (hImg - cy) ** 2, (wImg - cx) ** 2 + (hImg - cy) ** 2)))) * kinfty
     depth, conf = orc.flow_to_depth_radial(cart, cx, cy, infty)
     return dict(polar_prev=pp, polar_img=pi, feat1=f1, feat2=f2, output=out, polar_flow=pf, flow=cart, depth=depth, confs=conf)
+
+
+def version2_flow_oracle(prev, cur, datap, weights, biases, threshold=1e-4, thresval=1e-4):
+    """version2/test.lua:43-51 on the oracle: getNetwork(datap):forward({prev, cur}) (version2/network.lua:5-39: contrastive
+    normalisation of both frames with gaussian1D(normalization_k), the first branch cropped by the window, the shared convolution
+    stack, SpatialMatching(hWin, wWin)) and the decode (first minimum over the window, yflow = idx // wWin - tWin,
+    xflow = idx % wWin - lWin).  weights[i] [nOut][nIn][kH][kW], biases[i] [nOut]."""
+    import math
+    from tests import oracle as orc
+
+    k = datap["normalization_k"]
+    i = np.arange(1, k + 1, dtype=np.float64)
+    g = np.exp(-(((i - (k / 2 + 0.5)) / (0.25 * k)) ** 2) / 2).astype(np.float32)      # image.gaussian1D(k): sigma 0.25, amplitude 1
+    n0 = orc.contrastive_normalization(prev, g, threshold, thresval)
+    n1 = orc.contrastive_normalization(cur, g, threshold, thresval)
+    hWin, wWin = datap["hWin"], datap["wWin"]
+    lWin, tWin = math.ceil(wWin / 2) - 1, math.ceil(hWin / 2) - 1
+    H, W = prev.shape[1:]
+    a = np.ascontiguousarray(n0[:, tWin : tWin + H - (hWin - 1), lWin : lWin + W - (wWin - 1)])
+    b = n1
+    for w, bb in zip(weights, biases):
+        a = orc.spatial_convolution(a, w, bb)
+        b = orc.spatial_convolution(b, w, bb)
+    vol = orc.spatial_matching(a, b, hWin, wWin)
+    H1, W1 = vol.shape[:2]
+    idx0 = vol.reshape(H1, W1, -1).argmin(axis=2)               # numpy: the first minimum
+    return {"volume": vol, "index": idx0 + 1, "yflow": (idx0 // wWin - tWin).astype(np.float32), "xflow": (idx0 % wWin - lWin).astype(np.float32)}

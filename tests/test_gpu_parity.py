@@ -1070,3 +1070,180 @@ def test_entry_points_run_on_their_ctx_device_and_leave_the_callers_alone(dfe, c
             np.testing.assert_array_equal(got, ref)
         lib.dfe_ctx_destroy(h)
         assert hip.hipSetDevice(before) == 0
+
+
+# ------------------------------------------------------------------ version2/: the single-scale learned model
+@pytest.mark.parametrize("H,W,layers,win", [
+    (60, 300, [(3, 17, 17, 8)], 17),                 # the script's geometry with fewer planes: 17 x 17 kernel, 17 x 17 window (flat-tile matcher, extra row)
+    (48, 64, [(3, 5, 5, 4), (4, 3, 3, 6)], 9),      # two layers, small window (chunk matcher)
+])
+def test_version2_one_call_equals_staged_and_oracle(dfe, cuda, H, W, layers, win):
+    """version2/test.lua:40-51: getNetwork(datap), flat parameters loaded, forward on a frame pair, the dense decode.
+    dfe_version2_flow_pair_f32 == the module-by-module host path bit for bit (volume, index, flows); both against the oracle
+    composition (tests/refpath.version2_flow_oracle): the volume to 1e-4 relative (the normalisation divides by a device sqrt), the
+    arg-min wherever the oracle's two smallest costs are not within that band."""
+    v2 = dfe.version2
+    datap = v2.defaultDatap(wImg=W, hImg=H, normalization_k=9, layers=layers, wWin=win, hWin=win)
+    g = torch.Generator().manual_seed(H + W)
+    net = v2.getNetwork(datap, device=cuda, generator=g)
+    flat = (torch.rand(net.flatParameters().numel(), generator=g) - 0.5) * 0.2
+    net.loadParameters(flat)                                               # parameters:copy(torch.load(...))
+    assert torch.equal(net.flatParameters().cpu(), flat)
+    f1c = net.modules[0].modules[0].modules[2:]
+    f2c = net.modules[0].modules[1].modules[1:]
+    assert all(a.weight.data_ptr() == b.weight.data_ptr() for a, b in zip(f1c, f2c)), "the second branch shares the first one's weights"
+    rng = np.random.default_rng(W)
+    prev = rng.random((3, H, W), dtype=np.float32)
+    cur = np.roll(prev, (2, -3), axis=(1, 2)) + rng.normal(0, 0.01, (3, H, W)).astype(np.float32)
+    tp, tc = T(prev, cuda), T(cur, cuda)
+    staged = v2.flowPair(net, datap, tp, tc, one_call=False, want_volume=True)
+    one = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=True)
+    for k in ("volume", "index", "xflow", "yflow"):
+        assert torch.equal(staged[k], one[k]), k
+    xf, yf = v2.decodeFlow(staged["volume"], datap)                        # test.lua:45-51 on the module output
+    assert torch.equal(xf.to(torch.float32), one["xflow"]) and torch.equal(yf.to(torch.float32), one["yflow"])
+    ws = [m.weight.cpu().numpy() for m in f1c]
+    bs = [m.bias.cpu().numpy() for m in f1c]
+    ref = rp.version2_flow_oracle(prev, cur, datap, ws, bs)
+    vol = one["volume"].cpu().numpy()
+    assert vol.shape == ref["volume"].shape
+    assert np.allclose(vol, ref["volume"], rtol=1e-4, atol=1e-5 * float(np.abs(ref["volume"]).max()))
+    srt = np.sort(ref["volume"].reshape(vol.shape[0], vol.shape[1], -1), axis=2)
+    clear = (srt[..., 1] - srt[..., 0]) > 2e-4 * srt[..., 1] + 1e-5 * float(np.abs(ref["volume"]).max())
+    assert clear.mean() > 0.9
+    assert np.array_equal(one["index"].cpu().numpy()[clear], ref["index"][clear])
+    assert np.array_equal(one["xflow"].cpu().numpy()[clear], ref["xflow"][clear]) and np.array_equal(one["yflow"].cpu().numpy()[clear], ref["yflow"][clear])
+    # the planted shift is what most pixels find: cur = prev rolled by (+2, -3) -> the window cell of prev's pixel in cur
+    inner = one["yflow"].cpu().numpy()[8:-8, 8:-8], one["xflow"].cpu().numpy()[8:-8, 8:-8]
+    assert np.mean((inner[0] == 2) & (inner[1] == -3)) > 0.6
+
+
+def test_version2_trainer_network_patch_mode(dfe, cuda):
+    """getTrainerNetwork (version2/network.lua:41-47) in patch mode: a hKernel x wKernel patch against its (hKernel + hWin - 1)-sized
+    neighbourhood -> log-probabilities over the hWin * wWin displacements; exp sums to one, the arg-max is the planted displacement."""
+    v2 = dfe.version2
+    datap = v2.defaultDatap(normalization_k=5, layers=[(3, 5, 5, 6)], wWin=9, hWin=9)
+    g = torch.Generator().manual_seed(5)
+    net = v2.getTrainerNetwork(datap, device=cuda, generator=g)
+    # patch mode bypasses the crop (the trainer feeds already-cropped patches): replace it by the identity, as the patches are pre-cut
+    net.modules[0].modules[0].modules[1] = dfe.radial.SpatialPadding(0, 0, 0, 0)
+    rng = np.random.default_rng(9)
+    big = rng.random((3, 5 + 8, 5 + 8), dtype=np.float32)
+    dy, dx = 6, 2
+    patch = big[:, dy : dy + 5, dx : dx + 5].copy()
+    out = net.forward([T(patch, cuda), T(big, cuda)])
+    assert tuple(out.shape) == (81,)
+    assert abs(float(out.exp().sum()) - 1.0) < 1e-4
+    # (the normalisation sees different neighbourhoods in the two branches, so the match is approximate: the planted cell is among the best)
+    assert int(out.argmax()) in {dy * 9 + dx + o for o in (-10, -9, -8, -1, 0, 1, 8, 9, 10)}
+
+
+# ------------------------------------------------------------------ prepareInput / rgb2y / uint8 ingest
+def test_rgb2y_and_prepare_input(dfe, cuda):
+    """opticalflow_model.lua:131-151: luminance switch for one-plane models (dfe_rgb2y_f32 == oracle bit for bit), the single-scale
+    narrow of patch 1 by the search window (rows / columns ceil(max/2) .., H - maxh + 1 of them), the multiscale pass-through, the
+    prefilter plane check, and the line as literally written (both patches = the luminance of patch 1)."""
+    rng = np.random.default_rng(4)
+    a = rng.random((3, 40, 52), dtype=np.float32)
+    b = rng.random((3, 40, 52), dtype=np.float32)
+    ta, tb = T(a, cuda), T(b, cuda)
+    assert np.array_equal(dfe.rgb2y(ta).cpu().numpy(), orc.rgb2y(a))
+    geo = dict(layers=[[1, 5, 5, 4]], maxh=16, maxw=17, multiscale=False)
+    p1, p2 = dfe.prepareInput(geo, ta, tb)
+    assert tuple(p2.shape) == (1, 40, 52) and tuple(p1.shape) == (1, 40 - 16 + 1, 52 - 17 + 1)
+    assert np.array_equal(p2.cpu().numpy(), orc.rgb2y(b))
+    assert np.array_equal(p1.cpu().numpy(), orc.rgb2y(a)[:, 7 : 7 + 25, 8 : 8 + 36])          # narrow(2, ceil(16/2) = 8, 25) 1-based -> rows 7..31
+    l1, l2 = dfe.prepareInput(geo, ta, tb, literal_rgb2y=True)
+    assert np.array_equal(l2.cpu().numpy(), orc.rgb2y(a))                                      # as written: patch2 is overwritten by patch1's luminance
+    m1, m2 = dfe.prepareInput(dict(layers=[[3, 5, 5, 4]], maxh=8, maxw=8, multiscale=True), ta, tb)
+    assert m1 is ta and m2 is tb
+    with pytest.raises(AssertionError):
+        dfe.prepareInput(dict(layers=[[3, 5, 5, 4]], maxh=8, maxw=8, multiscale=True, prefilter=True), ta, tb)   # 3 planes, the stack ends in 4
+    with pytest.raises(AssertionError):
+        dfe.prepareInput(geo, ta, tb[:, :-1])
+
+
+def test_uint8_frames_equal_the_fp32_entries(dfe, cuda):
+    """dfe_flow_depth_pair_u8 / dfe_multiscale_flow_pair_u8 on uint8 frames == the fp32 entries on float(frame) * scale, bit for bit
+    (odd sizes: the conversion's 4-pixel and byte paths), and dfe_u8_to_f32 itself."""
+    from depth_estimation_amd._lib import ratios_array
+
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    rng = np.random.default_rng(12)
+    H, W, k, win = 75, 101, 7, 33
+    u0 = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    u1 = np.roll(u0, (1, -2), axis=(1, 2))
+    t0, t1 = torch.from_numpy(u0).to(cuda), torch.from_numpy(u1).to(cuda)
+    for scale in (1.0, 1.0 / 255.0):
+        f0 = torch.empty((3, H, W), device=cuda)
+        ctx.check(lib.dfe_u8_to_f32(ctx.handle, t0.data_ptr(), t0.numel(), scale, f0.data_ptr()))
+        assert np.array_equal(f0.cpu().numpy(), u0.astype(np.float32) * np.float32(scale))
+        odd = torch.empty((t0.numel() - 1,), device=cuda)
+        ctx.check(lib.dfe_u8_to_f32(ctx.handle, t0.data_ptr() + 1, t0.numel() - 1, scale, odd.data_ptr()))   # unaligned source: the byte path
+        assert np.array_equal(odd.cpu().numpy(), u0.reshape(-1)[1:].astype(np.float32) * np.float32(scale))
+    f0, f1 = t0.to(torch.float32), t1.to(torch.float32)
+    outs = []
+    for which in ("f32", "u8"):
+        flow = torch.full((2, H, W), -9.0, device=cuda)
+        scores, depth, conf = (torch.full((H, W), -9.0, device=cuda) for _ in range(3))
+        if which == "f32":
+            ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, f0.data_ptr(), f1.data_ptr(), 3, H, W, k, win, win, 50.0, 37.0, 0.21, flow.data_ptr(), scores.data_ptr(),
+                                                  depth.data_ptr(), conf.data_ptr()))
+        else:
+            ctx.check(lib.dfe_flow_depth_pair_u8(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, win, win, 50.0, 37.0, 0.21, 1.0, flow.data_ptr(), scores.data_ptr(),
+                                                 depth.data_ptr(), conf.data_ptr()))
+        outs.append((flow, scores, depth, conf))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    Hm, Wm = 64, 96
+    m0, m1 = t0[:, :Hm, :Wm].contiguous(), t1[:, :Hm, :Wm].contiguous()
+    rr, n = ratios_array([1, 2, 4])
+    res = []
+    for which, fs in (("f32", 0.0), ("u8", 0.0), ("f16", 2.0 ** -8), ("u8", 2.0 ** -8)):
+        flow = torch.empty((2, Hm, Wm), device=cuda)
+        idx = torch.empty((Hm, Wm), dtype=torch.int64, device=cuda)
+        a0, a1 = m0.to(torch.float32), m1.to(torch.float32)
+        if which == "f32":
+            ctx.check(lib.dfe_multiscale_flow_pair_f32(ctx.handle, a0.data_ptr(), a1.data_ptr(), 3, Hm, Wm, 7, 8, 8, rr, n, flow.data_ptr(), idx.data_ptr()))
+        elif which == "f16":
+            ctx.check(lib.dfe_multiscale_flow_pair_f16(ctx.handle, a0.data_ptr(), a1.data_ptr(), 3, Hm, Wm, 7, 8, 8, rr, n, fs, flow.data_ptr(), idx.data_ptr()))
+        else:
+            ctx.check(lib.dfe_multiscale_flow_pair_u8(ctx.handle, m0.data_ptr(), m1.data_ptr(), 3, Hm, Wm, 7, 8, 8, rr, n, 1.0, fs, flow.data_ptr(), idx.data_ptr()))
+        res.append((flow, idx))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[2][0], res[3][0]) and torch.equal(res[2][1], res[3][1])
+
+
+def test_time_matching_lua_exact_shape(dfe, cuda):
+    """tests/time_matching.lua:5-47 at its own shape: getFilter({3,5,5,4},{4,5,5,4},{4,5,5,10}) on randn 3 x 180 x 320 frames, the narrow of
+    prepareInput, nn.SpatialMatching(16, 16) on the 10-plane 168 x 308 features (output 153 x 293 x 16 x 16) and the script's min over
+    the leading dimension of its Reshape(256, 293, 153) view -- features and volume bit-exact against the oracle (the exact convolution and
+    the k-ordered matcher), the minimum against numpy."""
+    g = torch.Generator().manual_seed(1)
+    geometry = dict(maxh=16, maxw=16, layers=[[3, 5, 5, 4], [4, 5, 5, 4], [4, 5, 5, 10]], multiscale=False, prefilter=True)
+    filt = dfe.getFilter(geometry, device=cuda, generator=g)
+    im1, im2 = torch.randn((3, 180, 320), generator=g), torch.randn((3, 180, 320), generator=g)
+    f1 = filt.forward(im1.to(cuda)).clone()
+    f2 = filt.forward(im2.to(cuda))
+    assert tuple(f1.shape) == (10, 168, 308)
+    layers = []
+    for m in filt.modules:
+        if isinstance(m, dfe.network.Tanh):
+            layers[-1]["tanh"] = True
+        else:
+            layers.append({"weight": m.weight.cpu().numpy(), "bias": m.bias.cpu().numpy(), "tanh": False})
+    r1, r2 = rp.filter_stack_oracle(im1.numpy(), layers), rp.filter_stack_oracle(im2.numpy(), layers)
+    assert np.allclose(f1.cpu().numpy(), r1, rtol=0, atol=2e-6) and np.allclose(f2.cpu().numpy(), r2, rtol=0, atol=2e-6)   # (device tanhf vs glibc)
+    p1, p2 = dfe.prepareInput(geometry, f1, f2)
+    assert tuple(p1.shape) == (10, 153, 293)
+    out = dfe.nn.SpatialMatching(16, 16, False).forward([p1, p2])
+    assert dfe.get_ctx(0).last_kernel() == "feat_matching_flat_kernel"
+    assert np.array_equal(out.cpu().numpy(), orc.spatial_matching(p1.cpu().numpy(), p2.cpu().numpy(), 16, 16))
+    ctx = dfe.get_ctx(0)
+    M = 293 * 153
+    mn = torch.empty((M,), device=cuda)
+    mi = torch.empty((M,), dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_min_dim0_f32(ctx.handle, out.data_ptr(), 256, M, mn.data_ptr(), mi.data_ptr()))
+    view = out.cpu().numpy().reshape(256, M)
+    assert np.array_equal(mn.cpu().numpy(), view.min(axis=0)) and np.array_equal(mi.cpu().numpy(), view.argmin(axis=0) + 1)
