@@ -139,6 +139,22 @@ def timed_region(step, steps, warmup, world, dist, device, sync, spin_s=0.08, be
     return float(el.item())
 
 
+def scale_leg(step, steps, warmup, world, dist, device, sync, H, W, spin_s=0.04):
+    """A second timed region of the same protocol on another frame size, run only when world > 1: the >= 6x-at-8-GPUs target of the
+    north star is stated for batched 1080p pairs, the driver's scaling run uses the default (VGA) workload -- so the VGA line carries
+    the 1080p number of the same launch as an extra key (`scale_1080p`).  Returns {value, ms_per_step, pairs_per_step}."""
+    el = timed_region(step, steps, warmup, world, dist, device, sync, spin_s=spin_s)
+    return {"value": round(world * steps * H * W / el / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(el / steps * 1e3, 4), "pairs_per_step": world,
+            "steps": steps, "warmup": warmup}
+
+
+def rccl_info(dist, world):
+    """What the live process group is: {"world", "backend"} (backend "nccl" IS RCCL on ROCm; gloo in the CPU tests)."""
+    if world <= 1 or not dist.is_initialized():
+        return {"world": 1, "backend": None}
+    return {"world": dist.get_world_size(), "backend": dist.get_backend()}
+
+
 def gather_results(tensors, world, rank, dist, sync):
     """Optional result gather: every rank's per-pair outputs -- flow as int16 x 2, confidence and depth fp32 --
     to rank 0 over the process group (RCCL gather over xGMI on the GPU box), timed on its own, outside the timed region.
@@ -198,6 +214,8 @@ def run_banded_step(frames_u8, plan, world, rank, dist, compute_band, device, sy
     t0 = time.perf_counter()
     if world > 1:
         dist.broadcast(frames_u8, src=0)
+        if timing is not None:
+            sync()          # (the collective is asynchronous to the host: without this its time would be charged to `compute`)
     t1 = time.perf_counter()
     mine = {}
     for b, (o0, o1, r0, r1) in enumerate(plan):
@@ -460,7 +478,9 @@ def main_bands(args, world, rank, local_rank, dev, torch, dist, d, rp):
             "dtype": "f32 sums, f16 volume%s" % ("" if kind == "single" else "s"), "data": "synthetic",
             "config": {"workload": "%dx%d C=%d %s, fp16 volume(s); uint8 frames broadcast from rank 0, %d row bands (halo %d rows), owned rows gathered to rank 0"
                                    % (W, H, Cc, "single-scale 33x33" if kind == "single" else "pyramid %s 8x8" % list(ratios), len(plan), compute.halo),
-                       "pairs_per_step": 1, "sharding": "row-bands", "bands": len(plan)},
+                       "pairs_per_step": 1, "sharding": "row-bands", "bands": len(plan),
+                       # rows computed per row owned, summed over the bands: what the halo recompute costs the strong-scaling efficiency
+                       "halo_overhead": round(sum(r1 - r0 for _, _, r0, r1 in plan) / float(sum(o1 - o0 for o0, o1, _, _ in plan)), 4)},
             "roofline": {"bound": "hbm", "kernel": "whole step (broadcast, band pipelines, gather)", "achieved": round(balg / step_s / 1e9, 2),
                          "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(balg / step_s / 1e9 / (HBM_PEAK_GBS * world), 4), "traffic": None,
                          "algorithmic_bytes_per_launch": balg},
@@ -718,8 +738,10 @@ def main():
     elapsed = timed_region(step, args.steps, args.warmup, world, dist, dev, torch.cuda.synchronize, before_timed=before_timed)
     kernel = kernel[0]
     cv_ms, cv_n = C.c_double(), C.c_int()
-    ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(cv_ms), C.byref(cv_n)))
+    each = (C.c_float * max(args.steps * 4, 1))()
+    ctx.check(lib.dfe_profile_read_each(ctx.handle, C.byref(cv_ms), C.byref(cv_n), each, len(each)))
     ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
+    each = sorted(each[: min(cv_n.value, len(each))])
 
     # outside the timed region: the cost-volume build ALONE (dfe_ssd_cost_volume_f32, no flow epilogue), the kernel the
     # north-star roofline target is stated for; reported as `roofline_build_only` next to the step's dominant kernel
@@ -756,6 +778,51 @@ def main():
         if rank == 0:
             assert len(res) == world and torch.equal(res[0][1], scores)
             gather = {"ms": round(g_s * 1e3, 3), "bytes_to_rank0": g_bytes, "note": "untimed: after the K steps, one gather of every pair's {flow int16 x2, scores, depth}"}
+
+    # "H2D excluded and included, both stated".  `value` above has the frames resident in HBM; this leg starts every step
+    # from PINNED HOST uint8 frames (what a camera pipeline holds): two async copies on the step's stream + dfe_flow_depth_pair_u8
+    # (conversion on the device), nothing overlapped -- the serial cost of the boundary; with two streams the copy of pair i+1 would hide
+    # behind the step of pair i.
+    h2d = None
+    if rank == 0 and not f16 and Cc == 3:
+        hu0 = torch.from_numpy(f0.astype(np.uint8)).pin_memory()
+        hu1 = torch.from_numpy(f1.astype(np.uint8)).pin_memory()
+        du0, du1 = torch.empty_like(hu0, device=dev), torch.empty_like(hu1, device=dev)
+
+        def step_h2d():
+            du0.copy_(hu0, non_blocking=True)
+            du1.copy_(hu1, non_blocking=True)
+            ctx.check(lib.dfe_flow_depth_pair_u8(ctx.handle, du0.data_ptr(), du1.data_ptr(), Cc, H, W, k, hWin, wWin, cx, cy, 0.21, 1.0,
+                                                 flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), dconf.data_ptr()))
+
+        for _ in range(5):
+            step_h2d()
+        torch.cuda.synchronize()
+        nh = max(20, min(args.steps, 100))
+        th = time.perf_counter()
+        for _ in range(nh):
+            step_h2d()
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - th) / nh
+        h2d = {"value": round(H * W / th / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(th * 1e3, 4), "host_bytes_per_step": int(2 * hu0.numel()),
+               "note": "pinned host uint8 frames -> device per step (2 async copies + on-device conversion + the same pipeline), serial on one stream; "
+                       "fp32 frames would move 4x the bytes"}
+
+    scale1080 = None
+    if world > 1 and args.workload == "vga":
+        # the same step on one 1080p pair per GPU (8.6 GB of volume each: fits the default 16-GiB arena in one band)
+        H2, W2 = WORKLOADS["1080p"][:2]
+        g0, g1, _, (cx2, cy2) = rp.synth_pair(H2, W2, C=Cc, seed=pair_id, max_flow=12)
+        u0, u1 = torch.from_numpy(g0).to(dev), torch.from_numpy(g1).to(dev)
+        fl2 = torch.empty((2, H2, W2), device=dev)
+        sc2, de2, co2 = (torch.empty((H2, W2), device=dev) for _ in range(3))
+
+        def step1080():
+            ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, u0.data_ptr(), u1.data_ptr(), Cc, H2, W2, k, hWin, wWin, cx2, cy2, 0.21,
+                                                  fl2.data_ptr(), sc2.data_ptr(), de2.data_ptr(), co2.data_ptr()))
+
+        scale1080 = scale_leg(step1080, max(5, args.steps // 4), max(2, args.warmup // 4), world, dist, dev, torch.cuda.synchronize, H2, W2)
+        del u0, u1, fl2, sc2, de2, co2
 
     if rank == 0:
         balg = algorithmic_bytes(H, W, Cc, k, hWin, wWin, 2 if f16 else 4)
@@ -810,6 +877,8 @@ def main():
                 "gflops_sliding_window": round((3 * Cc + 4) * (H - k - hWin + 2) * (W - k - wWin + 2) * hWin * wWin / kern_s / 1e9, 1)
                 if kern_s > 0 else None,
                 "kernel_ms": round(kern_s * 1e3, 5),
+                # per launch, over the timed region (the average above is what `frac` prices)
+                "kernel_ms_min_median_max": [round(each[0], 5), round(each[len(each) // 2], 5), round(each[-1], 5)] if each else None,
                 "launches_timed": cv_n.value,
                 "launches_per_step": cv_n.value // max(args.steps, 1),
             },
@@ -823,6 +892,11 @@ def main():
             }
         if gather:
             out["gather"] = gather
+        if h2d:
+            out["h2d_inclusive"] = h2d
+        if scale1080:
+            out["scale_1080p"] = scale1080
+        out["rccl"] = rccl_info(dist, world)
         if world == 1 and not args.no_cpu_baseline and not f16:
             out["cpu_baseline"] = cpu_baseline(f0, f1, k, hWin, wWin, cx, cy)
         print(json.dumps(out), flush=True)

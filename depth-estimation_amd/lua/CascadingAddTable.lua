@@ -11,7 +11,7 @@ local CascadingAddTable, parent = torch.class('nn.CascadingAddTable', 'nn.Module
 function CascadingAddTable:__init(ratios, trainable, single_beta)
    parent.__init(self)
    self.ratios = ratios
-   self.trainable = trainable or false
+   if trainable == nil then self.trainable = true else self.trainable = trainable end   -- (the reference's default, CascadingAddTable.lua:11)
    self.single_beta = single_beta or false
    self.output = {}
    self.gradInput = {}

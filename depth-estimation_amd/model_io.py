@@ -73,15 +73,21 @@ def loadModel(filename, full_output=True, prefilter=False, wImg=None, hImg=None,
     geometry["training_mode"] = not full_output                                                         # :176-180
     make = getModelMultiscale if geometry.get("multiscale") else getModel
     ret = {"geometry": geometry, "score": loaded.get("score"), "getKernels": loaded.get("getKernels")}
-    ret["model"] = make(geometry, full_output, prefilter, device=device) if not prefilter else make(geometry, full_output, True)
+    ret["model"] = make(geometry, full_output, prefilter, device=device)
     weights = loaded.get("weights") or {}
+
+    def _w(k):
+        if k not in weights:
+            raise ValueError("loadModel: %s holds no weight named '%s' (it has %s)" % (filename, k, sorted(weights)))
+        return weights[k]
+
     if prefilter:                                                                                       # :184-195
         filt = getFilter(geometry, device=device)
         ret["filter"] = getMultiscalePrefilter(geometry, filt) if geometry.get("multiscale") else filt
         for k, w in ret["filter"].getWeights().items():
-            _copy_into(w, weights[k], k)
+            _copy_into(w, _w(k), k)
     for k, w in ret["model"].getWeights().items():                                                      # :192-199
-        _copy_into(w, weights[k], k)
+        _copy_into(w, _w(k), k)
     return ret
 
 

@@ -8,7 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
-SO = os.path.join(ODIR, "libdfe_oracle.so")
+# DFE_ORACLE_SO: another build of the same source (the AddressSanitizer build of `make -C oracle asan`, tests/test_sanitizer_cpu.py)
+SO = os.environ.get("DFE_ORACLE_SO") or os.path.join(ODIR, "libdfe_oracle.so")
 
 _lib = None
 f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -17,6 +18,8 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
 def build():
+    if os.environ.get("DFE_ORACLE_SO"):
+        return
     src = os.path.join(ODIR, "dfe_oracle.c")
     if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ODIR, "dfe_oracle.h"))):
         subprocess.check_call(["make", "-C", ODIR, "libdfe_oracle.so"], stdout=subprocess.DEVNULL)

@@ -41,7 +41,10 @@ def _worker(rank, world, port, q):
     idx = torch.from_numpy(res[0]["idx"]).to(torch.int16)
     best = torch.from_numpy(res[0]["best"])
     gathered, g_s, g_bytes = bench.gather_results([idx, best], world, rank, dist, lambda: None)
-    q.put((rank, pair, el, calls[0], marks, int(idx.sum()), None if gathered is None else [[int(t.sum()) for t in r] for r in gathered], g_bytes))
+    # the extra keys of a multi-rank line: a second timed region on another frame size (`scale_1080p`) and what the process group is
+    leg = bench.scale_leg(step, 3, 1, world, dist, torch.device("cpu"), lambda: None, 1080, 1920, spin_s=0.0)
+    info = bench.rccl_info(dist, world)
+    q.put((rank, pair, el, calls[0], marks, int(idx.sum()), None if gathered is None else [[int(t.sum()) for t in r] for r in gathered], g_bytes, leg, info))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,10 +62,13 @@ def test_bench_protocol_gloo_world2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, pair0, el0, calls0, marks0, s0, g0, b0), (r1, pair1, el1, calls1, marks1, s1, g1, b1) = got
+    (r0, pair0, el0, calls0, marks0, s0, g0, b0, leg0, info0), (r1, pair1, el1, calls1, marks1, s1, g1, b1, leg1, info1) = got
     assert (r0, pair0, r1, pair1) == (0, 0, 1, 1)               # pair p on rank p
     assert el0 == el1 and el0 >= 5 * 0.004                      # max over ranks (rank 1 sleeps), the same number on every rank
-    assert calls0 == calls1 == 7 and marks0 == marks1 == [2]    # W warm-up steps, the hook, then exactly K timed steps
+    assert calls0 == calls1 == 7 + 4 and marks0 == marks1 == [2]    # W warm-up steps, the hook, then exactly K timed steps (+ 1 + 3 of the extra leg)
+    assert leg0 == leg1 and leg0["pairs_per_step"] == 2 and leg0["steps"] == 3 and leg0["ms_per_step"] >= 4.0    # the slow rank's time again
+    assert abs(leg0["value"] - 2 * 1080 * 1920 / (leg0["ms_per_step"] * 1e3)) / leg0["value"] < 1e-3              # whole-job Mpixels/s
+    assert info0 == info1 == {"world": 2, "backend": "gloo"}
     assert s0 != s1                                             # each rank processed its own pair
     assert g1 is None and g0 == [[s0, g0[0][1]], [s1, g0[1][1]]]  # rank 0 holds every rank's results, in rank order
     assert b0 == b1 > 0
