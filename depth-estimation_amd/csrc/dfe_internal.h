@@ -26,9 +26,8 @@ enum DfeOpt {
     DFE_OPT_SWEEP_OVH,        // cost model of the persistent column sweep: per-piece overhead in rows
     DFE_OPT_SWEEP_BLOCKS,     // ... number of blocks
     DFE_OPT_DEBUG_ARENA,      // print where the scratch arena lands
-    DFE_OPT_FLOW_FINALIZE,
-    DFE_OPT_FM_FLAT,
-    DFE_OPT_FM_STAGGER,       // flat-tile feature matcher: start delay per XCD index in tenths of a microsecond (0: none)          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)    // 1: per-pixel results finished by flow_finalize_kernel also where the sweep could finish them itself
+    DFE_OPT_FM_FLAT,          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)
+    DFE_OPT_FM_STAGGER,       // flat-tile feature matcher: start delay per XCD index in tenths of a microsecond (0: none)
     DFE_NOPT
 };
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };
@@ -247,6 +246,119 @@ struct CvFuseArgs {
 #define DFE_REC (32 + 8 * DFE_REC_NLEAD)   // floats per tile-row record (1 or 3 whole 128-B lines)
 #define DFE_REC_CENTRE 16  // (entries 0..15: (minimum, index) of the 8 pixels; 16..23: their centre costs; 24..31: 0)
 #define DFE_REC_LEAD 32    // (entries 32..: [pixel][DFE_REC_NLEAD] the pixels' first cells)
+// ---- the finalize of a pixel from its tile row's record: flow_finalize_kernel's record path (postops.hip), kept here next to the record layout it reads
+// (round 4 also ran it at the end of the fused sweep: no gain, ssd_cost_volume.hip) ----
+// replaces: radial/radial_opticalflow_groundtruth.lua:87-105 (min(3), tie-break, decode, extractOutput)
+struct TailOut {
+    long long *idx;      // [P] or null
+    float *best;         // [P] or null
+    float *fy, *fx;      // decoded displacement, written at (y+pad_t)*pitch + x+pad_l  (pad-back :108), or null
+    float *scores;       // extractOutput score, same addressing as fy/fx when padded != 0, else [P]
+    long long *imaxs;    // [P] or null (goes with scores)
+    int Wo;              // pixels per volume row
+    int pitch, pad_t, pad_l;   // full-frame addressing for fy/fx/(scores if padded)
+    int padded;          // scores addressed full-frame (1) or [P] (0)
+    long long p_off;     // pixel offset of this band inside the [P] outputs
+    int row_off;         // output-row offset of this band
+    // frame mode (flow_finalize_kernel, one band only): the threads cover the whole H x W frame -- interior pixels run the
+    // pipeline's tail and the flow -> depth formula, border pixels are zeroed -- so the pair step needs no third launch
+    int frame_H, frame_W;     // 0 = off
+    float *depth, *conf;      // [H][W] or null
+    float mw, mh, infty;      // focus of expansion, depth clamp (test_opticalflow.lua:143-216)
+};
+
+// flow -> depth of one pixel (i, j) with displacement (dy, dx): the quirk-preserving cartesian formula of
+// test_opticalflow.lua:143-216 (same arithmetic as flow_to_depth_cartesian_kernel)
+__device__ __forceinline__ void pair_depth_px(int i, int j, float dy, float dx, float mw, float mh, float infty, float *r_out, float *c_out) {
+    const float py = (float)i - mh, px = (float)j - mw;
+    const float pn = (float)sqrt((double)(px * px + py * py));
+    const float dn = (float)sqrt((double)(dx * dx + dy * dy));
+    float r = 0.f, c = 0.f;
+    if (dn >= 0.2f) {
+        const float q = pn / dn;
+        r = q < infty ? q : infty;
+        if (px * dx + dy * dy > 0.125f) c = 1.0f;   // test_opticalflow.lua:181 (sic)
+    } else {
+        c = 1.0f;
+        r = infty;
+    }
+    *r_out = r;
+    *c_out = c;
+}
+
+
+// A6: the record's (minimum, first index), centre override.  A9: decode.  A7: extractOutput over the pixel's first DFE_REC_NLEAD cells
+// (in the record), walking on through the volume itself only if fewer than M of them pass the threshold (extract_output.cpp:99-112 stops
+// at M as well).  p: pixel index inside the band (row-major over Wo); (fi, fj): its frame position (frame mode).
+template <int M>
+__device__ __forceinline__ void dfe_finalize_rec_pixel(const float *__restrict__ rec, int rec_rows, const float *__restrict__ vol, long long p, int N,
+                                                       int hWin, int wWin, int middle, double threshold, const TailOut &o, int fi, int fj) {
+    const long long pg = o.p_off + p;
+    const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
+    const int ncols = (o.Wo + 7) >> 3;
+    const int g = min(x >> 3, ncols - 1), xb = g == ncols - 1 ? o.Wo - 8 : g << 3;   // (the last tile column is shifted inwards)
+    const float *rp = rec + ((long long)g * rec_rows + y) * DFE_REC;
+    // (non-temporal: what is read here is REWRITTEN by the next frame's cost-volume launch -- lines left in the memory-side cache by
+    //  these reads made that launch's stores slower: 1080p 2.4 against 1.8 ms)
+    float2 b;
+    b.x = __builtin_nontemporal_load(rp + 2 * (x - xb));
+    b.y = __builtin_nontemporal_load(rp + 2 * (x - xb) + 1);
+    const float cen = __builtin_nontemporal_load(rp + DFE_REC_CENTRE + x - xb);
+    long long id = (long long)__float_as_int(b.y) + 1;
+    if (middle > 0 && b.x == cen) id = middle;
+    if (o.idx) o.idx[pg] = id;
+    if (o.best) o.best[pg] = b.x;
+    const long long fo = (long long)(y + o.pad_t) * o.pitch + x + o.pad_l;
+    const long long fl = (id - 1) / wWin;
+    const float dyf = (float)(fl - (hWin - 1) / 2), dxf = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
+    if (o.fy) o.fy[fo] = dyf;
+    if (o.fx) o.fx[fo] = dxf;
+    if (o.frame_H && o.depth) pair_depth_px(fi, fj, dyf, dxf, o.mw, o.mh, o.infty, &o.depth[fo], &o.conf[fo]);
+    if (o.scores) {
+        static_assert(DFE_REC_NLEAD == 8, "the record holds a pixel's first 8 cells");
+        float hv[M], hi[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) { hv[j] = 0.f; hi[j] = 0.f; }
+        int n = 0;
+        float qq[DFE_REC_NLEAD];
+        const float *lv = rp + DFE_REC_LEAD + (x - xb) * DFE_REC_NLEAD;
+#pragma unroll
+        for (int kk = 0; kk < DFE_REC_NLEAD; ++kk) qq[kk] = __builtin_nontemporal_load(lv + kk);
+#pragma unroll
+        for (int kk = 0; kk < DFE_REC_NLEAD; ++kk) {
+            if (kk < N && n < M && (double)qq[kk] > threshold) {
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    if (j == n) { hv[j] = qq[kk]; hi[j] = (float)(kk + 1); }
+                ++n;
+            }
+        }
+        if (n < M && N > DFE_REC_NLEAD) {   // rare: keep scanning the volume itself
+            const float *v = vol + p * N;
+            for (int kk = DFE_REC_NLEAD; kk < N && n < M; ++kk) {
+                const float t = v[kk];
+                if ((double)t > threshold) {
+#pragma unroll
+                    for (int j = 0; j < M; ++j)
+                        if (j == n) { hv[j] = t; hi[j] = (float)(kk + 1); }
+                    ++n;
+                }
+            }
+        }
+        if (hv[0] > 0) {
+            if (M == 4) dfe_sort4(hv, hi); else dfe_sort8(hv, hi);
+            if (o.imaxs) o.imaxs[pg] = (long long)hi[0];
+#pragma unroll
+            for (int j = 1; j < M; ++j) hv[j] += hv[j - 1];
+            double acc = 0;
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc += hv[j];
+            o.scores[o.padded ? fo : pg] = (float)acc;
+        } else if (o.padded) {
+            o.scores[fo] = 0.f;   // pair mode: the caller's buffer is not pre-zeroed (pixels without a hit read 0)
+        }
+    }
+}
 // frame mode of dfe_flow_finalize (one band only): finalize also zeroes the frame border and makes depth / confidence
 struct DfePairDepth { int H, W; float cx, cy; float *depth, *conf; };
 // (rec != nullptr: part / centre / lead are ignored -- minimum / index / centre come from the tile-row records [col group][rec_rows][DFE_REC],
@@ -255,6 +367,9 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
                       const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
                       float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
                       const struct DfePairDepth *pd = nullptr, const float *rec = nullptr, int rec_rows = 0);
+struct TailOut;
+void dfe_make_tailout(TailOut *o, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int Wo, int pitch, int pad_t, int pad_l,
+                      int scores_padded, int row_off, const struct DfePairDepth *pd);
 int dfe_pair_border_depth(dfe_ctx *ctx, float *flow, float *scores, int H, int W, int pad_t, int pad_l, int Ho, int Wo, float cx,
                           float cy, float *depth, float *conf);
 int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,

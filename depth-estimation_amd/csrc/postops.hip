@@ -170,42 +170,8 @@ __global__ void x2yx_multi_compat_kernel(CompatGeom g, const long long *__restri
 
 // ---- fused single-scale tail: A6 (min + centre tie-break) + A7 + A9 in one pass over the volume ----
 // replaces: radial/radial_opticalflow_groundtruth.lua:87-105 (min(3), tie-break, decode, extractOutput)
-struct TailOut {
-    long long *idx;      // [P] or null
-    float *best;         // [P] or null
-    float *fy, *fx;      // decoded displacement, written at (y+pad_t)*pitch + x+pad_l  (pad-back :108), or null
-    float *scores;       // extractOutput score, same addressing as fy/fx when padded != 0, else [P]
-    long long *imaxs;    // [P] or null (goes with scores)
-    int Wo;              // pixels per volume row
-    int pitch, pad_t, pad_l;   // full-frame addressing for fy/fx/(scores if padded)
-    int padded;          // scores addressed full-frame (1) or [P] (0)
-    long long p_off;     // pixel offset of this band inside the [P] outputs
-    int row_off;         // output-row offset of this band
-    // frame mode (flow_finalize_kernel, one band only): the threads cover the whole H x W frame -- interior pixels run the
-    // pipeline's tail and the flow -> depth formula, border pixels are zeroed -- so the pair step needs no third launch
-    int frame_H, frame_W;     // 0 = off
-    float *depth, *conf;      // [H][W] or null
-    float mw, mh, infty;      // focus of expansion, depth clamp (test_opticalflow.lua:143-216)
-};
-
-// flow -> depth of one pixel (i, j) with displacement (dy, dx): the quirk-preserving cartesian formula of
-// test_opticalflow.lua:143-216 (same arithmetic as flow_to_depth_cartesian_kernel)
-__device__ __forceinline__ void pair_depth_px(int i, int j, float dy, float dx, float mw, float mh, float infty, float *r_out, float *c_out) {
-    const float py = (float)i - mh, px = (float)j - mw;
-    const float pn = (float)sqrt((double)(px * px + py * py));
-    const float dn = (float)sqrt((double)(dx * dx + dy * dy));
-    float r = 0.f, c = 0.f;
-    if (dn >= 0.2f) {
-        const float q = pn / dn;
-        r = q < infty ? q : infty;
-        if (px * dx + dy * dy > 0.125f) c = 1.0f;   // test_opticalflow.lua:181 (sic)
-    } else {
-        c = 1.0f;
-        r = infty;
-    }
-    *r_out = r;
-    *c_out = c;
-}
+// (TailOut, pair_depth_px and the record path of the finalize -- dfe_finalize_rec_pixel -- live in dfe_internal.h: the fused sweep
+//  finishes its own pixels with the same code)
 
 // Finishes what the fused cost-volume epilogue started; one thread per pixel, everything it normally reads is compact
 // and coalesced (8*nchunks + 4 + 64 bytes per pixel):
@@ -238,6 +204,10 @@ __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__rest
                 continue;
             }
             p = (long long)iy * o.Wo + ix;
+        }
+        if (rec) {
+            dfe_finalize_rec_pixel<M>(rec, rec_rows, vol, p, N, hWin, wWin, middle, threshold, o, fi, fj);
+            continue;
         }
         const long long pg = o.p_off + p;
         const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
@@ -498,12 +468,9 @@ int grid_for(long long n, int block) {
 
 }  // namespace
 
-int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
-                      const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
-                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
-                      const DfePairDepth *pd, const float *rec, int rec_rows) {
-    if (rec) nchunks = 1;
-    TailOut o;
+void dfe_make_tailout(TailOut *po, int64_t *idx, float *best, float *fy, float *fx, float *scores, int64_t *imaxs, int Wo, int pitch, int pad_t, int pad_l,
+                      int scores_padded, int row_off, const DfePairDepth *pd) {
+    TailOut &o = *po;
     o.frame_H = 0; o.frame_W = 0; o.depth = nullptr; o.conf = nullptr; o.mw = o.mh = o.infty = 0.f;
     if (pd) {   // frame mode: this call owns the whole frame (one band), fy / fx / scores are full-frame planes
         o.frame_H = pd->H; o.frame_W = pd->W; o.depth = pd->depth; o.conf = pd->conf;
@@ -512,6 +479,15 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
     o.idx = (long long *)idx; o.best = best; o.fy = fy; o.fx = fx; o.scores = scores; o.imaxs = (long long *)imaxs;
     o.Wo = Wo; o.pitch = pitch; o.pad_t = pad_t; o.pad_l = pad_l; o.padded = scores_padded;
     o.p_off = (long long)row_off * Wo; o.row_off = row_off;
+}
+
+int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, const float *lead, int nchunks, long long Ptot,
+                      const float *vol, double threshold, int rows, int Wo, int hWin, int wWin, int row_off, int64_t *idx, float *best,
+                      float *fy, float *fx, float *scores, int64_t *imaxs, int pitch, int pad_t, int pad_l, int scores_padded,
+                      const DfePairDepth *pd, const float *rec, int rec_rows) {
+    if (rec) nchunks = 1;
+    TailOut o;
+    dfe_make_tailout(&o, idx, best, fy, fx, scores, imaxs, Wo, pitch, pad_t, pad_l, scores_padded, row_off, pd);
     const long long Pb = (long long)rows * Wo;
     const int N = hWin * wWin;
     const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);

@@ -1578,6 +1578,12 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // next piece: every wave is past its last reads of the rings and the images (LDS-only barrier, the stores drain on)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
+    // (Round 4 tried the finalize INSIDE this kernel: at the end of the launch each block finished the pixels of its own tile rows --
+    //  centre override, decode, extractOutput, depth, its share of the frame border -- with the code flow_finalize_kernel runs
+    //  (dfe_finalize_rec_pixel), bit-identical, no second launch.  Same-call A/B, profiles/r04_ac_ab_finalize_in_sweep.txt: step
+    //  0.2486 / 0.2508 / 0.2504 ms against 0.2496 / 0.2483 / 0.2509 ms with the launch -- the kernel grew by the 5.5 us that the phase takes
+    //  behind the drain of the block's stores (two dependent passes over ~1100 pixels a block), which is what the launch and its boundary
+    //  cost: a step is kernel + ~6 us of launch boundary whether that holds one kernel or two.  Taken out again.)
 }
 
 // LDS bytes of a static-tile block of `ty` output rows (0 = does not apply) and the kernel arguments that go with it

@@ -382,7 +382,7 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode
             pytest.skip("tile codes of the row-image kernel")
         mode, tile = 0, mode - 100
     H, W = 90, 110
-    want = "ssd_cv_rowimg_kernel+fused_tail" if (mode == 0 and hWin == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"
+    want = "ssd_cv_rowimg_kernel+fused_tail" if (mode == 0 and hWin == 33 and C == 3) else "ssd_cv_tiled_kernel+fused_tail"   # (+finalize: see the assert)
     f0, f1, _, _ = rp.synth_pair(H, W, C=C, seed=hWin + C, max_flow=min(hWin, wWin) // 2 - 1, noise_sigma=1.0)
     ref = rp.dense_flow_oracle(f0, f1, hWin, wWin, 7, 7, thr=thr)
     Ho, Wo = ref["idx"].shape
@@ -403,7 +403,7 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode
             ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, 7, 7, hWin, wWin, thr,
                                                 idx.data_ptr(), best.data_ptr(), fy.data_ptr(), fx.data_ptr(), scores.data_ptr(), imaxs.data_ptr()))
             if not limit:   # (a short last band may legitimately fall back to the reference-order kernel + tail pass)
-                assert ctx.last_kernel() == want
+                assert ctx.last_kernel().startswith(want)
         finally:
             ctx.set_cost_volume_kernel(0)
             ctx.set_cost_volume_tile(0)
@@ -565,7 +565,7 @@ def test_flow_depth_pair_matches_oracle(dfe, cuda, H, W, win, C, thr):
     ctx.check(dfe.lib().dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), C, H, W, k, win, win, cx, cy, thr,
                                                flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), conf.data_ptr()))
     name = ctx.last_kernel()
-    assert name == ("ssd_cv_rowimg_kernel+fused_tail" if win == 33 else "ssd_cv_tiled_kernel+fused_tail"), name
+    assert name.startswith("ssd_cv_rowimg_kernel+fused_tail" if win == 33 else "ssd_cv_tiled_kernel+fused_tail"), name
     eflow = ref["flowp"][:2]
     assert np.array_equal(flow.cpu().numpy(), eflow)
     assert np.array_equal(scores.cpu().numpy(), ref["flowp"][3])
@@ -657,7 +657,7 @@ def test_full_vga_cost_volume_properties(dfe, cuda):
     ffy, ffx = torch.empty_like(fbest), torch.empty_like(fbest)
     ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, 0.21,
                                         fidx.data_ptr(), fbest.data_ptr(), ffy.data_ptr(), ffx.data_ptr(), None, None))
-    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel+fused_tail"
+    assert ctx.last_kernel().startswith("ssd_cv_rowimg_kernel+fused_tail")
     assert torch.equal(fidx, idx)
     assert torch.equal(fbest, tiled.reshape(442 * 602, -1).gather(1, (idx.reshape(-1, 1) - 1)).reshape(442, 602))
     del tiled
@@ -927,7 +927,7 @@ def test_benched_single_scale_sizes_properties(dfe, cuda, H, W):
     ffy, ffx = torch.empty_like(best), torch.empty_like(best)
     ctx.check(lib.dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, 0.21, fidx.data_ptr(), fbest.data_ptr(),
                                    ffy.data_ptr(), ffx.data_ptr(), None, None))
-    assert ctx.last_kernel() == "ssd_cv_rowimg_kernel+fused_tail"
+    assert ctx.last_kernel().startswith("ssd_cv_rowimg_kernel+fused_tail")
     assert torch.equal(fidx, idx) and torch.equal(fbest, best)
     y, x = dfe.x2yx(dict(maxh=win, maxw=win), idx)
     assert torch.equal((y - 17).float(), ffy) and torch.equal((x - 17).float(), ffx)
@@ -1247,3 +1247,4 @@ def test_time_matching_lua_exact_shape(dfe, cuda):
     ctx.check(dfe.lib().dfe_min_dim0_f32(ctx.handle, out.data_ptr(), 256, M, mn.data_ptr(), mi.data_ptr()))
     view = out.cpu().numpy().reshape(256, M)
     assert np.array_equal(mn.cpu().numpy(), view.min(axis=0)) and np.array_equal(mi.cpu().numpy(), view.argmin(axis=0) + 1)
+
