@@ -615,7 +615,7 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
     ms, n = C.c_double(), C.c_int()
     ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(ms), C.byref(n)))
     ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
-    kernel = ctx.last_kernel() if tm else "feat_matching_flat_kernel"
+    kernel = ctx.last_kernel()
     stages = None
     if tm:
         for _ in range(10):

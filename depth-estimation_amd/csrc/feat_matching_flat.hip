@@ -75,6 +75,9 @@ struct FfArgs {
     int G;            // groups per image row = ceil(W1 / PX)
     int NG;           // H1 * G
     int ntiles;       // ceil(NG / 64)
+    long long *idx;   // ARGMIN: [H1][W1] 1-based window index of the first minimum, or NULL
+    float *xflow, *yflow;   // ARGMIN: [H1][W1] decoded displacement (index % wWin - lWin, index / wWin - tWin), or NULL
+    int lWin, tWin;
     int stagger;      // start delay per XCD index, in ticks of the 100-MHz constant clock (s_memrealtime)
     unsigned long long *dbg;   // FF_TIMELINE builds: stamps of block 0's second tile
 };
@@ -112,7 +115,9 @@ __device__ __forceinline__ void ff_glds4(unsigned voff, const void *sbase, const
 }
 
 // maxh <= 16: waves 0 .. maxh-1 each sweep one window row.  EXTRA (maxh == 17): 16 waves, row 16 as the extra task.
-template <int MW, bool EXTRA>
+// ARGMIN: no volume -- the arithmetic's result goes through the first-minimum decode of version2/test.lua:45-51 (FfArgs::idx / xflow /
+// yflow) instead of the copy-out: the volume of a 17 x 17 window on VGA features is 316 MB that the one-call model never reads back.
+template <int MW, bool EXTRA, bool ARGMIN = false>
 __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 #pragma clang fp contract(off)
     constexpr int PX = FF_PX;
@@ -342,6 +347,64 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         // of 8 keeps the 64 lanes' 16-B writes on different banks.
         const long long tile_px0 = (long long)y_first * p.W1 + xA0;       // first pixel of the tile (row-major pixel index)
         const int WNP = ff_wnp(WN);
+        if constexpr (ARGMIN) {
+            // Every (lane, pixel, window row) leaves its row's minimum and the first cell attaining it (strict '<' in cell order) in LDS --
+            // cand[slot 4 l + q][row] -- the extra task's lanes one candidate per 4-cell group of row 16 (cand[..][16 + c]); then one
+            // thread per pixel slot walks its candidates in window order, again with strict '<': the first minimum of the whole window,
+            // exactly what the arg-min over the stored volume finds (NaN never wins, as in torch.min).
+            constexpr int NC = EXTRA ? 20 : 16;                           // candidates per pixel slot
+            lds_f *cv = img;                                              // [256][NC] values
+            lds_i *ci = (lds_i *)(img + 256 * NC);                        // [256][NC] window indices (0-based)
+            {
+                const int lc = lane_fresh();
+#pragma unroll
+                for (int q = 0; q < PX; ++q) {
+                    float best = __int_as_float(0x7f800000);
+                    int bi = 0x7fffffff;
+#pragma unroll
+                    for (int d = 0; d < MW; ++d)
+                        if (acc[q][d] < best) { best = acc[q][d]; bi = dy * MW + d; }
+                    cv[(lc * PX + q) * NC + dy] = best;
+                    ci[(lc * PX + q) * NC + dy] = bi;
+                }
+                if (!EXTRA && NW < 16) {                                  // (fewer window rows than candidates: the rest never win)
+                    for (int r = NW + wave; r < 16; r += NW)
+#pragma unroll
+                        for (int q = 0; q < PX; ++q) { cv[(lc * PX + q) * NC + r] = __int_as_float(0x7f800000); ci[(lc * PX + q) * NC + r] = 0x7fffffff; }
+                }
+            }
+            if constexpr (EXTRA) {
+                const int pp = lane >> 2, c = lane & 3;                   // slot 16 wave + pp, cells 4 c .. 4 c + 3 (+ cell 16 on c == 3) of row 16
+                float best = __int_as_float(0x7f800000);
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if ((j < 4 || c == 3) && accx[j] < best) { best = accx[j]; bi = 16 * MW + 4 * c + j; }
+                cv[(16 * wave + pp) * NC + 16 + c] = best;
+                ci[(16 * wave + pp) * NC + 16 + c] = bi;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            for (int sl = threadIdx.x; sl < 256; sl += 64 * NW) {
+                const int ll = sl >> 2, q = sl & 3;
+                const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
+                if (g0 + ll >= p.NG || xg + q >= p.W1) continue;
+                float best = __int_as_float(0x7f800000);
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int r = 0; r < NC; ++r) {
+                    const float v = cv[sl * NC + r];
+                    const int vi = ci[sl * NC + r];
+                    if (v < best) { best = v; bi = vi; }
+                }
+                if (bi == 0x7fffffff) bi = 0;
+                const long long px = tile_px0 + ll * PX - (ll >= nA ? padpx : 0) + q;
+                const int fy = bi / MW;
+                if (p.idx) p.idx[px] = (long long)bi + 1;
+                if (p.yflow) p.yflow[px] = (float)(fy - p.tWin);
+                if (p.xflow) p.xflow[px] = (float)(bi - fy * MW - p.lWin);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next tile's tables / planes overwrite the candidates
+        } else
         static_for_q<0, ((FF_ABLATE & 8) ? 0 : PX)>([&](auto qphase) {
             constexpr int q = decltype(qphase)::value;
             {
@@ -415,7 +478,9 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 }  // namespace
 
 // *handled stays false when the shape is not this kernel's (the caller goes on to the round-3 kernels)
-int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled) {
+static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, long long *idx, float *xflow,
+                     float *yflow, bool *handled) {
+    const bool argmin = out == nullptr;
     *handled = false;
     if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || ctx->opt[DFE_OPT_FM_FLAT] == 0) return DFE_OK;
     if (maxw != 16 && maxw != 17) return DFE_OK;
@@ -429,6 +494,8 @@ int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int
     a.in1 = in1; a.in2 = in2; a.out = out;
     a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;
     a.G = G; a.NG = (int)NGl; a.ntiles = dfe_cdiv(NGl, FF_GROUPS);
+    a.idx = idx; a.xflow = xflow; a.yflow = yflow;
+    a.lWin = (maxw + 1) / 2 - 1; a.tWin = (maxh + 1) / 2 - 1;            // version2/test.lua:18-19
     const bool extra = maxh == 17;
     const int NW = extra ? 16 : maxh;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
@@ -436,8 +503,10 @@ int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int
     const int WNP = ff_wnp(WN);
     const size_t lds = ((size_t)3 * (maxh + 1) * PITCH + 3 * 64 * FF_PX + 64 + (size_t)64 * WNP) * sizeof(float);
     if (lds > 160 * 1024) return DFE_OK;
-    void (*kern)(FfArgs) = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
-                                      : feat_matching_flat_kernel<16, false>;
+    void (*kern)(FfArgs) = argmin ? (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, true> : feat_matching_flat_kernel<17, false, true>)
+                                                : feat_matching_flat_kernel<16, false, true>)
+                                  : (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
+                                                : feat_matching_flat_kernel<16, false>);
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
     // (2 us per XCD step by default, where there are several rounds of tiles to stagger; "fm_stagger": tenths of a microsecond)
@@ -463,7 +532,19 @@ int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int
         for (int i = 1; i < 10; ++i) fprintf(stderr, "[ff timeline] %-20s +%6lld  (total %lld)\n", nm[i], (long long)(hdbg[i] - hdbg[i - 1]), (long long)(hdbg[i] - hdbg[0]));
     }
 #endif
-    ctx->last_kernel = "feat_matching_flat_kernel";
+    ctx->last_kernel = argmin ? "feat_matching_flat_kernel+argmin" : "feat_matching_flat_kernel";
     *handled = true;
     return DFE_OK;
+}
+
+int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled) {
+    *handled = false;
+    if (!out) return DFE_OK;
+    return ff_launch(ctx, in1, in2, K, H1, W1, maxh, maxw, out, nullptr, nullptr, nullptr, handled);
+}
+
+// nn.SpatialMatching(maxh, maxw) + `min` over the window + the decode of version2/test.lua:45-51, without the volume
+int dfe_feat_matching_flat_argmin(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, long long *idx, float *xflow,
+                                  float *yflow, bool *handled) {
+    return ff_launch(ctx, in1, in2, K, H1, W1, maxh, maxw, nullptr, idx, xflow, yflow, handled);
 }

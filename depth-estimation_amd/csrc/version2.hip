@@ -116,6 +116,14 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
         }
         DFE_REQUIRE(ctx, ha == H1 && wa == W1 && hb == H1 + hWin - 1 && wb == W1 + wWin - 1, DFE_E_SHAPE, "dfe_version2_flow_pair_f32: internal shape mismatch");
     }
+    if (!volume && (xflow || yflow || idx)) {
+        // nobody asked for the volume: matcher and decode in one kernel where the flat-tile matcher takes the shape (bit-identical to the
+        // volume path: the same sums, the same first minimum)
+        DfeStageScope st(ctx, DFE_STAGE_MATCH);
+        bool done = false;
+        rc = dfe_feat_matching_flat_argmin(ctx, ia, ib, K, H1, W1, hWin, wWin, (long long *)idx, xflow, yflow, &done);
+        if (rc || done) return rc;
+    }
     {
         DfeStageScope st(ctx, DFE_STAGE_MATCH);
         rc = dfe_spatial_matching_dispatch(ctx, ia, ib, K, H1, W1, hWin, wWin, vol);

@@ -1075,6 +1075,7 @@ def test_entry_points_run_on_their_ctx_device_and_leave_the_callers_alone(dfe, c
 # ------------------------------------------------------------------ version2/: the single-scale learned model
 @pytest.mark.parametrize("H,W,layers,win", [
     (60, 300, [(3, 17, 17, 8)], 17),                 # the script's geometry with fewer planes: 17 x 17 kernel, 17 x 17 window (flat-tile matcher, extra row)
+    (50, 330, [(3, 9, 9, 5)], 17),                  # ragged: W1 = 306 (not a multiple of 4), H1 = 26
     (48, 64, [(3, 5, 5, 4), (4, 3, 3, 6)], 9),      # two layers, small window (chunk matcher)
 ])
 def test_version2_one_call_equals_staged_and_oracle(dfe, cuda, H, W, layers, win):
@@ -1100,6 +1101,11 @@ def test_version2_one_call_equals_staged_and_oracle(dfe, cuda, H, W, layers, win
     one = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=True)
     for k in ("volume", "index", "xflow", "yflow"):
         assert torch.equal(staged[k], one[k]), k
+    lean = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=False)   # nobody reads the volume: matcher + first-min decode in one kernel
+    if win in (16, 17) and W - (win - 1) - (datap["wKernel"] - 1) >= 253:
+        assert dfe.get_ctx(0).last_kernel() == "feat_matching_flat_kernel+argmin"
+    for k in ("index", "xflow", "yflow"):
+        assert torch.equal(lean[k], one[k]), k
     xf, yf = v2.decodeFlow(staged["volume"], datap)                        # test.lua:45-51 on the module output
     assert torch.equal(xf.to(torch.float32), one["xflow"]) and torch.equal(yf.to(torch.float32), one["yflow"])
     ws = [m.weight.cpu().numpy() for m in f1c]
