@@ -31,18 +31,6 @@ namespace {
 
 constexpr int FF_PX = 4;                     // pixels per lane
 constexpr int FF_GROUPS = 64;                // groups (lanes) per tile
-#ifndef FF_ABLATE
-#define FF_ABLATE 0   // tuning (side builds only): 1 no staging requests, 2 no barrier in the plane loop, 4 no copy-out stores, 8 no copy-out at all,
-                      // 16 no arithmetic
-#endif
-#ifndef FF_TIMELINE
-#define FF_TIMELINE 0   // tuning (side builds only): s_memtime stamps of block 0's second tile, printed by the launcher (DFE_FF_TIMELINE=1)
-#endif
-#if FF_TIMELINE
-#define FF_STAMP(i) do { if (dbg_on && threadIdx.x == 0) p.dbg[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FF_STAMP(i) do { } while (0)
-#endif
 #ifndef FF_ST_FLAGS
 #define FF_ST_FLAGS " nt"   // cache policy of the copy-out stores
 #endif
@@ -78,8 +66,6 @@ struct FfArgs {
     long long *idx;   // ARGMIN: [H1][W1] 1-based window index of the first minimum, or NULL
     float *xflow, *yflow;   // ARGMIN: [H1][W1] decoded displacement (index % wWin - lWin, index / wWin - tWin), or NULL
     int lWin, tWin;
-    int stagger;      // start delay per XCD index, in ticks of the 100-MHz constant clock (s_memrealtime)
-    unsigned long long *dbg;   // FF_TIMELINE builds: stamps of block 0's second tile
 };
 
 template <int MW> struct FfGeom {
@@ -143,21 +129,9 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     const int nbx = gridDim.x, per_xcd = nbx >> 3;
     const int vb = (nbx & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
 
-    // STAGGER: the tiles all cost the same, so the CUs would reach their copy-outs together, round after round -- 64 MB at once, which the
-    // memory takes at ~6 TB/s while every CU waits in its stores (10 us of a 50-us tile), and nothing in between.  The blocks of XCD x
-    // start x * stagger later: the bursts of the XCDs (8 MB each) come one after the other at full speed, behind other XCDs' arithmetic.
-    // (The XCDs with the highest index have the tiles of the last, partial round to spare: their delay is free.)
-    if (p.stagger > 0 && !(nbx & 7)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)(blockIdx.x & 7) * (unsigned)p.stagger;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-
+    // (Tried: the blocks of XCD x starting x * 1 .. 8 us later, so that the XCDs' copy-out bursts come one after the other -- no gain,
+    //  profiles/r04_u: the bursts are not what the copy-out waits for.)
     for (int t = vb; t < p.ntiles; t += nbx) {
-#if FF_TIMELINE
-        const bool dbg_on = p.dbg && blockIdx.x == 0 && t == vb + nbx;
-#endif
-        FF_STAMP(0);
         // ---- tile geometry (wave-uniform scalars, then per-lane offsets) ----
         const int g0 = t * FF_GROUPS;
         const int y_first = g0 / p.G, xgA0 = g0 - y_first * p.G, xA0 = xgA0 * PX;
@@ -274,7 +248,6 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             }
         };
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the tables are in LDS
-        FF_STAMP(1);
         if constexpr (EXTRA) {
             const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), q = pp & 3, c = lane & 3;
             xoff_b = gtab[lg] + 16 * PITCH + q + 4 * c;
@@ -287,7 +260,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             const int bp = bs == 0 ? 2 : bs - 1;                          // (kk - 1) % 3: complete since the previous barrier
             if (FF_DEEP) read_head(bc);
             read_tail(bc);                                                // (kk < 2: nothing there yet, nothing is computed from it)
-            if (kk < p.K && !(FF_ABLATE & 1)) stage(kk, bs);
+            if (kk < p.K) stage(kk, bs);
             __builtin_amdgcn_sched_barrier(0);
             // the (pixel, cell) pairs in batches of FF_BATCH: all differences, then all squares, then all adds
             auto pairs = [&](auto first_part) {
@@ -307,7 +280,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     });
                 });
             };
-            if (kk >= 2 && !(FF_ABLATE & 16)) {
+            if (kk >= 2) {
                 pairs(std::true_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 pairs(std::false_type{});
@@ -331,13 +304,9 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 else if (plain && nld == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
                 else if (plain && nld == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            } else if (FF_ABLATE & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             bs = bs == 2 ? 0 : bs + 1;
-            if (kk == 1) FF_STAMP(2);
-            if (kk == 11) FF_STAMP(3);
         }
-        FF_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // ---- copy-out: one phase per pixel q of the groups -- ALL lanes deposit their pixel q's window row (an LDS instruction costs its
@@ -405,7 +374,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next tile's tables / planes overwrite the candidates
         } else
-        static_for_q<0, ((FF_ABLATE & 8) ? 0 : PX)>([&](auto qphase) {
+        static_for_q<0, PX>([&](auto qphase) {
             constexpr int q = decltype(qphase)::value;
             {
                 const int lc = lane_fresh();
@@ -437,9 +406,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     if (c == 3) w[4] = accx[4];
                 }
             }
-            if (q == 0) FF_STAMP(5);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q == 0) FF_STAMP(6);
             // the block's waves share the 64 windows: wave w takes lanes w, w + NW, ...
             for (int ll = wave; ll < 64; ll += NW) {
                 const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
@@ -457,7 +424,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 #pragma unroll
                 for (int j = 0; j < NJ4; ++j) v[j] = sb[min(lane + 64 * j, nb4 - 1)];
                 if (lane < 8) vh = sw[lane < 4 ? min(lane, WN - 1) : min(tail0 + lane - 4, WN - 1)];   // lanes 0..3: head floats, 4..7: tail floats
-                if (!(FF_ABLATE & 4)) {
+                {
 #pragma unroll
                     for (int j = 0; j < NJ4; ++j)
                         if (lane + 64 * j < nb4)
@@ -466,12 +433,9 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     if (lane >= 4 && lane < 8 && tail0 + lane - 4 < WN) gw[tail0 + lane - 4] = vh;
                 }
             }
-            if (q == 0) FF_STAMP(7);
             // every wave is past its reads of the image before the next phase (or the next tile's tables / first plane) overwrites it
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (q == 2) FF_STAMP(8);
         });
-        FF_STAMP(9);
     }
 }
 
@@ -509,29 +473,11 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
                                                 : feat_matching_flat_kernel<16, false>);
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
-    // (2 us per XCD step by default, where there are several rounds of tiles to stagger; "fm_stagger": tenths of a microsecond)
-    a.stagger = ctx->opt[DFE_OPT_FM_STAGGER] >= 0 ? ctx->opt[DFE_OPT_FM_STAGGER] * 10 : (a.ntiles >= 2 * nblk ? 200 : 0);
-#if FF_TIMELINE
-    unsigned long long *dbg = nullptr, hdbg[16] = {0};
-    (void)hipMalloc((void **)&dbg, sizeof(hdbg));
-    (void)hipMemset(dbg, 0, sizeof(hdbg));
-    a.dbg = dbg;
-#endif
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), lds, ctx->stream, a);
     }
     DFE_LAUNCH_CHECK(ctx);
-#if FF_TIMELINE
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipMemcpy(hdbg, dbg, sizeof(hdbg), hipMemcpyDeviceToHost);
-    (void)hipFree(dbg);
-    static int printed = 0;
-    if (printed++ < 2) {
-        const char *nm[] = {"tile start", "tables", "fill done (kk=1)", "kk=11", "plane loop end", "phase 0 deposited", "phase 0 barrier", "phase 0 stored", "phase 3 end", "tile end"};
-        for (int i = 1; i < 10; ++i) fprintf(stderr, "[ff timeline] %-20s +%6lld  (total %lld)\n", nm[i], (long long)(hdbg[i] - hdbg[i - 1]), (long long)(hdbg[i] - hdbg[0]));
-    }
-#endif
     ctx->last_kernel = argmin ? "feat_matching_flat_kernel+argmin" : "feat_matching_flat_kernel";
     *handled = true;
     return DFE_OK;

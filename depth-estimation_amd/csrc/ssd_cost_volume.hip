@@ -209,13 +209,8 @@ __host__ __device__ inline int sweep_cut(int b, int B, int ncols, int Ho, int ov
 
 extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 
-// Tuning-only ablation bits (tools/ablate.sh builds side libraries with -DDFE_ABLATE=n; the product build
-// leaves it 0): 1 = no global stores, 2 = no LDS reads inside the row loop, 4 = no SMEM inside the row loop.
 #ifndef DFE_RI_SMEM
 #define DFE_RI_SMEM true   // row-image kernel: frame-0 values through warmed scalar loads (true) or LDS + DPP (false)
-#endif
-#ifndef DFE_ABLATE
-#define DFE_ABLATE 0
 #endif
 #ifndef DFE_A32
 #define DFE_A32 1
@@ -229,21 +224,6 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 #define DFE_CV_KERNEL_REV "cv-r4.1"
 #ifndef DFE_SMEM_JIT
 #define DFE_SMEM_JIT 0   // tuning: frame-0 scalars of a row loaded at its start instead of one row ahead
-#endif
-#ifndef DFE_TIMELINE
-#define DFE_TIMELINE 0   // tuning only (side builds): s_memtime stamps of the row phases of two blocks, read back with dfe_debug_timeline
-#endif
-#if DFE_TIMELINE
-#ifndef DFE_TL_MASK
-#define DFE_TL_MASK 127
-#endif
-__device__ unsigned long long dfe_tl[2][16][256][8];
-#define DFE_TL(i)                                                                                              \
-    do {                                                                                                       \
-        if (((DFE_TL_MASK) >> (i)) & 1) if (tl_blk >= 0 && (threadIdx.x & 63) == 0) dfe_tl[tl_blk][threadIdx.x >> 6][min(r, 255)][i] = __builtin_readcyclecounter(); \
-    } while (0)
-#else
-#define DFE_TL(i) do { } while (0)
 #endif
 // -DDFE_MARKERS=1 (tools/isa_regions.py, no product build): assembler comments at the phase boundaries of the row loop, so that the ISA
 // between them can be counted by class (VALU / v_readlane / LDS / ...) per phase
@@ -316,7 +296,7 @@ __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int l
     // (row-image kernel, shifted last tile: the first nover columns are the neighbour's and are not stored from here.  That
     //  rare path takes its column count through an asm barrier so that its per-column masks cannot be hoisted out of the
     //  caller's row loop -- eight SGPR pairs held across the sweep, as first written, cost every tile ~30 v_readlane per row)
-    if (!(DFE_ABLATE & 128) && chunk == cmid && lane == lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
+    if (chunk == cmid && lane == lmid) {      // the lane that owns the centre cell: 8 pixels = 32 B
         const float *cb = fa.centre + pg0;
         if (nover == 0) {   // (wave-uniform)
             asm volatile("global_store_dwordx4 %0, %1, %2\n\tglobal_store_dwordx4 %0, %3, %2 offset:16" ::"v"(0u), "v"(lo), "s"(cb), "v"(hi) : "memory");
@@ -328,7 +308,7 @@ __device__ __forceinline__ void fuse_plain_stores(const float (&vrow)[TX], int l
                 if (x >= nv) asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(0u), "v"(vrow[x]), "s"(cb), "n"(x * 4) : "memory");
         }
     }
-    if (!(DFE_ABLATE & 64) && chunk == 0 && lane < DFE_LEAD) {
+    if (chunk == 0 && lane < DFE_LEAD) {
         // the pixel's first cells, for extractOutput, pixel-major [P][DFE_LEAD]: the 8 pixels of the tile row are 512
         // contiguous, line-aligned bytes, written back to back by this wave (8 x 64 B) so that they leave L2 as whole
         // lines.  (Cell-major planes -- 2 dwordx4 stores -- left 16 partial lines per row step, 690 k per VGA launch, and
@@ -360,7 +340,7 @@ __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool vali
     for (int x = 0; x < TX; ++x) key[x] = valid ? __float_as_int(vrow[x]) : 0x7f800000;
     const int wk = wave_min8<TX>(key, lane);
     int wl = 0;
-    if (!(DFE_ABLATE & 256)) {
+    {
 #define DFE_FIRST(x)                                                                                     \
     {                                                                                                    \
         const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(key[x] == __builtin_amdgcn_readlane(wk, x))); \
@@ -369,7 +349,7 @@ __device__ __forceinline__ void fuse_epilogue(const float (&vrow)[TX], bool vali
         DFE_FIRST(0) DFE_FIRST(1) DFE_FIRST(2) DFE_FIRST(3) DFE_FIRST(4) DFE_FIRST(5) DFE_FIRST(6) DFE_FIRST(7)
 #undef DFE_FIRST
     }
-    if (lane < TX && (!(DFE_ABLATE & 1024) || wk == 0x12345))
+    if (lane < TX)
         fa.part[(long long)chunk * fa.Ptot + pg0 + lane] = make_float2(__int_as_float(wk), __int_as_float(chunk * 64 + wl));
 }
 
@@ -475,11 +455,6 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
 #pragma unroll
                 for (int i = 0; i < U; ++i) ring[i][x] = 0.f;
             }
-            px_t abl_px[(NE + 1) / 2 + 1];
-            if (DFE_ABLATE & 2) {
-#pragma unroll
-                for (int s = 0; s < (NE + 1) / 2 + 1; ++s) abl_px[s] = lp[s];
-            }
 
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -495,7 +470,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                         px_t b[BS];
 #pragma unroll
                         for (int s = 0; s < BS; ++s)
-                            if (bb * BS + s < NE) b[s] = (DFE_ABLATE & 2) ? abl_px[s] : lr[bb * BS + s];
+                            if (bb * BS + s < NE) b[s] = lr[bb * BS + s];
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (C == 3) {
                             // a (free) use of .w keeps each read a 16-B ds_read_b128 instead of the slower b96
@@ -518,7 +493,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                         // last one is requested but never used)
                         const int rn = min(y0 + oy + r + 1, p.H - 1) - (y0 + oy);
                         cfptr an = (cfptr)(I0 + a_base + (long long)rn * p.W);
-                        if (!(DFE_ABLATE & 4)) {
+                        {
 #pragma unroll
                             for (int c = 0; c < C; ++c) uload<NE>(an + c * HW, av[c]);
                         }
@@ -528,7 +503,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
                     hsum<K, TX>(e, h);
                     const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
                     const int y = y0 + r - (K - 1);
-                    const bool store_row = emit && y >= y0n && (!(DFE_ABLATE & 1) || hprev[0] == -12345.678f);   // wave-uniform
+                    const bool store_row = emit && y >= y0n;   // wave-uniform
                     const char *orow = (const char *)(out + ((long long)y * p.Wo + xt) * D);
                     float vrow[TX];
                     if constexpr (K == 7) {
@@ -600,7 +575,7 @@ __device__ __forceinline__ void ssd_cv_tiled_body(const float *__restrict__ I0, 
 #pragma unroll
                         for (int x = 0; x < TX; ++x)
                             if (!FUSE || valid) store_uniform_base(orow + (long long)x * D * 4, dbytes, vrow[x]);
-                        if constexpr (FUSE && !(DFE_ABLATE & 512))
+                        if constexpr (FUSE)
                             fuse_epilogue<TX>(vrow, valid, lane, chunk, (long long)(fa.row_off + y) * p.Wo + xt, fa);
                     }
                 }
@@ -796,7 +771,6 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     }
 }
 template <int S> __device__ __forceinline__ float bcast16(float v) {   // lane S of my row of 16, folded into the consumer
-    if (DFE_ABLATE & 16384) return v;
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + S, 0xf, 0xf, true));
 }
 template <int C, int S> __device__ __forceinline__ float sqdiff_bc(const typename Px<C>::type &a, const typename Px<C>::type &b) {
@@ -824,7 +798,7 @@ __device__ __forceinline__ void rowimg_task_row(const typename Px<C>::type *lr, 
         px_t b[BS];
 #pragma unroll
         for (int s = 0; s < BS; ++s)
-            if (bb * BS + s < NEL) b[s] = lr[(DFE_ABLATE & 2) ? bb * BS : bb * BS + s];   // (2: one LDS read per batch)
+            if (bb * BS + s < NEL) b[s] = lr[bb * BS + s];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (C == 3) {
 #pragma unroll
@@ -914,7 +888,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // waves 8..14 copy the image out (wave 15 refills the rings) -- instead of every wave doing a half-pixel scan AND three
     // pieces of the copy-out before it can start on the next row: per wave the chain scan -> stores (each wave's own stores
     // issue one behind the other, 130+ cycles apiece, more when the memory pushes back) -> main task was the row's critical
-    // path, 2.7 of 5.1 kilocycles of a VGA row spent before the slowest waves began their main task (timeline, DFE_TIMELINE).
+    // path, 2.7 of 5.1 kilocycles of a VGA row spent before the slowest waves began their main task (s_memtime stamps of two blocks, round 2).
     // (3-channel frames only: with one channel the main task is half as long and the all-waves scan of the plain layout
     //  wins, VGA luminance 215 against 254 us)
     constexpr bool ROLES = FUSE && (SWEEP || DFE_ROLES_STATIC) && DFE_ROLES && TX == 8 && DC == 1089 && C == 3;
@@ -970,9 +944,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         by = t / (int)gridDim.x;
         bx = t - by * (int)gridDim.x;
     }
-#if DFE_TIMELINE
-    const int tl_blk = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : -1;
-#endif
   for (;;) {   // pieces of this block (static tiles: one)
     // Every per-lane quantity is derived afresh from the thread id in each piece: nothing per-lane is then live across the
     // piece loop's back edge, and the register allocation of a piece is that of a one-piece kernel (with the ids taken
@@ -1064,7 +1035,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             return lds + packed + r * g_pitch;
     };
     // quarter task (waves 0..3): cells 1024 + lane, columns TQ*wave .. TQ*wave + TQ-1
-    const bool has_q = wave >= QW0 && wave < QW0 + NQW && D > 1024 && !(DFE_ABLATE & 8192);    // wave-uniform
+    const bool has_q = wave >= QW0 && wave < QW0 + NQW && D > 1024;    // wave-uniform
     const int dq = 1024 + lane;
     const bool validq = DC >= 1088 ? true : dq < D;
     int lpq;
@@ -1079,7 +1050,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // (it neither scans nor copies; with the mini task on wave 4, behind that wave's main task and scan, it was the last one
     //  at the barrier: VGA fused 258 -> 250 us, plain 228 -> 222 us)
     constexpr int MW = (C == 3 && (ROLES || (SWEEP && !FUSE))) ? LW : QW0 + NQW;
-    const bool has_m = wave == MW && (D > 1088 || TOWN) && !(DFE_ABLATE & 8192);    // wave-uniform
+    const bool has_m = wave == MW && (D > 1088 || TOWN);    // wave-uniform
     const bool mtail = TOWN && lane >= 32;
     const int dm = mtail ? lane - 32 : 1088 + (lane >> 3), xm = mtail ? TX : lane & 7;
     const bool validm = mtail ? lane < 63 : (dm < D && xm < TX && (!TOWN || lane < 32));
@@ -1126,7 +1097,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // chain then sits on the critical path of 12 waves instead of being shared by 16; after the copy-out, split around
     // it, or with its reads issued with the copy-out's it measured +3..5 % (round 1).
     auto scan_row = [&](const float *stp, long long pgp) {   // stp: image of the row to scan (+ its a0), pgp: its first entry in the planes
-        if (DFE_ABLATE & 512) return;
         constexpr int CPL = 9;                                         // cells per lane: 128 lanes x 9 >= 1096
         int lsc = lane;
         asm volatile("" : "+v"(lsc));
@@ -1153,10 +1123,10 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
             for (int i = CPL - 2; i >= 0; --i) bi = cv[i] == best ? i : bi;
             best = lane_out ? 0x7f800000 : best;
-            const int vmin = (DFE_ABLATE & 16777216) ? best : wave_min1(best);
-            const int f = (DFE_ABLATE & 33554432) ? 0 : __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
-            const int bif = (DFE_ABLATE & 33554432) ? bi : __builtin_amdgcn_readlane(bi, f);
-            if (lsc == 0 && xx >= nover && !(DFE_ABLATE & 4194304) && (!(DFE_ABLATE & 8388608) || vmin == 0x12345677))
+            const int vmin = wave_min1(best);
+            const int f = __builtin_ctzll(__builtin_amdgcn_ballot_w64(best == vmin));
+            const int bif = __builtin_amdgcn_readlane(bi, f);
+            if (lsc == 0 && xx >= nover)
                 fa.part[(long long)hh * fa.Ptot + pgp + xx] = make_float2(__int_as_float(vmin), __int_as_float((hh * 64 + f) * CPL + bif));
         }
     };
@@ -1165,7 +1135,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     // unit if any of its lanes attains the minimum.  Plane 1 of fa.part gets +inf (finalize keeps the smaller of the two).
     float *recbuf = stage + 2 * g_stage_len;       // ROLES: [2][DFE_REC] the tile row's record, double-buffered like the images
     auto scan_row_whole = [&](const float *stp, int rpar) {
-        if (DFE_ABLATE & 512) return;
         constexpr int CPL = 9;
         static_assert(!ROLES || DC % CPL == 0, "whole lanes only");
         int lsc = lane;
@@ -1226,7 +1195,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
         // 1.78 .. 2.21 ms depending on where the process' arena had landed (without them: 1.78 .. 1.81 ms in every process).
         // The pixel's first DFE_REC_NLEAD cells follow in the same record (lane 0 holds them already).
         static_assert(!ROLES || DC == 1089, "centre cell 544");
-        if (!(DFE_ABLATE & 192)) {
+        {
             const float cen = stp[xx * D + 544];
             if (lsc == 0) {
                 float *rb = recbuf + rpar * DFE_REC;
@@ -1250,7 +1219,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     auto write_record = [&](int rpar, const float *rb) {
         int lw = lane;
         asm volatile("" : "+v"(lw));
-        if (lw < DFE_REC / 4 && !(DFE_ABLATE & 192)) {
+        if (lw < DFE_REC / 4) {
             const f4_t v = *reinterpret_cast<const f4_t *>(recbuf + rpar * DFE_REC + 4 * lw);
             asm volatile("global_store_dwordx4 %0, %1, %2" DFE_REC_ST_FLAGS ::"v"((unsigned)lw * 16u), "v"(v), "s"(rb) : "memory");
         }
@@ -1281,9 +1250,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
-            DFE_TL(0);
             auto do_main = [&]() {
-                if (!(DFE_ABLATE & 65536)) {   // (65536: barrier + copy-out only)
+                {
                     px_t a{};
                     if constexpr (!SM) a = t0[t0r + l16];
                     float v[TX];
@@ -1292,7 +1260,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(I0 + a_base + (long long)r * p.W + c * HW), av[c]);
                     }
                     rowimg_task_row<C, K, TX, m, SM>(row_ptr(lp, r), a, av, ring, v);
-                    DFE_TL(1);
                     if constexpr (SWEEP) ring_step(lp);
                     if constexpr (SM && !DFE_SMEM_JIT) {   // next row's scalars (requested behind the last squared difference instead --
                                                            // inside the task row, in front of the sums -- the 42 scalars are live across the
@@ -1393,13 +1360,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             //  while the SIMD's other waves are busy, instead of alone behind them -- measured +-1 %)
             DFE_MARK("main");
             do_main();
-            DFE_TL(2);
             DFE_MARK("quarter");
             do_quarter();
             DFE_MARK("mini");
             do_mini();
             DFE_MARK("barrier");
-            DFE_TL(3);
             if (SWEEP || store_row) {
                 // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the previous row's
                 // global stores to be acknowledged before every barrier and serialise stores with compute.
@@ -1407,10 +1372,9 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 // after the barrier of row r+1, which every wave reaches after its copy-out of row r.
                 // (The column sweep needs it in the warm-up rows too: it also frees the tile row the sweep has just left.)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                DFE_TL(4);
                 DFE_MARK("refill");
                 if constexpr (SWEEP) {
-                    if (wave == LW && !(DFE_ABLATE & 131072)) {
+                    if (wave == LW) {
                         // Stream the rings: the pixels requested one row step ago go into the slots of the rows the sweep
                         // left at r-1 (no wave reads them again; their first use is >= 2 barriers away), then the rows
                         // that will take the slots of row r are requested.  This wave issues no stores at all, so waiting
@@ -1424,7 +1388,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         //  to the next barrier)
                         constexpr int RA = DFE_REFILL_AHEAD, hs = m % RA;
                         static_assert(VUnroll<K>::value % RA == 0, "hold slot = row step mod RA must be a compile-time value");
-                        if (r >= RA && !(DFE_ABLATE & 262144)) {
+                        if (r >= RA) {
                             px_t px;
                             if constexpr (C == 1) px = hold[hs][0]; else px = make_float4(hold[hs][0], hold[hs][1], hold[hs][2], 0.f);
                             if (t1lane) lds[((r - RA) & (g_lrows - 1)) * g_pitch + lw] = px;
@@ -1451,7 +1415,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 } else if constexpr (FUSE && !DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
-                DFE_TL(5);
                 DFE_MARK("copy");
                 // Copy-out by the waves WITHOUT an extra task (DFE_CW0.., 10 or 11 of them): a CU's vector-memory path takes 64 B
                 // per clock, i.e. ~545 cycles for the 34 848 B of a row, and every wave that stores waits its turn in it.  With all
@@ -1464,7 +1427,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 //  only the four scan waves without a quarter task taking them 270 us.)
                 constexpr int CW0 = ROLES ? TX : FUSE ? 0 : DFE_CW0;          // first copier wave
                 constexpr int NCW = (HAS_XW ? LW : NW) - CW0;                // copier waves
-                if (store_row && wave >= CW0 && (!HAS_XW || wave != LW) && (!(DFE_ABLATE & 1) || ring[0][0] == -12345.678f)) {
+                if (store_row && wave >= CW0 && (!HAS_XW || wave != LW)) {
                     const int ov = nover * D;                                // floats of the run that are the neighbour's (shifted last tile)
                     int tj = tid - CW0 * 64;
                     asm volatile("" : "+v"(tj));   // keeps per-lane copy addresses from being hoisted (and spilled)
@@ -1546,7 +1509,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                                     asm volatile("global_store_dwordx4 %0, %1, %2" DFE_ST_FLAGS ::"v"((unsigned)(tj + (g0 + i) * STR) * 16u), "v"(val[i]), "s"(gb) : "memory");
                     }
                     }
-                    if (!(DFE_ABLATE & 32)) {     // the run's two partial lines: head by wave 5, tail by wave 6
+                    {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
                         if constexpr (F16) {
                             _Float16 *oh = reinterpret_cast<_Float16 *>(out);
@@ -1561,7 +1524,6 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                 if constexpr (FUSE && DFE_SCAN_AFTER_COPY) {
                     if (store_row) scan_row(st, pg_run);
                 }
-                DFE_TL(6);
             }
             DFE_MARK("rowend");
             if constexpr (ROLES) rec_prev += DFE_REC;
@@ -1996,10 +1958,6 @@ int cv_frames_dispatch(dfe_ctx *ctx, const float *I0, const float *I1, int C, in
 }
 
 extern "C" {
-#if DFE_TIMELINE
-int dfe_debug_timeline(void *dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(dfe_tl), sizeof(dfe_tl)); }
-#endif
-
 // Bumped whenever a change can alter what the cost-volume kernels read or write: profiles/traffic_*.json carries the revision
 // its PMC counters were taken with, and bench.py reports `traffic` only when the two agree.
 const char *dfe_kernel_revision(void) { return DFE_CV_KERNEL_REV; }
