@@ -17,7 +17,11 @@ tail -1 gpurun_out/${tag}_smoke.log
 timeout -k 10 600 python bench.py > gpurun_out/${tag}_bench_default.log 2>&1 || { tail -5 gpurun_out/${tag}_bench_default.log; exit 1; }
 tail -1 gpurun_out/${tag}_bench_default.log | cut -c1-600
 bash tools/bench_all.sh $tag || exit $?
-bash tools/kstats.sh $tag vga vga-f16 720p-radial vga-pyramid-learned 1080p-pyramid-learned 1080p-pyramid-f16 > gpurun_out/${tag}_kstats.log 2>&1 || { tail -5 gpurun_out/${tag}_kstats.log; exit 1; }
+bash tools/kstats.sh $tag vga vga-f16 720p-radial vga-pyramid vga-pyramid-learned 1080p-pyramid-learned 1080p-pyramid-f16 version2-vga time-matching > gpurun_out/${tag}_kstats.log 2>&1 || { tail -5 gpurun_out/${tag}_kstats.log; exit 1; }
 cat gpurun_out/${tag}_kstats.log
 timeout -k 10 300 python tools/time_version2.py > gpurun_out/${tag}_time_version2.log 2>&1 || { tail -5 gpurun_out/${tag}_time_version2.log; exit 1; }
 grep -v amdgpu.ids gpurun_out/${tag}_time_version2.log
+# the feature matcher (verdict r3 item 2): kernel stats + PMC passes at the three shapes, and the headline kernel's traffic file
+for s in v2 k32 k10; do bash tools/pmc_any.sh ${tag}_fm_$s feat_matching tools/prof_fm.py $s 6 > gpurun_out/${tag}_fm_$s.log 2>&1 || { tail -3 gpurun_out/${tag}_fm_$s.log; exit 1; }; grep -E "K=|avg" gpurun_out/${tag}_fm_$s.txt; done
+bash tools/refresh_traffic.sh ${tag} > gpurun_out/${tag}_refresh.log 2>&1 || { tail -3 gpurun_out/${tag}_refresh.log; exit 1; }
+tail -1 gpurun_out/${tag}_refresh.log | cut -c1-200
