@@ -66,6 +66,8 @@ struct FfArgs {
     long long *idx;   // ARGMIN: [H1][W1] 1-based window index of the first minimum, or NULL
     float *xflow, *yflow;   // ARGMIN: [H1][W1] decoded displacement (index % wWin - lWin, index / wWin - tWin), or NULL
     int lWin, tWin;
+    int S;            // blocks per tile (1, or 2: the window's rows dealt to two half blocks that share a CU)
+    int nd;           // window rows of a block = maxh / S
 };
 
 template <int MW> struct FfGeom {
@@ -108,9 +110,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 #pragma clang fp contract(off)
     constexpr int PX = FF_PX;
     constexpr int PITCH = FfGeom<MW>::PITCH, NLOAD = FfGeom<MW>::NLOAD, NB4 = FfGeom<MW>::NB4;
-    const int NW = EXTRA ? 16 : p.maxh;                    // waves of the block = blockDim.x / 64
-    const int nrows = p.maxh + 1;                          // in2 rows of a tile: y_first .. y_first + maxh
+    const int nd = EXTRA ? 16 : p.nd;                      // window rows of this block (a half tile: maxh / 2)
+    const int NW = nd;                                     // waves of the block = blockDim.x / 64
+    const int nrows = EXTRA ? p.maxh + 1 : nd + 1;         // in2 rows of a (half) tile (EXTRA: 18 -- left a run-time value: as a constant it cost 160 B more scratch)
     const int WN = p.maxh * MW;                            // floats per window
+    const int WL = (EXTRA ? 17 : nd) * MW;                 // ... of them this block's
     // LDS: [3][nrows][PITCH] tile | [3][256] in1 pieces | [64] lane offsets (extra task) | [64][WNP] image
     lds_f *tile = (lds_f *)ff_smem;
     lds_f *abuf = tile + 3 * nrows * PITCH;
@@ -126,12 +130,32 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     // all planes of whose in2 rows (2.4 MB) stay in that XCD's 4-MB L2 while its CUs, in step with each other, walk through the planes.
     // (First version: a contiguous range of tiles per block -- the tiles in flight were spread over the whole frame, 76 % of the
     //  L2 requests missed, 790 MB were fetched for 39 MB of in2 and every plane waited out a memory round trip: r04_g, r04_j.)
-    const int nbx = gridDim.x, per_xcd = nbx >> 3;
-    const int vb = (nbx & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int nbx = gridDim.x;
+    int vb = (int)blockIdx.x;
+    if (!ARGMIN && !EXTRA && p.S == 2 && !(nbx & 15)) {
+        // two blocks per CU: the dispatcher fills every CU once (blocks 0 .. nbx/2 - 1), then a second time (blocks b and b + nbx/2
+        // share a CU: tools/ubench/cuid.hip, profiles/r04_ah_cu_residency.txt).  The second set takes the upper half of every round's
+        // tiles -- of a last, partial round none, so that its half tiles run one to a CU, 1.5 x faster than two to a CU.
+        // (Tried: the second set starting 0.25 .. 1.5 tiles late, to keep the two blocks of a CU in different phases -- no gain, and
+        //  a loss from 8 sleeps on: profiles/r04_ag_fm_split_sweep.txt.  The gain of the split is the last round: 4 full rounds take
+        //  0.213 ms either way, r04_ag_fm_split_rounds.txt.)
+        const int hb = nbx >> 1, b = (int)blockIdx.x >= hb ? (int)blockIdx.x - hb : (int)blockIdx.x;
+        vb = ((int)blockIdx.x >= hb ? hb : 0) + (b & 7) * (hb >> 3) + (b >> 3);
+    } else if (!(nbx & 7)) {
+        vb = (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3);
+    }
 
     // (Tried: the blocks of XCD x starting x * 1 .. 8 us later, so that the XCDs' copy-out bursts come one after the other -- no gain,
     //  profiles/r04_u: the bursts are not what the copy-out waits for.)
-    for (int t = vb; t < p.ntiles; t += nbx) {
+    // Half tiles (S == 2): block vt handles window rows dy0 .. dy0 + nd - 1 of tile vt / 2, TWO blocks of nd waves share a CU, each
+    // with its own barriers.  1141 tiles on 256 CUs are 4.46 rounds that cost one block per CU 5; as half tiles the last round's
+    // blocks have their CU to themselves and finish in 0.65 of a round (K = 32, 625 x 465: 0.265 -> 0.232 ms, K = 10: 0.134 -> 0.101).
+    // The price: the in1 piece and one in2 row are staged by both halves.
+    const bool halves = !ARGMIN && !EXTRA && p.S == 2;    // (the arg-min form and the 17-row window: always whole tiles)
+    const int nvt = halves ? 2 * p.ntiles : p.ntiles;
+    for (int vt = vb; vt < nvt; vt += nbx) {
+        const int t = halves ? vt >> 1 : vt;
+        const int dy0 = halves ? (vt & 1) * nd : 0;
         // ---- tile geometry (wave-uniform scalars, then per-lane offsets) ----
         const int g0 = t * FF_GROUPS;
         const int y_first = g0 / p.G, xgA0 = g0 - y_first * p.G, xA0 = xgA0 * PX;
@@ -168,7 +192,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         // where arithmetic and requests by themselves take 2100 and 1650 (r04_n).
         const int padpx = p.G * PX - p.W1;
         const int j1 = wave + NW;                                         // my second task: a row, the in1 piece (j1 == nrows) or none
-        const int yr0 = min(y_first + wave, p.H2 - 1), yr1 = min(y_first + j1, p.H2 - 1);
+        const int yr0 = min(y_first + dy0 + wave, p.H2 - 1), yr1 = min(y_first + dy0 + j1, p.H2 - 1);
         const char *rp0 = reinterpret_cast<const char *>(p.in2) + (long long)yr0 * p.W2 * 4;
         const char *rp1 = j1 < nrows ? reinterpret_cast<const char *>(p.in2) + (long long)yr1 * p.W2 * 4
                                      : reinterpret_cast<const char *>(p.in1) + ((long long)y_first * p.W1 + xA0) * 4;
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         // one contiguous run of the output (1 KB, line-aligned, at 16 x 16).  The image is [lane][WNP]; WNP = WN + 4 where WN is a multiple
         // of 8 keeps the 64 lanes' 16-B writes on different banks.
         const long long tile_px0 = (long long)y_first * p.W1 + xA0;       // first pixel of the tile (row-major pixel index)
-        const int WNP = ff_wnp(WN);
+        const int WNP = ff_wnp(WL);
         if constexpr (ARGMIN) {
             // Every (lane, pixel, window row) leaves its row's minimum and the first cell attaining it (strict '<' in cell order) in LDS --
             // cand[slot 4 l + q][row] -- the extra task's lanes one candidate per 4-cell group of row 16 (cand[..][16 + c]); then one
@@ -382,7 +406,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 if (g0 + lc < p.NG && x + q < p.W1) {
                     // (the window's image is shifted by its output address mod 16 B, so that 16-B pieces are aligned on both sides)
                     const int prl = lc * PX - (lc >= nA ? padpx : 0);
-                    const int ash = (int)(((uintptr_t)(p.out + (tile_px0 + prl + q) * WN) >> 2) & 3);
+                    const int ash = (int)(((uintptr_t)(p.out + (tile_px0 + prl + q) * WN + dy0 * MW) >> 2) & 3);
                     lds_f *w = img + lc * WNP + ash + dy * MW;
                     if constexpr (MW % 4 == 0) {
 #pragma unroll
@@ -407,15 +431,28 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (halves && WL == 128 && !((uintptr_t)p.out & 15)) {
+                // half windows of 16 x 16: 128 floats = 32 lanes' 16-B pieces, aligned -- a wave copies TWO windows per step
+                for (int l2 = 2 * wave; l2 < 64; l2 += 2 * NW) {
+                    const int ll = l2 + (lane >> 5);
+                    const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
+                    const int prl = ll * PX - (ll >= nA ? padpx : 0);
+                    const ff_f4 v = *(const lds_f4 *)(img + ll * WNP + 4 * (lane & 31));
+                    if (g0 + ll < p.NG && xg + q < p.W1) {
+                        float *gw = p.out + (tile_px0 + prl + q) * WN + dy0 * MW + 4 * (lane & 31);
+                        asm volatile("global_store_dwordx4 %0, %1, off" FF_ST_FLAGS ::"v"(gw), "v"(v) : "memory");
+                    }
+                }
+            } else
             // the block's waves share the 64 windows: wave w takes lanes w, w + NW, ...
             for (int ll = wave; ll < 64; ll += NW) {
                 const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
                 if (g0 + ll >= p.NG || xg + q >= p.W1) continue;         // (wave-uniform)
                 const int prl = ll * PX - (ll >= nA ? padpx : 0);        // pixel index of the group relative to the tile's first pixel
-                float *gw = p.out + (tile_px0 + prl + q) * WN;
+                float *gw = p.out + (tile_px0 + prl + q) * WN + dy0 * MW;  // my rows of the window: WL floats
                 const int ash = (int)(((uintptr_t)gw >> 2) & 3), head = (4 - ash) & 3;
                 const lds_f *sw = img + ll * WNP + ash;
-                const int nb4 = (WN - head) >> 2, tail0 = head + 4 * nb4;
+                const int nb4 = (WL - head) >> 2, tail0 = head + 4 * nb4;
                 const lds_f4 *sb = (const lds_f4 *)(sw + head);
                 const float *gb = gw + head;
                 constexpr int NJ4 = (17 * MW / 4 + 63) / 64;              // 16-B pieces per lane and window (2)
@@ -423,14 +460,14 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 float vh = 0.f;
 #pragma unroll
                 for (int j = 0; j < NJ4; ++j) v[j] = sb[min(lane + 64 * j, nb4 - 1)];
-                if (lane < 8) vh = sw[lane < 4 ? min(lane, WN - 1) : min(tail0 + lane - 4, WN - 1)];   // lanes 0..3: head floats, 4..7: tail floats
+                if (lane < 8) vh = sw[lane < 4 ? min(lane, WL - 1) : min(tail0 + lane - 4, WL - 1)];   // lanes 0..3: head floats, 4..7: tail floats
                 {
 #pragma unroll
                     for (int j = 0; j < NJ4; ++j)
                         if (lane + 64 * j < nb4)
                             asm volatile("global_store_dwordx4 %0, %1, %2" FF_ST_FLAGS ::"v"((unsigned)(lane + 64 * j) * 16u), "v"(v[j]), "s"(gb) : "memory");
                     if (lane < head) gw[lane] = vh;
-                    if (lane >= 4 && lane < 8 && tail0 + lane - 4 < WN) gw[tail0 + lane - 4] = vh;
+                    if (lane >= 4 && lane < 8 && tail0 + lane - 4 < WL) gw[tail0 + lane - 4] = vh;
                 }
             }
             // every wave is past its reads of the image before the next phase (or the next tile's tables / first plane) overwrites it
@@ -461,18 +498,22 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
     a.idx = idx; a.xflow = xflow; a.yflow = yflow;
     a.lWin = (maxw + 1) / 2 - 1; a.tWin = (maxh + 1) / 2 - 1;            // version2/test.lua:18-19
     const bool extra = maxh == 17;
-    const int NW = extra ? 16 : maxh;
+    // two half blocks per tile and CU where the window's rows split evenly into halves of >= 4 waves (the arg-min form needs the whole
+    // window in one block; 17 rows = 17 waves do not fit a CU's registers as 9 + 8)
+    const bool split = !argmin && !extra && maxh >= 8 && maxh % 2 == 0 && ctx->opt_bool(DFE_OPT_FM_SPLIT, true);
+    a.S = split ? 2 : 1;
+    a.nd = extra ? 16 : maxh / a.S;
+    const int NW = a.nd;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
-    const int WN = maxh * maxw;
-    const int WNP = ff_wnp(WN);
-    const size_t lds = ((size_t)3 * (maxh + 1) * PITCH + 3 * 64 * FF_PX + 64 + (size_t)64 * WNP) * sizeof(float);
-    if (lds > 160 * 1024) return DFE_OK;
+    const int WNP = ff_wnp((extra ? 17 : a.nd) * maxw);
+    const size_t lds = ((size_t)3 * (extra ? 18 : a.nd + 1) * PITCH + 3 * 64 * FF_PX + 64 + (size_t)64 * WNP) * sizeof(float);
+    if (lds * a.S > 160 * 1024) return DFE_OK;
     void (*kern)(FfArgs) = argmin ? (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, true> : feat_matching_flat_kernel<17, false, true>)
                                                 : feat_matching_flat_kernel<16, false, true>)
                                   : (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
                                                 : feat_matching_flat_kernel<16, false>);
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
+    const int nblk = (a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu) * a.S;
     {
         DfeProfScope prof(ctx);
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), lds, ctx->stream, a);

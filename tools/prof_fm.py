@@ -16,6 +16,10 @@ SHAPES = {
     "k10": (10, 480 - 15, 640 - 15, 16),
     "tm": (10, 180 - 12 - 15, 320 - 12 - 15, 16),
     "k32-720p": (32, 720 - 15, 1280 - 15, 16),
+    "k32-r4": (32, 512, 512, 16),     # 1024 tiles of the flat kernel: exactly 4 rounds on 256 CUs
+    "k32-r45": (32, 576, 512, 16),    # 1152 tiles: 4.5 rounds
+    "k32-r1": (32, 128, 512, 16),     # 256 tiles: one round
+    "k32-r05": (32, 64, 512, 16),     # 128 tiles: half of the CUs
 }
 
 
