@@ -144,6 +144,9 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     } else if (!(nbx & 7)) {
         vb = (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3);
     }
+    // (Also tried: CU j of an XCD starting j x 2048 cycles late, so that the 32 CUs of an XCD -- which run in step -- do not copy out
+    //  at the same moment through the XCD's one fabric port: 4 full rounds 0.213 -> 0.232 ms, i.e. the delay itself minus ~3 us a
+    //  round; the copy-out's 21 kilocycles a tile are not a shared-port effect either.  profiles/r04_aj_fm_cu_stagger.txt)
 
     // (Tried: the blocks of XCD x starting x * 1 .. 8 us later, so that the XCDs' copy-out bursts come one after the other -- no gain,
     //  profiles/r04_u: the bursts are not what the copy-out waits for.)
