@@ -157,6 +157,9 @@ int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, 
 // nn.SpatialContrastiveNormalization with caller-provided scratch ((C + 3) * H * W floats): for the one-call pipelines (filters.hip)
 int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
                                       float thresval, float *scratch, float *out);
+// ... of two frames of one size in the same two launches; out0 only the crop window cw x ch at (cx, cy) when cw > 0 (scratch: 4 * H * W floats)
+int dfe_contrastive_normalization_run2(dfe_ctx *ctx, const float *in0, const float *in1, int C, int H, int W, const float *kernel_host, int k,
+                                       float threshold, float thresval, float *scratch, float *out0, float *out1, int cx, int cy, int cw, int ch);
 // nn.SpatialMatching on feature maps, fast kernels or the reference-order one (ssd_cost_volume.hip)
 int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 

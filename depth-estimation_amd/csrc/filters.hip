@@ -347,86 +347,167 @@ namespace {
 constexpr int CN_MAXK = 33;
 struct CnKernel { float kn[CN_MAXK]; int k; };
 
-// mode 0: src = in; 1: src = (in - est/coef)^2 (the divisive stage's input, recomputed instead of stored)
-template <int MODE>
-__global__ void cn_rows_kernel(const float *__restrict__ in, const float *__restrict__ est, const float *__restrict__ coef, int C, int H, int W,
-                               CnKernel kk, int ones, float *__restrict__ tmp) {
-#pragma clang fp contract(off)
-    const long long n = (long long)C * H * W, P = (long long)H * W;
-    const int pl = kk.k / 2;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % W);
-        const long long row = e - x;
-        const long long p0 = (e % P) - x;
-        float s = 0.f;
-        for (int v = 0; v < kk.k; ++v) {
-            const int xx = x + v - pl;
-            float a = 0.f;
-            if (xx >= 0 && xx < W) {
-                if (ones) a = 1.f;
-                else if (MODE == 0) a = in[row + xx];
-                else { const float y = in[row + xx] - est[p0 + xx] / coef[p0 + xx]; a = y * y; }
-            }
-            s = s + kk.kn[v] * a;
-        }
-        tmp[e] = s;
-    }
-}
+// Two launches for up to two frames (blockIdx.z), each a tile kernel that does an estimator's horizontal pass, vertical pass and plane
+// sum in LDS, in the term order of the stand-alone passes (`s = s + kn[v] * a` over v, then over planes and u: c outer, u inner; zero
+// padding as operands, not as skipped terms):
+//   MODE 0: est = estimator(in), coef = estimator(ones) (no memory operand: 17 + C * 17 terms per pixel, recomputed per call)
+//   MODE 1: est2 = estimator((in - est / coef)^2), then out = (in - est / coef) / max-thresholded(sqrt(est2) / coef), optionally only a
+//           crop window of it (version2's SpatialPadding(-lWin, -tWin, -rWin, -bWin) behind the first branch's normalisation).
+// (First version: seven grid-stride launches per frame through a C-plane temporary -- 100 us per VGA frame, a fifth of version2's step.)
+struct CnFused {
+    const float *in[2];
+    float *est[2], *coef[2], *out[2];
+    int cx[2], cy[2], cw[2], ch[2];        // crop window of out[f] (cw x ch at (cx, cy); the whole frame: 0, 0, W, H)
+    int C, H, W;
+    float threshold, thresval;
+    CnKernel kk;
+};
+constexpr int CN_TW = 64, CN_TH = 16;
+extern __shared__ float cn_smem[];
 
-__global__ void cn_cols_kernel(const float *__restrict__ tmp, int C, int H, int W, CnKernel kk, float *__restrict__ out) {
+template <int MODE, int KT>   // KT: the kernel size as a constant (taps unrolled, coefficients in scalar registers), 0 = any size <= CN_MAXK
+__global__ __launch_bounds__(256) void cn_fused_kernel(CnFused a) {
 #pragma clang fp contract(off)
+    const int k = KT ? KT : a.kk.k, pl = k / 2, RH = CN_TH + k - 1, SW = CN_TW + k - 1;
+    float *src = cn_smem;                   // [RH][SW] the plane's tile with its halo, zero outside the frame
+    float *tmpl = src + RH * SW;            // [RH][TW] after the horizontal pass
+    float *qt = tmpl + RH * CN_TW;          // [RH][SW] MODE 1: est / coef on the halo'd tile
+    float *kl = qt + (MODE == 1 ? RH * SW : 0);   // KT == 0: the coefficients (a run-time index into the argument block would be a scalar load per tap)
+    const int f = blockIdx.z, H = a.H, W = a.W, C = a.C;
+    const float *in = a.in[f];
+    const int x0 = blockIdx.x * CN_TW, y0 = blockIdx.y * CN_TH;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long long P = (long long)H * W;
-    const int pl = kk.k / 2;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < P; e += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % W), y = (int)(e / W);
-        float s = 0.f;
-        for (int c = 0; c < C; ++c)
-            for (int u = 0; u < kk.k; ++u) {
-                const int yy = y + u - pl;
-                const float a = (yy >= 0 && yy < H) ? tmp[c * P + (long long)yy * W + x] : 0.f;
-                s = s + kk.kn[u] * a;
-            }
-        out[e] = s;
+    auto kn = [&](int v) { return KT ? a.kk.kn[v] : kl[v]; };
+    if (!KT) {
+        if (threadIdx.x < CN_MAXK) kl[threadIdx.x] = a.kk.kn[threadIdx.x];
     }
-}
-
-__global__ void cn_finish_kernel(const float *__restrict__ in, const float *__restrict__ est, const float *__restrict__ est2,
-                                 const float *__restrict__ coef, int C, long long P, float threshold, float thresval, float *__restrict__ out) {
-#pragma clang fp contract(off)
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < C * P; e += (long long)gridDim.x * blockDim.x) {
-        const long long p = e % P;
-        const float y = in[e] - est[p] / coef[p];
-        float sd = sqrtf(est2[p]) / coef[p];
-        sd = sd > threshold ? sd : thresval;
-        out[e] = y / sd;
+    if (MODE == 1) {
+        const float *est = a.est[f], *coef = a.coef[f];
+        for (int i = threadIdx.x; i < RH * SW; i += 256) {
+            const int r = i / SW, c = i - r * SW, yy = y0 + r - pl, xx = x0 + c - pl;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            qt[i] = ok ? est[(long long)yy * W + xx] / coef[(long long)yy * W + xx] : 0.f;
+        }
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        __syncthreads();                    // the previous plane's vertical pass is done with tmpl (and everyone with src)
+        for (int i = threadIdx.x; i < RH * SW; i += 256) {
+            const int r = i / SW, cc = i - r * SW, yy = y0 + r - pl, xx = x0 + cc - pl;
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                v = in[c * P + (long long)yy * W + xx];
+                if (MODE == 1) { const float y = v - qt[i]; v = y * y; }      // (qt[i] is this thread's own write)
+            }
+            src[i] = v;
+        }
+        __syncthreads();
+        for (int r = ty; r < RH; r += 4) {
+            const float *sr = src + r * SW + tx;
+            float t = 0.f;
+            if (KT) {
+#pragma unroll
+                for (int v = 0; v < (KT ? KT : 1); ++v) t = t + kn(v) * sr[v];
+            } else {
+                for (int v = 0; v < k; ++v) t = t + kn(v) * sr[v];
+            }
+            tmpl[r * CN_TW + tx] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *tc = tmpl + (ty + 4 * j) * CN_TW + tx;
+            if (KT) {
+#pragma unroll
+                for (int u = 0; u < (KT ? KT : 1); ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
+            } else {
+                for (int u = 0; u < k; ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
+            }
+        }
+    }
+    const int x = x0 + tx;
+    if (x >= W) return;
+    if (MODE == 0) {
+        float ro = 0.f;                     // the horizontal pass over a row of ones
+        for (int v = 0; v < k; ++v) {
+            const int xx = x + v - pl;
+            ro = ro + kn(v) * ((xx >= 0 && xx < W) ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + ty + 4 * j;
+            if (y >= H) continue;
+            float cf = 0.f;
+            for (int c = 0; c < C; ++c)
+                for (int u = 0; u < k; ++u) {
+                    const int yy = y + u - pl;
+                    cf = cf + kn(u) * ((yy >= 0 && yy < H) ? ro : 0.f);
+                }
+            a.est[f][(long long)y * W + x] = s[j];
+            a.coef[f][(long long)y * W + x] = cf;
+        }
+    } else {
+        const int cx = a.cx[f], cy = a.cy[f], cw = a.cw[f], ch = a.ch[f];
+        if (x < cx || x >= cx + cw) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = y0 + ty + 4 * j;
+            if (y >= H || y < cy || y >= cy + ch) continue;
+            const long long p = (long long)y * W + x;
+            const float cf = a.coef[f][p];
+            float sd = sqrtf(s[j]) / cf;
+            sd = sd > a.threshold ? sd : a.thresval;
+            const float q = a.est[f][p] / cf;
+            for (int c = 0; c < C; ++c) a.out[f][((long long)c * ch + (y - cy)) * cw + (x - cx)] = (in[c * P + p] - q) / sd;
+        }
     }
 }
 
 }  // namespace
 
-// scratch: (C + 3) * H * W floats of device memory
-int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
-                                      float thresval, float *scratch, float *out) {
-    DFE_REQUIRE(ctx, in && kernel_host && out && scratch, DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
+// Normalises in0 (and in1 when not NULL) -- same C x H x W -- into out0 / out1; out0 receives only the crop window (cw x ch at (cx, cy))
+// when cw > 0.  scratch: 4 * H * W floats of device memory.
+int dfe_contrastive_normalization_run2(dfe_ctx *ctx, const float *in0, const float *in1, int C, int H, int W, const float *kernel_host, int k,
+                                       float threshold, float thresval, float *scratch, float *out0, float *out1, int cx, int cy, int cw, int ch) {
+    DFE_REQUIRE(ctx, in0 && kernel_host && out0 && scratch && (!in1 || out1), DFE_E_ARG, "dfe_contrastive_normalization_f32: NULL argument");
     DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && k > 0 && k <= CN_MAXK, DFE_E_SHAPE, "dfe_contrastive_normalization_f32: C=%d %dx%d kernel %d (max %d)", C, H,
                 W, k, CN_MAXK);
-    CnKernel kk;
-    kk.k = k;
+    DFE_REQUIRE(ctx, cw <= 0 || (cx >= 0 && cy >= 0 && ch > 0 && cx + cw <= W && cy + ch <= H), DFE_E_SHAPE,
+                "dfe_contrastive_normalization_f32: crop %dx%d at (%d, %d) of %dx%d", cw, ch, cx, cy, W, H);
+    CnFused a{};
+    a.kk.k = k;
     float ks = 0.f;
     for (int i = 0; i < k; ++i) ks += kernel_host[i];
-    for (int i = 0; i < k; ++i) kk.kn[i] = kernel_host[i] / (ks * (float)C);       // self.kernel:div(self.kernel:sum() * self.nInputPlane)
+    for (int i = 0; i < k; ++i) a.kk.kn[i] = kernel_host[i] / (ks * (float)C);     // self.kernel:div(self.kernel:sum() * self.nInputPlane)
     const long long P = (long long)H * W;
-    float *tmp = scratch, *coef = tmp + C * P, *est = coef + P, *est2 = est + P;
-    const int g1 = grid_n(C * P), g2 = grid_n(P);
-    hipLaunchKernelGGL(cn_rows_kernel<0>, dim3(g1), dim3(256), 0, ctx->stream, in, (const float *)nullptr, (const float *)nullptr, C, H, W, kk, 1, tmp);
-    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, coef);
-    hipLaunchKernelGGL(cn_rows_kernel<0>, dim3(g1), dim3(256), 0, ctx->stream, in, (const float *)nullptr, (const float *)nullptr, C, H, W, kk, 0, tmp);
-    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, est);
-    hipLaunchKernelGGL(cn_rows_kernel<1>, dim3(g1), dim3(256), 0, ctx->stream, in, est, coef, C, H, W, kk, 0, tmp);
-    hipLaunchKernelGGL(cn_cols_kernel, dim3(g2), dim3(256), 0, ctx->stream, tmp, C, H, W, kk, est2);
-    hipLaunchKernelGGL(cn_finish_kernel, dim3(g1), dim3(256), 0, ctx->stream, in, est, est2, coef, C, P, threshold, thresval, out);
+    const int nf = in1 ? 2 : 1;
+    a.in[0] = in0; a.in[1] = in1; a.out[0] = out0; a.out[1] = out1;
+    for (int f = 0; f < 2; ++f) {
+        a.coef[f] = scratch + 2 * f * P;
+        a.est[f] = scratch + (2 * f + 1) * P;
+        a.cx[f] = 0; a.cy[f] = 0; a.cw[f] = W; a.ch[f] = H;
+    }
+    if (cw > 0) { a.cx[0] = cx; a.cy[0] = cy; a.cw[0] = cw; a.ch[0] = ch; }
+    a.C = C; a.H = H; a.W = W; a.threshold = threshold; a.thresval = thresval;
+    const dim3 grid(dfe_cdiv(W, CN_TW), dfe_cdiv(H, CN_TH), nf);
+    const int RH = CN_TH + k - 1, SW = CN_TW + k - 1;
+    const size_t lds0 = ((size_t)RH * SW + (size_t)RH * CN_TW + CN_MAXK) * sizeof(float), lds1 = lds0 + (size_t)RH * SW * sizeof(float);
+    if (k == 17) {
+        hipLaunchKernelGGL((cn_fused_kernel<0, 17>), grid, dim3(256), lds0, ctx->stream, a);
+        hipLaunchKernelGGL((cn_fused_kernel<1, 17>), grid, dim3(256), lds1, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL((cn_fused_kernel<0, 0>), grid, dim3(256), lds0, ctx->stream, a);
+        hipLaunchKernelGGL((cn_fused_kernel<1, 0>), grid, dim3(256), lds1, ctx->stream, a);
+    }
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
+}
+
+// scratch: (C + 3) * H * W floats of device memory (>= the 4 * H * W of the fused form)
+int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
+                                      float thresval, float *scratch, float *out) {
+    return dfe_contrastive_normalization_run2(ctx, in, nullptr, C, H, W, kernel_host, k, threshold, thresval, scratch, out, nullptr, 0, 0, 0, 0);
 }
 
 extern "C" int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,

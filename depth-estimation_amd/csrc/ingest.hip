@@ -37,14 +37,47 @@ __global__ void rgb2y_kernel(const float *__restrict__ rgb, long long P, float *
     }
 }
 
-// minimum over the leading dimension of an [n][M] view (first row attaining it), one thread per column: tests/time_matching.lua:41-43
-__global__ void min_dim0_kernel(const float *__restrict__ in, int n, long long M, float *__restrict__ val, long long *__restrict__ idx) {
-    for (long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
-        float best = in[m];
-        int bi = 0;
-        for (int r = 1; r < n; ++r) {
-            const float v = in[(long long)r * M + m];
+// minimum over the leading dimension of an [n][M] view (first row attaining it): tests/time_matching.lua:41-43, where the view is the
+// matcher's volume read as [wsize * wsize][W' * H'].  A block = 64 columns x MD_RG row groups: group g walks its n / MD_RG rows (loads of
+// 256 contiguous bytes per wave and row, eight in flight), the groups' first minima meet in LDS and are merged in row order with the
+// same strict '<' -- the row the sequential loop `best = in[0]; if (v < best) ...` ends on, NaN handling included (a NaN in row 0
+// stays, a NaN elsewhere never wins).  (First version: one thread per column, 256 dependent loads each: 101 us for the script's 46 MB.)
+constexpr int MD_RG = 16;
+__global__ __launch_bounds__(64 * MD_RG) void min_dim0_kernel(const float *__restrict__ in, int n, long long M, float *__restrict__ val,
+                                                              long long *__restrict__ idx) {
+    __shared__ float sv[MD_RG][64];
+    __shared__ int si[MD_RG][64];
+    const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long m = (long long)blockIdx.x * 64 + tx;
+    const int per = (n + MD_RG - 1) / MD_RG;
+    const int r0 = g * per, r1 = min(n, r0 + per);
+    float best = __int_as_float(0x7f800000);
+    int bi = -1;
+    if (m < M) {
+        const float *p = in + m;
+        int r = r0;
+        if (g == 0 && r < r1) { best = p[0]; bi = 0; r = 1; }
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long long)(r + u) * M];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (v[u] < best) { best = v[u]; bi = r + u; }
+        }
+        for (; r < r1; ++r) {
+            const float v = p[(long long)r * M];
             if (v < best) { best = v; bi = r; }
+        }
+    }
+    sv[g][tx] = best;
+    si[g][tx] = bi;
+    __syncthreads();
+    if (g == 0 && m < M) {
+#pragma unroll
+        for (int h = 1; h < MD_RG; ++h) {
+            const float v = sv[h][tx];
+            if (si[h][tx] >= 0 && v < best) { best = v; bi = si[h][tx]; }
         }
         if (val) val[m] = best;
         if (idx) idx[m] = (long long)bi + 1;
@@ -101,7 +134,8 @@ int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, in && (val || idx), DFE_E_ARG, "dfe_min_dim0_f32: NULL tensor");
     DFE_REQUIRE(ctx, n > 0 && M > 0, DFE_E_SHAPE, "dfe_min_dim0_f32: %d x %lld", n, (long long)M);
-    hipLaunchKernelGGL(min_dim0_kernel, dim3(in_grid(M)), dim3(256), 0, ctx->stream, in, n, (long long)M, val, (long long *)idx);
+    DFE_REQUIRE(ctx, (M + 63) / 64 < (1ll << 31), DFE_E_SHAPE, "dfe_min_dim0_f32: %lld columns", (long long)M);
+    hipLaunchKernelGGL(min_dim0_kernel, dim3((unsigned)((M + 63) / 64)), dim3(64 * MD_RG), 0, ctx->stream, in, n, (long long)M, val, (long long *)idx);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

@@ -10,16 +10,6 @@
 
 namespace {
 
-__global__ void v2_crop_kernel(const float *__restrict__ in, int C, int H, int W, int l, int t, int Ho, int Wo, float *__restrict__ out) {
-    const long long n = (long long)C * Ho * Wo;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(e % Wo);
-        const long long r = e / Wo;
-        const int y = (int)(r % Ho), c = (int)(r / Ho);
-        out[e] = in[((long long)c * H + y + t) * W + x + l];
-    }
-}
-
 // one wave per pixel: first minimum of the window's N cells (index order), decoded as version2/test.lua:45-51 does
 __global__ __launch_bounds__(256) void v2_argmin_decode_kernel(const float *__restrict__ vol, long long P, int N, int wWin, int lWin, int tWin,
                                                                long long *__restrict__ idx, float *__restrict__ xflow, float *__restrict__ yflow) {
@@ -80,7 +70,7 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
     DFE_REQUIRE(ctx, H1 > 0 && W1 > 0, DFE_E_SHAPE, "dfe_version2_flow_pair_f32: frame %dx%d too small for window %dx%d + kernel %dx%d", H, W, hWin, wWin, hk, wk);
     const int K = layers[nlayers - 1].nOut, N = hWin * wWin;
     const long long P = (long long)H * W, P1 = (long long)H1 * W1;
-    // arena: normalisation scratch | n0 | n1 | cropped n0 | two ping-pong feature buffers per branch | volume (unless the caller gave one)
+    // arena: normalisation scratch | normalised cur | cropped normalised prev | two ping-pong feature buffers per branch | volume (unless the caller gave one)
     int maxplanes = C;
     for (int i = 0; i < nlayers; ++i) maxplanes = maxplanes > layers[i].nOut ? maxplanes : layers[i].nOut;
     const size_t f_cn = ((size_t)C + 3) * P, f_n = (size_t)C * P, f_c = (size_t)C * Hc * Wc;
@@ -88,21 +78,19 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
     const size_t f_vol = volume ? 0 : (size_t)P1 * N;
     auto al = [](size_t f) { return (f + 63) / 64 * 64; };
     void *scr = nullptr;
-    int rc = dfe_scratch(ctx, (al(f_cn) + 2 * al(f_n) + al(f_c) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_vol)) * sizeof(float), &scr);
+    int rc = dfe_scratch(ctx, (al(f_cn) + al(f_n) + al(f_c) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_vol)) * sizeof(float), &scr);
     if (rc) return rc;
-    float *s_cn = (float *)scr, *n0 = s_cn + al(f_cn), *n1 = n0 + al(f_n), *c0 = n1 + al(f_n);
+    float *s_cn = (float *)scr, *n1 = s_cn + al(f_cn), *c0 = n1 + al(f_n);
     float *fa[2] = {c0 + al(f_c), c0 + al(f_c) + al(f_fa)};
     float *fb[2] = {fa[1] + al(f_fa), fa[1] + al(f_fa) + al(f_fb)};
     float *vol = volume ? volume : fb[1] + al(f_fb);
     const float *ia = c0, *ib = n1;
     {
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
-        rc = dfe_contrastive_normalization_run(ctx, prev, C, H, W, norm_kernel_host, norm_k, threshold, thresval, s_cn, n0);
+        // both frames in the normalisation's two launches; the first branch's crop (SpatialPadding(-lWin, -tWin, -rWin, -bWin)) is the
+        // window its last launch writes
+        rc = dfe_contrastive_normalization_run2(ctx, prev, cur, C, H, W, norm_kernel_host, norm_k, threshold, thresval, s_cn, c0, n1, lWin, tWin, Wc, Hc);
         if (rc) return rc;
-        rc = dfe_contrastive_normalization_run(ctx, cur, C, H, W, norm_kernel_host, norm_k, threshold, thresval, s_cn, n1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(v2_crop_kernel, dim3(v2_grid((long long)C * Hc * Wc, 256)), dim3(256), 0, ctx->stream, n0, C, H, W, lWin, tWin, Hc, Wc, c0);
-        DFE_LAUNCH_CHECK(ctx);
         int ha = Hc, wa = Wc, hb = H, wb = W;
         for (int i = 0; i < nlayers; ++i) {
             const float *in2[2] = {ia, ib};

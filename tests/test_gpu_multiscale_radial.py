@@ -1169,7 +1169,8 @@ def test_contrastive_normalization_equals_oracle(dfe, cuda):
     """nn.SpatialContrastiveNormalization(3, image.gaussian1D(k)) (version2/network.lua:12): bit-identical to the oracle's
     restatement (same term order), zero local mean / unit local deviation where the kernel fits, borders corrected."""
     rng = np.random.default_rng(4)
-    for k, H, W in ((7, 40, 56), (9, 33, 31), (4, 20, 24)):
+    # (17: the unrolled instantiation of version2's normalization_k; frames of several 64 x 16 tiles with ragged edges; 33: the largest kernel)
+    for k, H, W in ((7, 40, 56), (9, 33, 31), (4, 20, 24), (17, 70, 150), (17, 21, 200), (33, 50, 90)):
         x = (rng.random((3, H, W)) * 3 + 1).astype(np.float32)
         g = orc.gaussian1D(k)
         assert np.array_equal(dfe.network.gaussian1D(k).numpy(), g)

@@ -1254,3 +1254,29 @@ def test_time_matching_lua_exact_shape(dfe, cuda):
     view = out.cpu().numpy().reshape(256, M)
     assert np.array_equal(mn.cpu().numpy(), view.min(axis=0)) and np.array_equal(mi.cpu().numpy(), view.argmin(axis=0) + 1)
 
+
+
+@pytest.mark.parametrize("n,M", [(256, 1000), (37, 129), (5, 64), (1, 70), (16, 63), (100, 4099)])
+def test_min_dim0_is_the_sequential_first_minimum(dfe, cuda, n, M):
+    """dfe_min_dim0_f32 (tests/time_matching.lua:41-43, `output:min(1)`): the row the loop `best = in[0]; if (v < best) ...` ends on -- ties
+    go to the first row, +inf never replaces, a NaN in row 0 stays and a NaN elsewhere never wins -- for row counts that do not divide
+    into the kernel's 16 row groups and column counts that do not fill its 64-column blocks."""
+    rng = np.random.default_rng(n * 1000 + M)
+    a = rng.integers(0, 6, size=(n, M)).astype(np.float32)            # many ties
+    a[:, 3] = np.inf
+    if n > 2:
+        a[2, 5] = np.nan
+        a[0, 7] = np.nan
+        a[n - 1, 9] = -1.0
+    ctx = dfe.get_ctx(0)
+    t = torch.from_numpy(a).to(cuda)
+    mn = torch.empty((M,), device=cuda)
+    mi = torch.empty((M,), dtype=torch.int64, device=cuda)
+    ctx.check(dfe.lib().dfe_min_dim0_f32(ctx.handle, t.data_ptr(), n, M, mn.data_ptr(), mi.data_ptr()))
+    best, bi = a[0].copy(), np.zeros(M, dtype=np.int64)
+    with np.errstate(invalid="ignore"):
+        for r in range(1, n):
+            w = a[r] < best
+            best[w] = a[r][w]
+            bi[w] = r
+    assert np.array_equal(mn.cpu().numpy(), best, equal_nan=True) and np.array_equal(mi.cpu().numpy(), bi + 1)
