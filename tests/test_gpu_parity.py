@@ -262,6 +262,8 @@ def test_spatial_matching_module_bit_exact(dfe, cuda):
     (3, 6, 290, 8, 16),      # fewer window rows than waves: 8 x 16
     (3, 6, 327, 12, 17),     # 17 wide, 12 high (no extra task)
     (1, 1, 260, 16, 16),     # a single output row, one plane
+    (3, 6, 270, 14, 16),     # half tiles of 7 window rows (fm_split: two blocks per tile), 112-float half windows
+    (2, 4, 300, 10, 17),     # half tiles of 5 rows of a 17-wide window (unaligned half windows)
 ])
 def test_spatial_matching_flat_kernel_bit_exact(dfe, cuda, K, H1, W1, mh, mw):
     """nn.SpatialMatching with 16- / 17-wide windows on wide feature maps (opticalflow_model.lua:93, version2/network.lua:30,
@@ -285,13 +287,19 @@ def test_spatial_matching_flat_kernel_bit_exact(dfe, cuda, K, H1, W1, mh, mw):
         old = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
         assert ctx.last_kernel() != "feat_matching_flat_kernel"
     assert torch.equal(old, out)
+    with ctx.options(fm_split=0):                                    # one block per tile instead of two half blocks
+        whole = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
+        assert ctx.last_kernel() == "feat_matching_flat_kernel"
+    assert torch.equal(whole, out)
 
 
-def test_spatial_matching_flat_kernel_output_is_bounded(dfe, cuda):
+@pytest.mark.parametrize("mh,mw", [(17, 17), (16, 16), (10, 16)])
+def test_spatial_matching_flat_kernel_output_is_bounded(dfe, cuda, mh, mw):
     """The flat-tile kernel writes nothing outside its output: guard floats in front of and behind an (unaligned) output buffer stay
-    untouched, and an output that starts 4 bytes off a 16-B boundary (partial head / tail lines everywhere) is still bit-exact."""
+    untouched, and an output that starts 4 bytes off a 16-B boundary (partial head / tail lines everywhere; with half tiles the
+    general copy path instead of the two-windows-per-wave one) is still bit-exact."""
     rng = np.random.default_rng(77)
-    K, H1, W1, mh, mw = 3, 4, 270, 17, 17
+    K, H1, W1 = 3, 4, 270
     in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
     in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
     n = H1 * W1 * mh * mw
