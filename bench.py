@@ -692,10 +692,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libdfe has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a one-GPU box only (tools/rehearse_ranks.sh): DFE_BENCH_DEVICE puts every rank on that device, DFE_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one GPU).  The driver's launch sets neither: one rank per GPU over RCCL.
+    dev_index = int(os.environ.get("DFE_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("DFE_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    local_rank = dev_index
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.workload in PYRAMIDS:
         return main_pyramid(args, world, rank, local_rank, dev, torch, dist, d, rp)
