@@ -132,15 +132,17 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     //  L2 requests missed, 790 MB were fetched for 39 MB of in2 and every plane waited out a memory round trip: r04_g, r04_j.)
     const int nbx = gridDim.x;
     int vb = (int)blockIdx.x;
-    if (!ARGMIN && !EXTRA && p.S == 2 && !(nbx & 15)) {
+    const int S = (!ARGMIN && !EXTRA) ? p.S : 1, lgS = S == 4 ? 2 : S == 2 ? 1 : 0;   // (the arg-min form and the 17-row window: always whole tiles)
+    if (S > 1 && !(nbx & (8 * S - 1))) {
         // two blocks per CU: the dispatcher fills every CU once (blocks 0 .. nbx/2 - 1), then a second time (blocks b and b + nbx/2
         // share a CU: tools/ubench/cuid.hip, profiles/r04_ah_cu_residency.txt).  The second set takes the upper half of every round's
         // tiles -- of a last, partial round none, so that its half tiles run one to a CU, 1.5 x faster than two to a CU.
         // (Tried: the second set starting 0.25 .. 1.5 tiles late, to keep the two blocks of a CU in different phases -- no gain, and
         //  a loss from 8 sleeps on: profiles/r04_ag_fm_split_sweep.txt.  The gain of the split is the last round: 4 full rounds take
         //  0.213 ms either way, r04_ag_fm_split_rounds.txt.)
-        const int hb = nbx >> 1, b = (int)blockIdx.x >= hb ? (int)blockIdx.x - hb : (int)blockIdx.x;
-        vb = ((int)blockIdx.x >= hb ? hb : 0) + (b & 7) * (hb >> 3) + (b >> 3);
+        // (S == 4: four sets, blocks b, b + nbx/4, ... on one CU.)
+        const int hb = nbx >> lgS, set = (int)blockIdx.x / hb, b = (int)blockIdx.x - set * hb;
+        vb = set * hb + (b & 7) * (hb >> 3) + (b >> 3);
     } else if (!(nbx & 7)) {
         vb = (int)(blockIdx.x & 7) * (nbx >> 3) + (int)(blockIdx.x >> 3);
     }
@@ -154,11 +156,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     // with its own barriers.  1141 tiles on 256 CUs are 4.46 rounds that cost one block per CU 5; as half tiles the last round's
     // blocks have their CU to themselves and finish in 0.65 of a round (K = 32, 625 x 465: 0.265 -> 0.232 ms, K = 10: 0.134 -> 0.101).
     // The price: the in1 piece and one in2 row are staged by both halves.
-    const bool halves = !ARGMIN && !EXTRA && p.S == 2;    // (the arg-min form and the 17-row window: always whole tiles)
-    const int nvt = halves ? 2 * p.ntiles : p.ntiles;
+    const bool halves = S > 1;
+    const int nvt = p.ntiles << lgS;
     for (int vt = vb; vt < nvt; vt += nbx) {
-        const int t = halves ? vt >> 1 : vt;
-        const int dy0 = halves ? (vt & 1) * nd : 0;
+        const int t = vt >> lgS;
+        const int dy0 = (vt & (S - 1)) * nd;
         // ---- tile geometry (wave-uniform scalars, then per-lane offsets) ----
         const int g0 = t * FF_GROUPS;
         const int y_first = g0 / p.G, xgA0 = g0 - y_first * p.G, xA0 = xgA0 * PX;
@@ -434,15 +436,16 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (halves && WL == 128 && !((uintptr_t)p.out & 15)) {
-                // half windows of 16 x 16: 128 floats = 32 lanes' 16-B pieces, aligned -- a wave copies TWO windows per step
-                for (int l2 = 2 * wave; l2 < 64; l2 += 2 * NW) {
-                    const int ll = l2 + (lane >> 5);
+            if (halves && MW == 16 && (WL == 128 || WL == 64) && !((uintptr_t)p.out & 15)) {
+                // half / quarter windows of 16 x 16: 128 / 64 floats = 32 / 16 lanes' 16-B pieces, aligned -- a wave copies 2 / 4 windows per step
+                const int lgl = WL == 128 ? 5 : 4, wps = 64 >> lgl, pc = lane & ((1 << lgl) - 1);
+                for (int l2 = wps * wave; l2 < 64; l2 += wps * NW) {
+                    const int ll = l2 + (lane >> lgl);
                     const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
                     const int prl = ll * PX - (ll >= nA ? padpx : 0);
-                    const ff_f4 v = *(const lds_f4 *)(img + ll * WNP + 4 * (lane & 31));
+                    const ff_f4 v = *(const lds_f4 *)(img + ll * WNP + 4 * pc);
                     if (g0 + ll < p.NG && xg + q < p.W1) {
-                        float *gw = p.out + (tile_px0 + prl + q) * WN + dy0 * MW + 4 * (lane & 31);
+                        float *gw = p.out + (tile_px0 + prl + q) * WN + dy0 * MW + 4 * pc;
                         asm volatile("global_store_dwordx4 %0, %1, off" FF_ST_FLAGS ::"v"(gw), "v"(v) : "memory");
                     }
                 }
@@ -503,8 +506,12 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
     const bool extra = maxh == 17;
     // two half blocks per tile and CU where the window's rows split evenly into halves of >= 4 waves (the arg-min form needs the whole
     // window in one block; 17 rows = 17 waves do not fit a CU's registers as 9 + 8)
-    const bool split = !argmin && !extra && maxh >= 8 && maxh % 2 == 0 && ctx->opt_bool(DFE_OPT_FM_SPLIT, true);
-    a.S = split ? 2 : 1;
+    // (option fm_split: 0 whole tiles, 1 / 2 halves, 4 quarters; the launcher's own choice: quarters for few planes -- the copy-out is
+    //  then a larger share of a tile, K = 10: 0.102 -> 0.098 ms, time_matching.lua's shape 0.024 -> 0.022 -- else halves, which cost
+    //  less staging: profiles/r04_ao_fm_quarters.txt)
+    const int want = ctx->opt[DFE_OPT_FM_SPLIT] < 0 ? (K <= 16 ? 4 : 2) : ctx->opt[DFE_OPT_FM_SPLIT] == 1 ? 2 : ctx->opt[DFE_OPT_FM_SPLIT];
+    const bool can = !argmin && !extra;
+    a.S = can && want >= 4 && maxh == 16 ? 4 : can && want >= 2 && maxh >= 8 && maxh % 2 == 0 ? 2 : 1;
     a.nd = extra ? 16 : maxh / a.S;
     const int NW = a.nd;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;

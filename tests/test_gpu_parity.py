@@ -287,10 +287,11 @@ def test_spatial_matching_flat_kernel_bit_exact(dfe, cuda, K, H1, W1, mh, mw):
         old = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
         assert ctx.last_kernel() != "feat_matching_flat_kernel"
     assert torch.equal(old, out)
-    with ctx.options(fm_split=0):                                    # one block per tile instead of two half blocks
-        whole = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
-        assert ctx.last_kernel() == "feat_matching_flat_kernel"
-    assert torch.equal(whole, out)
+    for split in (0, 2, 4):                                          # one block per tile / two half blocks / four quarter blocks (16 rows only)
+        with ctx.options(fm_split=split):
+            other = dfe.nn.SpatialMatching(mh, mw, False).forward([t1, t2])
+            assert ctx.last_kernel() == "feat_matching_flat_kernel"
+        assert torch.equal(other, out), split
 
 
 @pytest.mark.parametrize("mh,mw", [(17, 17), (16, 16), (10, 16)])
