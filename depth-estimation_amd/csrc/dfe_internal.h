@@ -28,6 +28,7 @@ enum DfeOpt {
     DFE_OPT_DEBUG_ARENA,      // print where the scratch arena lands
     DFE_OPT_FM_FLAT,          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)
     DFE_OPT_FM_SPLIT,         // ... a tile's window rows dealt to two co-resident half blocks (0: one block per tile)
+    DFE_OPT_CONV_NARROW,      // batched convolution: 64 x 16 output tiles (0: 128 x 8; automatic: for kernels of 9 x 9 and larger)
     DFE_NOPT
 };
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };

@@ -103,12 +103,16 @@ struct ConvBatch {
     int blk0[2 * DFE_MAX_RATIOS + 1];   // first block of entry e (tiles x output groups each): the grid holds no idle blocks
     int n;
 };
-constexpr int CB_TW = 128, CB_TH = 8, CB_PX = 4;
+constexpr int CB_PX = 4;   // (tile: 128 x 8 or 64 x 16 outputs, 256 threads)
 extern __shared__ __attribute__((aligned(16))) float conv_smem[];
 
-template <int KW, int NT, bool TANH>
+// NARROW: tiles of 64 x 16 outputs (16 x 16 threads) instead of 128 x 8: less halo per output for large kernels (the launcher's
+// rule and the measurement behind it: launch_conv_batch).  Same strips, same order of operations per output: the results do not
+// depend on the shape.
+template <int KW, int NT, bool TANH, bool NARROW = false>
 __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, int nOut, int kH, int groups) {
 #pragma clang fp contract(off)
+    constexpr int CB_TW = NARROW ? 64 : 128, CB_TH = NARROW ? 16 : 8, TXN = CB_TW / CB_PX;
     constexpr int HALO = (KW - 1 + 3) / 4 * 4;             // halo columns, rounded so that rows stay 16-B aligned
     constexpr int PITCH = CB_TW + (HALO < 8 ? 8 : HALO);
     static_assert(PITCH <= 192, "three 64-lane passes stage a tile row");
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const int nrows = nIn * trows;
-        const int c0 = min(x0 + lane, W - 1), c1 = min(x0 + lane + 64, W - 1), c2 = min(x0 + min(lane + 128, PITCH - 1), W - 1);
+        const int c0 = min(x0 + lane, W - 1), c1 = min(x0 + min(lane + 64, PITCH - 1), W - 1), c2 = min(x0 + min(lane + 128, PITCH - 1), W - 1);
         for (int rr = wv; rr < nrows; rr += 8) {
             float v[2][3];
 #pragma unroll
@@ -137,21 +141,23 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
                 const int r2 = min(rr + 4 * j, nrows - 1);
                 const int i = r2 / trows, r = r2 - i * trows;
                 const float *src = in + ((long long)i * H + min(y0 + r, H - 1)) * W;
-                v[j][0] = src[c0]; v[j][1] = src[c1]; v[j][2] = src[c2];
+                v[j][0] = src[c0]; v[j][1] = src[c1];
+                v[j][2] = PITCH > 128 ? src[c2] : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r2 = rr + 4 * j;
                 if (r2 < nrows) {
                     float *dst = conv_smem + r2 * PITCH;
-                    dst[lane] = v[j][0]; dst[lane + 64] = v[j][1];
-                    if (lane + 128 < PITCH) dst[lane + 128] = v[j][2];
+                    dst[lane] = v[j][0];
+                    if (PITCH >= 128 || lane + 64 < PITCH) dst[lane + 64] = v[j][1];
+                    if (PITCH > 128 && lane + 128 < PITCH) dst[lane + 128] = v[j][2];
                 }
             }
         }
     }
     __syncthreads();
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
     const int o0 = grp * NT;
     // Two pixels per instruction: the multiply and the add of a tap are v_pk_mul_f32 / v_pk_add_f32 on pixel pairs (the weight is an
     // SGPR pair with op_sel broadcasting its low half) -- each element rounded exactly as the scalar multiply and add are, in the same
@@ -209,14 +215,21 @@ template <int KW, int NT>
 static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn, int nOut, int kH, int tanh_after, int maxblocks) {
     const int groups = nOut / NT;
     constexpr int halo = (KW - 1 + 3) / 4 * 4;
-    const size_t lds = (size_t)nIn * (CB_TH + kH - 1) * (CB_TW + (halo < 8 ? 8 : halo)) * sizeof(float);
+    // tile shape (option conv_narrow forces): 64 x 16 for large kernels -- 17 x 17 stages 2.5 values per output instead of 3.4 and
+    // version2's layer runs 0.594 -> 0.556 ms -- and 128 x 8 otherwise: at 5 x 5 the narrow tiles were 4 % SLOWER (VGA learned pyramid
+    // 0.182 -> 0.189 ms, 1080p 0.86 -> 0.89) although they waste 9 % of their area at 645 columns instead of 19 %: a wave then spans
+    // four tile rows and the block stages 20 rows per plane instead of 12 (profiles/r04_aq_conv_tile_shapes.txt).
+    const bool narrow = ctx->opt_bool(DFE_OPT_CONV_NARROW, KW >= 9 && kH >= 9);
+    const int TW = narrow ? 64 : 128, TH = narrow ? 16 : 8;
+    const size_t lds = (size_t)nIn * (TH + kH - 1) * (TW + (halo < 8 ? 8 : halo)) * sizeof(float);
     if (lds > 64 * 1024) return false;
-    auto kern = tanh_after ? conv_batch_kernel<KW, NT, true> : conv_batch_kernel<KW, NT, false>;
+    auto kern = narrow ? (tanh_after ? conv_batch_kernel<KW, NT, true, true> : conv_batch_kernel<KW, NT, false, true>)
+                       : (tanh_after ? conv_batch_kernel<KW, NT, true, false> : conv_batch_kernel<KW, NT, false, false>);
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
     ConvBatch c2 = cb;
     c2.n = n;
     c2.blk0[0] = 0;
-    for (int e = 0; e < n; ++e) c2.blk0[e + 1] = c2.blk0[e] + dfe_cdiv(cb.W[e] - KW + 1, CB_TW) * dfe_cdiv(cb.H[e] - kH + 1, CB_TH) * groups;
+    for (int e = 0; e < n; ++e) c2.blk0[e + 1] = c2.blk0[e] + dfe_cdiv(cb.W[e] - KW + 1, TW) * dfe_cdiv(cb.H[e] - kH + 1, TH) * groups;
     (void)maxblocks;
     hipLaunchKernelGGL(kern, dim3(c2.blk0[n]), dim3(256), lds, ctx->stream, c2, nIn, nOut, kH, groups);
     return true;
@@ -238,7 +251,7 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
             DFE_REQUIRE(ctx, in[e] && out[e] && L[e]->weight && H[e] >= L0.kH && W[e] >= L0.kW, DFE_E_SHAPE, "filter layer batch: entry %d: %dx%d kernel on %dx%d", e,
                         L0.kH, L0.kW, H[e], W[e]);
             cb.in[e] = in[e]; cb.out[e] = out[e]; cb.w[e] = L[e]->weight; cb.bias[e] = L[e]->bias; cb.H[e] = H[e]; cb.W[e] = W[e];
-            const int b = dfe_cdiv(W[e] - L0.kW + 1, CB_TW) * dfe_cdiv(H[e] - L0.kH + 1, CB_TH);
+            const int b = dfe_cdiv(W[e] - L0.kW + 1, 64) * dfe_cdiv(H[e] - L0.kH + 1, 8);
             if (b > maxblocks) maxblocks = b;
         }
         const int nt = L0.nOut % 8 == 0 ? 8 : (L0.nOut % 10 == 0 && ctx->opt[DFE_OPT_CONV_NT10] != 0) ? 10 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;

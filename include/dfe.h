@@ -78,7 +78,7 @@ int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* Behaviour switches of the launchers (tuning and tests; none is needed for correct results -- every choice has a parity test or is
  * a pure scheduling choice).  value >= 0 forces, -1 restores the launcher's own choice per shape.  Keys: "cascade_px", "fine_fuse",
  * "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10", "fm64", "fm_rows",
- * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
+ * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
  * (DFE_<KEY> variables of the tuning scripts) -- never inside an op, so an op's behaviour depends on its ctx only.
  * replaces: the option tables the reference's drivers pass down (opticalflow.lua:138-198 `geometry`), for the switches that have no
  * counterpart there.  Unknown key: DFE_E_ARG. */

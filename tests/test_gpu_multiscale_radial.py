@@ -426,6 +426,21 @@ def test_process_output_mean_extraction(dfe, cuda):
     assert np.all(full[:, :4] == 0)
 
 
+@pytest.mark.parametrize("nIn,nOut,kH,kW,H,W", [(4, 4, 5, 5, 37, 201), (3, 8, 3, 5, 20, 77), (4, 10, 5, 5, 23, 140), (3, 8, 17, 17, 40, 150), (2, 5, 7, 7, 19, 66)])
+def test_batched_convolution_tile_shapes_bit_exact(dfe, cuda, nIn, nOut, kH, kW, H, W):
+    """The LDS-tiled convolution (conv_batch_kernel) with its 128 x 8 and its 64 x 16 output tiles (option conv_narrow; the launcher
+    takes the narrow shape for kernels of 9 x 9 and larger): both bit-exact against the oracle's loop order on frames that end inside a tile."""
+    rng = np.random.default_rng(nIn * 100 + kW)
+    x = rng.standard_normal((nIn, H, W)).astype(np.float32)
+    conv = dfe.nn.SpatialConvolution(nIn, nOut, kW, kH, generator=torch.Generator().manual_seed(3))
+    ref = orc.spatial_convolution(x, conv.weight.cpu().numpy(), conv.bias.cpu().numpy())
+    ctx = dfe.get_ctx(0)
+    for narrow in (0, 1, -1):
+        with ctx.options(conv_narrow=narrow):
+            out = conv.forward(T(x, cuda))
+        assert np.array_equal(out.cpu().numpy(), ref), narrow
+
+
 def test_filter_stack_and_single_scale_model(dfe, cuda):
     """A15 / N1: nn.SpatialConvolution, nn.SpatialConvolutionMap, nn.Tanh against the oracle (bit-exact: same accumulation
     order), getFilter's layer rule, and getModel end to end: shared-weight filters -> SpatialMatching -> softmax(-cost)
