@@ -161,6 +161,9 @@ int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int 
 // ... of two frames of one size in the same two launches; out0 only the crop window cw x ch at (cx, cy) when cw > 0 (scratch: 4 * H * W floats)
 int dfe_contrastive_normalization_run2(dfe_ctx *ctx, const float *in0, const float *in1, int C, int H, int W, const float *kernel_host, int k,
                                        float threshold, float thresval, float *scratch, float *out0, float *out1, int cx, int cy, int cw, int ch);
+// the raw-patch pyramid on uint8 frames, converted inside its preparation kernels (multiscale.hip; f16_scale 0 = fp32 volumes)
+int dfe_multiscale_flow_pair_bytes(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                   const int *ratios, int nratios, float u8_scale, float f16_scale, float *flow, int64_t *idx);
 // nn.SpatialMatching on feature maps, fast kernels or the reference-order one (ssd_cost_volume.hip)
 int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 

@@ -165,11 +165,10 @@ int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *
     DFE_ENTER(ctx);
     DFE_REQUIRE(ctx, I0 && I1, DFE_E_ARG, "dfe_multiscale_flow_pair_u8: NULL frame");
     DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && scale > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_u8: C=%d %dx%d scale=%g", C, H, W, (double)scale);
-    float *f0 = nullptr, *f1 = nullptr;
-    int rc = ingest_pair(ctx, I0, I1, (long long)C * H * W, scale, &f0, &f1);
-    if (rc) return rc;
-    if (f16_scale != 0.f) return dfe_multiscale_flow_pair_f16(ctx, f0, f1, C, H, W, k, maxh, maxw, ratios, nratios, f16_scale, flow, idx);
-    return dfe_multiscale_flow_pair_f32(ctx, f0, f1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx);
+    DFE_REQUIRE(ctx, f16_scale >= 0.f && f16_scale < INFINITY, DFE_E_ARG, "dfe_multiscale_flow_pair_u8: f16_scale=%g", (double)f16_scale);
+    // no conversion pass: the pyramid's preparation kernels are the only readers of the frames and take the bytes as they are
+    // (float(byte) * scale at the load: the bits of dfe_u8_to_f32 followed by the fp32 entry)
+    return dfe_multiscale_flow_pair_bytes(ctx, I0, I1, C, H, W, k, maxh, maxw, ratios, nratios, scale, f16_scale, flow, idx);
 }
 
 }  // extern "C"

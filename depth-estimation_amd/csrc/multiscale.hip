@@ -25,13 +25,20 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for_ms(F
 // ---- nn.SpatialDownSampling(r,r): mean of r x r blocks (row-major accumulation, then * 1/(r*r)) ----
 // the r x r box of one output pixel, summed row-major like the generic loop; for the usual ratios every load is issued
 // before the first add (a run-time loop of load-add pairs makes the r = 4 scale a chain of 16 memory latencies)
-template <int R> __device__ __forceinline__ float box_sum(const float *__restrict__ src, int W) {
+// a frame pixel as the pipeline's fp32 value: fp32 frames as they are, uint8 frames as float(byte) * scale -- the expression of
+// u8_to_f32_kernel (ingest.hip), so the preparation kernels reading bytes give the bits of conversion pass + fp32 preparation
+__device__ __forceinline__ float px_ld(const float *__restrict__ p, long long i, float) { return p[i]; }
+__device__ __forceinline__ float px_ld(const unsigned char *__restrict__ p, long long i, float sc) {
+#pragma clang fp contract(off)
+    return (float)p[i] * sc;
+}
+template <int R, typename T = float> __device__ __forceinline__ float box_sum(const T *__restrict__ src, int W, float sc = 0.f) {
 #pragma clang fp contract(off)
     float t[R * R];
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < R; ++j) t[i * R + j] = src[(long long)i * W + j];
+        for (int j = 0; j < R; ++j) t[i * R + j] = px_ld(src, (long long)i * W + j, sc);
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < R * R; ++k) s = s + t[k];
@@ -73,8 +80,9 @@ __global__ void zero_pad_kernel(const float *__restrict__ img, int C, int H, int
 }
 
 // ---- down-sample by r (same arithmetic as downsample_box_kernel) and zero-pad, both frames, one launch ----
-__device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int r, int pl,
-                                                int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1) {
+template <typename T>
+__device__ __forceinline__ void prep_scale_body(const T *__restrict__ I0, const T *__restrict__ I1, int C, int H, int W, int r, int pl,
+                                                int pt, int Hp, int Wp, float *__restrict__ p0, float *__restrict__ p1, float sc) {
 #pragma clang fp contract(off)
     const int Hs = H / r, Ws = W / r;
     // 32-bit element indices (the launcher checks 2 * C * Hp * Wp < 2^31): with 64-bit div/mod per element this kernel
@@ -84,22 +92,22 @@ __device__ __forceinline__ void prep_scale_body(const float *__restrict__ I0, co
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * total; e += gridDim.x * blockDim.x) {
         const bool second = e >= total;
         const unsigned ee = second ? e - total : e;
-        const float *img = second ? I1 : I0;
+        const T *img = second ? I1 : I0;
         const unsigned t = ee / (unsigned)Wp;
         const int x = (int)(ee - t * (unsigned)Wp);
         const int c = (int)(t / (unsigned)Hp), y = (int)(t - (unsigned)c * Hp);
         const int sy = y - pt, sx = x - pl;
         float v = 0.f;
         if (sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
-            const float *src = img + ((long long)c * H + sy * r) * W + sx * r;
+            const T *src = img + ((long long)c * H + sy * r) * W + sx * r;
             float s = 0.f;
-            if (r == 1) s = 0.f + src[0];
-            else if (r == 2) s = box_sum<2>(src, W);
-            else if (r == 4) s = box_sum<4>(src, W);
-            else if (r == 8) s = box_sum<8>(src, W);
+            if (r == 1) s = 0.f + px_ld(src, 0, sc);
+            else if (r == 2) s = box_sum<2, T>(src, W, sc);
+            else if (r == 4) s = box_sum<4, T>(src, W, sc);
+            else if (r == 8) s = box_sum<8, T>(src, W, sc);
             else {
                 for (int i = 0; i < r; ++i)
-                    for (int j = 0; j < r; ++j) s = s + src[(long long)i * W + j];
+                    for (int j = 0; j < r; ++j) s = s + px_ld(src, (long long)i * W + j, sc);
             }
             v = r > 1 ? s * inv : s;
         }
@@ -111,9 +119,10 @@ struct PrepScales {
     int r[DFE_MAX_RATIOS], Hp[DFE_MAX_RATIOS], Wp[DFE_MAX_RATIOS];
     float *p0[DFE_MAX_RATIOS], *p1[DFE_MAX_RATIOS];
 };
-__global__ void prep_scales_kernel(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int pl, int pt, PrepScales ps) {
+template <typename T>
+__global__ void prep_scales_kernel(const T *__restrict__ I0, const T *__restrict__ I1, int C, int H, int W, int pl, int pt, PrepScales ps, float sc) {
     const int s = blockIdx.y;
-    prep_scale_body(I0, I1, C, H, W, ps.r[s], pl, pt, ps.Hp[s], ps.Wp[s], ps.p0[s], ps.p1[s]);
+    prep_scale_body<T>(I0, I1, C, H, W, ps.r[s], pl, pt, ps.Hp[s], ps.Wp[s], ps.p0[s], ps.p1[s], sc);
 }
 
 // ---- every scale of both frames from ONE read of the frames (ratios 1, 2, 4, 8, 16) ---------------------------------------------
@@ -128,12 +137,13 @@ struct PrepTile {
     int ns;
 };
 constexpr int PT = 64;
-__global__ __launch_bounds__(256) void prep_tiles_kernel(const float *__restrict__ I0, const float *__restrict__ I1, int C, int H, int W, int pl, int pt,
-                                                        PrepTile ps) {
+template <typename T>
+__global__ __launch_bounds__(256) void prep_tiles_kernel(const T *__restrict__ I0, const T *__restrict__ I1, int C, int H, int W, int pl, int pt,
+                                                        PrepTile ps, float sc) {
 #pragma clang fp contract(off)
     __shared__ float tile[PT][PT + 1];
     const int f = blockIdx.z / C, c = blockIdx.z - f * C;
-    const float *__restrict__ img = (f ? I1 : I0) + (long long)c * H * W;
+    const T *__restrict__ img = (f ? I1 : I0) + (long long)c * H * W;
     const int x0 = blockIdx.x * PT, y0 = blockIdx.y * PT;
     const int tw = min(PT, W - x0), th = min(PT, H - y0);
     {
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256) void prep_tiles_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                    // 16 rows of 64 per pass: all loads in flight before the LDS writes
             const int e = i * 256 + threadIdx.x, yy = e >> 6, xx = e & 63;
-            v[i] = img[(long long)min(y0 + yy, H - 1) * W + min(x0 + xx, W - 1)];
+            v[i] = px_ld(img, (long long)min(y0 + yy, H - 1) * W + min(x0 + xx, W - 1), sc);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -983,8 +993,10 @@ int dfe_pyramid_scale_volume_f32(dfe_ctx *ctx, const float *I0, const float *I1,
 // f16_scale != 0: every scale's volume is stored as half(cost * f16_scale) (dfe_multiscale_flow_pair_f16)
 // the learned patch filters of the matcher (NULL = raw patches, the identity filter): layers [share ? 1 : nratios][nlayers]
 struct MsFilter { const dfe_filter_layer *layers; int nlayers, share; };
+// u8_scale > 0: I0 / I1 point to uint8 frames (raw-patch pyramid only: the preparation kernels, the frames' only readers, convert)
 static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw,
-                                const int *ratios, int nratios, float *flow, int64_t *idx, float f16_scale, const MsFilter *filt = nullptr) {
+                                const int *ratios, int nratios, float *flow, int64_t *idx, float f16_scale, const MsFilter *filt = nullptr,
+                                float u8_scale = 0.f) {
     DFE_REQUIRE(ctx, I0 && I1 && (flow || idx), DFE_E_ARG, "dfe_multiscale_flow_pair_f32: NULL tensor");
     DFE_REQUIRE(ctx, C > 0 && k > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_multiscale_flow_pair_f32: bad size");
     CascadeGeom g;
@@ -1029,10 +1041,10 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     rc = dfe_scratch(ctx, total, &scr);
     if (rc) return rc;
     // the same call again (same buffers, shapes and arena): replay its launches as a graph
-    struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; float f16; } gkey;
+    struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; float f16, u8; } gkey;
     memset(&gkey, 0, sizeof gkey);
     gkey.I0 = I0; gkey.I1 = I1; gkey.flow = flow; gkey.idx = idx; gkey.scr = scr;
-    gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios; gkey.f16 = f16_scale;
+    gkey.C = C; gkey.H = H; gkey.W = W; gkey.k = k; gkey.maxh = maxh; gkey.maxw = maxw; gkey.nratios = nratios; gkey.f16 = f16_scale; gkey.u8 = u8_scale;
     for (int s = 0; s < nratios; ++s) gkey.ratios[s] = ratios[s];
     const int gmode = filt ? 0 : dfe_graph_lookup(ctx, ctx->ms_graph, &gkey, sizeof gkey);
     if (gmode == 2) {
@@ -1109,9 +1121,17 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
             PrepTile pq;
             pq.ns = nratios;
             for (int s = 0; s < nratios; ++s) { pq.r[s] = ps.r[s]; pq.Hp[s] = ps.Hp[s]; pq.Wp[s] = ps.Wp[s]; pq.p[0][s] = ps.p0[s]; pq.p[1][s] = ps.p1[s]; }
-            hipLaunchKernelGGL(prep_tiles_kernel, dim3(dfe_cdiv(W, PT), dfe_cdiv(H, PT), 2 * C), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, pq);
+            if (u8_scale > 0.f)
+                hipLaunchKernelGGL(prep_tiles_kernel<unsigned char>, dim3(dfe_cdiv(W, PT), dfe_cdiv(H, PT), 2 * C), dim3(256), 0, ctx->stream,
+                                   (const unsigned char *)I0, (const unsigned char *)I1, C, H, W, pl, pt, pq, u8_scale);
+            else
+                hipLaunchKernelGGL(prep_tiles_kernel<float>, dim3(dfe_cdiv(W, PT), dfe_cdiv(H, PT), 2 * C), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, pq, 0.f);
         } else {
-            hipLaunchKernelGGL(prep_scales_kernel, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps);
+            if (u8_scale > 0.f)
+                hipLaunchKernelGGL(prep_scales_kernel<unsigned char>, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream,
+                                   (const unsigned char *)I0, (const unsigned char *)I1, C, H, W, pl, pt, ps, u8_scale);
+            else
+                hipLaunchKernelGGL(prep_scales_kernel<float>, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps, 0.f);
         }
         DFE_LAUNCH_CHECK(ctx);
     }
@@ -1495,3 +1515,9 @@ int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, co
 }
 
 }  // extern "C"
+
+// uint8 frames straight into the preparation kernels (dfe_multiscale_flow_pair_u8, ingest.hip); f16_scale as in the _f16 entry, 0 = fp32 volumes
+int dfe_multiscale_flow_pair_bytes(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
+                                   const int *ratios, int nratios, float u8_scale, float f16_scale, float *flow, int64_t *idx) {
+    return multiscale_flow_pair(ctx, (const float *)I0, (const float *)I1, C, H, W, k, maxh, maxw, ratios, nratios, flow, idx, f16_scale, nullptr, u8_scale);
+}

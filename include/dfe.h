@@ -455,7 +455,9 @@ int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val
 int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int hWin, int wWin,
                            float foe_x, float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth,
                            float *depth_conf);
-/* dfe_multiscale_flow_pair_f32 (f16_scale == 0) or dfe_multiscale_flow_pair_f16 (f16_scale != 0: its `scale`) on uint8 frames. */
+/* dfe_multiscale_flow_pair_f32 (f16_scale == 0) or dfe_multiscale_flow_pair_f16 (f16_scale > 0: its `scale`) on uint8 frames: no
+ * conversion pass -- the pyramid's preparation kernels, the only readers of the frames, take the bytes as they are (float(byte) * scale
+ * at the load), so the results are bit-identical to the fp32 entries on the converted frames. */
 int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
                                 const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx);
 

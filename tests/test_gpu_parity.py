@@ -1230,6 +1230,39 @@ def test_uint8_frames_equal_the_fp32_entries(dfe, cuda):
     assert torch.equal(res[2][0], res[3][0]) and torch.equal(res[2][1], res[3][1])
 
 
+def test_uint8_pyramid_large_frame_equals_fp32_entry(dfe, cuda):
+    """dfe_multiscale_flow_pair_u8 where every scale is made from ONE read of the frames (prep_tiles_kernel, frames of 1.5 MP and more): the
+    bytes go into the preparation kernel as they are -- float(byte) * scale at the load -- and the result is that of the fp32 entry on the
+    converted frames, bit for bit, with a scale that is not a power of two."""
+    from depth_estimation_amd._lib import ratios_array
+
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    rng = np.random.default_rng(21)
+    H, W = 1024, 1536
+    u0 = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    u1 = np.roll(u0, (2, -3), axis=(1, 2))
+    t0, t1 = torch.from_numpy(u0).to(cuda), torch.from_numpy(u1).to(cuda)
+    scale = 1.0 / 255.0
+    f0, f1 = torch.empty((3, H, W), device=cuda), torch.empty((3, H, W), device=cuda)
+    ctx.check(lib.dfe_u8_to_f32(ctx.handle, t0.data_ptr(), t0.numel(), scale, f0.data_ptr()))
+    ctx.check(lib.dfe_u8_to_f32(ctx.handle, t1.data_ptr(), t1.numel(), scale, f1.data_ptr()))
+    rr, n = ratios_array([1, 2, 4, 8])
+    res = []
+    for which in ("f32", "u8"):
+        flow = torch.empty((2, H, W), device=cuda)
+        idx = torch.empty((H, W), dtype=torch.int64, device=cuda)
+        if which == "f32":
+            ctx.check(lib.dfe_multiscale_flow_pair_f32(ctx.handle, f0.data_ptr(), f1.data_ptr(), 3, H, W, 7, 8, 8, rr, n, flow.data_ptr(), idx.data_ptr()))
+        else:
+            ctx.check(lib.dfe_multiscale_flow_pair_u8(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 8, 8, rr, n, scale, 0.0, flow.data_ptr(), idx.data_ptr()))
+        res.append((flow, idx))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # the planted shift is found in the interior
+    fl = res[1][0].cpu().numpy()
+    assert (fl[0, 100:-100, 100:-100] == 2).mean() > 0.9 and (fl[1, 100:-100, 100:-100] == -3).mean() > 0.9
+
+
 def test_time_matching_lua_exact_shape(dfe, cuda):
     """tests/time_matching.lua:5-47 at its own shape: getFilter({3,5,5,4},{4,5,5,4},{4,5,5,10}) on randn 3 x 180 x 320 frames, the narrow of
     prepareInput, nn.SpatialMatching(16, 16) on the 10-plane 168 x 308 features (output 153 x 293 x 16 x 16) and the script's min over
