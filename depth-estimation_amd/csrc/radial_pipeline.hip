@@ -93,9 +93,17 @@ __global__ __launch_bounds__(256) void polar_warp_pair_kernel(const float *__res
                                                              int wdst, int hdst, int Wp, int lpad, float xc, float yc, const float *__restrict__ rt,
                                                              const double *__restrict__ sn, const double *__restrict__ cs, float *__restrict__ o0,
                                                              float *__restrict__ o1) {
+    // A block = a patch of 8 radii x 32 angles of the polar image: its 1024 taps fall into a compact piece of the frame (an arc of ~50
+    // pixels, 8 deep: ~60 cache lines), where 256 consecutive angles of ONE radius -- the first version -- ran along 400 pixels of a
+    // circle, nearly every tap its own line (176 MB gathered for 45 MB written, 76 % of the wave-cycles waiting: profiles/r04_af).  The
+    // stores stay whole 128-B lines (32 angles of a row).
     const long long total = (long long)hdst * Wp, HW = (long long)H * W;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(e / Wp), jp = (int)(e - (long long)i * Wp);
+    const int npx = (Wp + 31) >> 5;
+    {
+        const int pb = blockIdx.x, pi = pb / npx, pj = pb - pi * npx;
+        const int i = pi * 8 + (int)(threadIdx.x >> 5), jp = pj * 32 + (int)(threadIdx.x & 31);
+        if (i >= hdst || jp >= Wp) return;
+        const long long e = (long long)i * Wp + jp;
         int j = jp - lpad;
         j = j < 0 ? j + wdst : (j >= wdst ? j - wdst : j);
         const float r = rt[i];
@@ -170,6 +178,54 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const float *__restrict_
     }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) out[((long long)o * H + y) * Wo + x] = TANH ? tanhf(acc[o]) : acc[o];
+}
+
+// The same sums for TWO image rows per thread (KW taps unrolled): the multiply and the add of a tap are v_pk_mul_f32 / v_pk_add_f32 on
+// the row pair (the weight an SGPR pair with its low half broadcast), each element rounded as the scalar operations are, in the same
+// order -- same results.  With one row per thread every operation had a scalar operand (the VALU's slow path, 0.9 per cycle and CU:
+// DESIGN 4.6) and conv_rows_kernel<5, false, 17> ran at 46 % of the rate its 255 multiply-adds per pixel allow; the tile holds the two
+// rows interleaved ([plane][column][2]), so a tap's operand pair is one aligned 8-B piece of an LDS read.
+template <int NOUT, bool TANH, int KW>
+__global__ __launch_bounds__(256) void conv_rows_pk_kernel(const float *__restrict__ in, const float *__restrict__ w, const float *__restrict__ bias,
+                                                          int nIn, int H, int W, float *__restrict__ out) {
+#pragma clang fp contract(off)
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [nIn][TW][2]
+    constexpr int TW = 256 + KW - 1 + ((256 + KW - 1) & 1);        // (even: 16-B alignment of the planes)
+    const int Wo = W - KW + 1;
+    const int y = 2 * blockIdx.y, y1 = min(y + 1, H - 1), x0 = blockIdx.x * 256, tx = threadIdx.x;
+    for (int i = 0; i < nIn; ++i)
+        for (int s = tx; s < TW; s += 256) {
+            const int x = x0 + s;
+            const float a = x < W ? in[((long long)i * H + y) * W + x] : 0.f, b = x < W ? in[((long long)i * H + y1) * W + x] : 0.f;
+            *reinterpret_cast<f2 *>(tile + ((long long)i * TW + s) * 2) = f2{a, b};
+        }
+    __syncthreads();
+    const int x = x0 + tx;
+    if (x >= Wo) return;
+    f2 acc[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) { const float b = bias ? bias[o] : 0.f; acc[o] = f2{b, b}; }
+    for (int i = 0; i < nIn; ++i) {
+        f2 a[KW];
+#pragma unroll
+        for (int v = 0; v < KW; ++v) a[v] = *reinterpret_cast<const f2 *>(tile + ((long long)i * TW + tx + v) * 2);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float wv[KW];
+            load_uniform<KW>(w + ((long long)o * nIn + i) * KW, wv);
+#pragma unroll
+            for (int v = 0; v < KW; ++v) {
+                const f2 w2 = f2{wv[v], wv[v]};
+                acc[o] = acc[o] + w2 * a[v];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        out[((long long)o * H + y) * Wo + x] = TANH ? tanhf(acc[o][0]) : acc[o][0];
+        if (y + 1 < H) out[((long long)o * H + y + 1) * Wo + x] = TANH ? tanhf(acc[o][1]) : acc[o][1];
+    }
 }
 
 // out[o][y][x] = bias[o] + sum_i sum_u w[o][i][u] * in[i][y+u][x]   (kW = 1); RY output rows per thread
@@ -307,8 +363,10 @@ int launch_conv_rows(dfe_ctx *ctx, const float *in, const float *w, const float 
     const size_t lds = (size_t)nIn * (256 + kW - 1) * sizeof(float);
     dim3 grid(dfe_cdiv(Wo, 256), H);
     if (kW == 17) {
-        if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true, 17>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
-        else hipLaunchKernelGGL((conv_rows_kernel<NOUT, false, 17>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
+        const dim3 grid2(dfe_cdiv(Wo, 256), dfe_cdiv(H, 2));
+        const size_t lds2 = (size_t)nIn * (256 + 17 - 1) * 2 * sizeof(float);
+        if (tanh_after) hipLaunchKernelGGL((conv_rows_pk_kernel<NOUT, true, 17>), grid2, dim3(256), lds2, ctx->stream, in, w, b, nIn, H, W, out);
+        else hipLaunchKernelGGL((conv_rows_pk_kernel<NOUT, false, 17>), grid2, dim3(256), lds2, ctx->stream, in, w, b, nIn, H, W, out);
     } else if (tanh_after) hipLaunchKernelGGL((conv_rows_kernel<NOUT, true>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
     else hipLaunchKernelGGL((conv_rows_kernel<NOUT, false>), grid, dim3(256), lds, ctx->stream, in, w, b, nIn, H, W, kW, out);
     DFE_LAUNCH_CHECK(ctx);
@@ -404,7 +462,7 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
     const size_t f2_b = ((size_t)p->n2 * Hf2 * W * 4 + 255) / 256 * 256, f1_b = f2_b;
     const size_t pf_b = ((size_t)hm * W * 4 + 255) / 256 * 256;
     const size_t tab_b = ((size_t)H * 4 + 255) / 256 * 256 + 2 * (((size_t)W * 8 + 255) / 256 * 256);
-    const bool il = p->C <= 4;
+    const bool il = p->C <= 4;   // (planar taps measured with the patch mapping too: 0.194 against 0.185 ms at 720p)
     const size_t il_b = il ? ((size_t)p->hImg * p->wImg * 16 + 255) / 256 * 256 : 0;
     void *scr = nullptr;
     int rc = dfe_scratch(ctx, 2 * polar_b + tmp_b + f1_b + f2_b + pf_b + tab_b + 2 * il_b, &scr);
@@ -426,10 +484,10 @@ int dfe_radial_flow_depth_pair_f32(dfe_ctx *ctx, const dfe_radial_params *p, con
             float4 *i0 = (float4 *)(tb + tab_b), *i1 = (float4 *)(tb + tab_b + il_b);
             hipLaunchKernelGGL(interleave_pair_kernel, dim3(grid1d((long long)p->hImg * p->wImg)), dim3(256), 0, ctx->stream, prev, cur, p->C,
                                (long long)p->hImg * p->wImg, i0, i1);
-            hipLaunchKernelGGL(polar_warp_pair_kernel<true>, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, (const float *)i0,
+            hipLaunchKernelGGL(polar_warp_pair_kernel<true>, dim3(dfe_cdiv(H, 8) * dfe_cdiv(Wp, 32)), dim3(256), 0, ctx->stream, (const float *)i0,
                                (const float *)i1, p->C, p->hImg, p->wImg, W, H, Wp, lpad, (float)e2x, (float)e2y, rt, sn, cs, pol0, pol1);
         } else {
-            hipLaunchKernelGGL(polar_warp_pair_kernel<false>, dim3(grid1d((long long)H * Wp)), dim3(256), 0, ctx->stream, prev, cur, p->C, p->hImg,
+            hipLaunchKernelGGL(polar_warp_pair_kernel<false>, dim3(dfe_cdiv(H, 8) * dfe_cdiv(Wp, 32)), dim3(256), 0, ctx->stream, prev, cur, p->C, p->hImg,
                                p->wImg, W, H, Wp, lpad, (float)e2x, (float)e2y, rt, sn, cs, pol0, pol1);
         }
         DFE_LAUNCH_CHECK(ctx);
