@@ -109,6 +109,15 @@ extern __shared__ __attribute__((aligned(16))) float conv_smem[];
 // NARROW: tiles of 64 x 16 outputs (16 x 16 threads) instead of 128 x 8: less halo per output for large kernels (the launcher's
 // rule and the measurement behind it: launch_conv_batch).  Same strips, same order of operations per output: the results do not
 // depend on the shape.
+// One LDS-DMA load of 64 floats: lane l fetches the float at sbase + voff (bytes) into LDS at lds_dst + 4 l (M0 = the destination base,
+// saved and restored around the instruction: cdna_hip_programming.md, LDS-DMA recipe).
+__device__ __forceinline__ void cb_glds4(unsigned voff, const void *sbase, const float *lds_dst) {
+    const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
+}
+
 template <int KW, int NT, bool TANH, bool NARROW = false>
 __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, int nOut, int kH, int groups) {
 #pragma clang fp contract(off)
@@ -116,98 +125,103 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
     constexpr int HALO = (KW - 1 + 3) / 4 * 4;             // halo columns, rounded so that rows stay 16-B aligned
     constexpr int PITCH = CB_TW + (HALO < 8 ? 8 : HALO);
     static_assert(PITCH <= 192, "three 64-lane passes stage a tile row");
-    int ent = 0;
-    while (ent + 1 < cb.n && (int)blockIdx.x >= cb.blk0[ent + 1]) ++ent;       // (block-uniform; at most 10 entries)
-    const int H = cb.H[ent], W = cb.W[ent];
-    const int Ho = H - kH + 1, Wo = W - KW + 1;
-    const int tilesx = (Wo + CB_TW - 1) / CB_TW;
-    const int rel = blockIdx.x - cb.blk0[ent], grp = rel % groups, tile = rel / groups;   // (the groups of a tile next to each other: they stage the same input)
-    const int by = tile / tilesx, bx = tile - by * tilesx;
-    const int x0 = bx * CB_TW, y0 = by * CB_TH;
-    const int trows = CB_TH + kH - 1;
-    const float *__restrict__ in = cb.in[ent];
-    // stage: every input plane's tile (clamped at the frame edge: those values only feed outputs that are not stored).  A wave takes
-    // whole tile rows (row = wave, wave + 4, ...: the plane / row split is scalar arithmetic), its lanes the row's 136 columns in three
-    // passes, and all of a wave's loads for two rows are in flight before the first LDS write.  (The first version dealt single
-    // elements to threads: two integer divisions per element cost as many instructions as the convolution itself.)
-    {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int nrows = nIn * trows;
-        const int c0 = min(x0 + lane, W - 1), c1 = min(x0 + min(lane + 64, PITCH - 1), W - 1), c2 = min(x0 + min(lane + 128, PITCH - 1), W - 1);
-        for (int rr = wv; rr < nrows; rr += 8) {
-            float v[2][3];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r2 = min(rr + 4 * j, nrows - 1);
-                const int i = r2 / trows, r = r2 - i * trows;
-                const float *src = in + ((long long)i * H + min(y0 + r, H - 1)) * W;
-                v[j][0] = src[c0]; v[j][1] = src[c1];
-                v[j][2] = PITCH > 128 ? src[c2] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r2 = rr + 4 * j;
-                if (r2 < nrows) {
-                    float *dst = conv_smem + r2 * PITCH;
-                    dst[lane] = v[j][0];
-                    if (PITCH >= 128 || lane + 64 < PITCH) dst[lane + 64] = v[j][1];
-                    if (PITCH > 128 && lane + 128 < PITCH) dst[lane + 128] = v[j][2];
-                }
-            }
+    const int trows = CB_TH + kH - 1, nrows = nIn * trows;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    struct Loc { int ent, grp, tile, x0, y0, H, W; };
+    auto locate = [&](int idx) {
+        Loc L;
+        L.ent = 0;
+        while (L.ent + 1 < cb.n && idx >= cb.blk0[L.ent + 1]) ++L.ent;         // (block-uniform; at most 10 entries)
+        L.H = cb.H[L.ent]; L.W = cb.W[L.ent];
+        const int tilesx = (L.W - KW + 1 + CB_TW - 1) / CB_TW;
+        const int rel = idx - cb.blk0[L.ent];
+        L.grp = rel % groups; L.tile = rel / groups;                           // (the groups of a tile next to each other: they share its input)
+        const int by = L.tile / tilesx, bx = L.tile - by * tilesx;
+        L.x0 = bx * CB_TW; L.y0 = by * CB_TH;
+        return L;
+    };
+    // stage: every input plane's tile (clamped at the frame edge: those values only feed outputs that are not stored), by LDS-DMA -- a
+    // wave takes whole tile rows (row = wave, wave + 4, ...), its lanes the row's columns in up to three requests, all in flight at once.
+    // (Before: through registers, two rows' loads in flight before the first LDS write -- VGA learned pyramid 0.181 -> 0.175 ms, version2
+    //  0.789 -> 0.767.  The very first version dealt single elements to threads: two integer divisions per element cost as many
+    //  instructions as the convolution itself.)
+    auto stage = [&](const Loc &L, float *buf) {
+        const float *__restrict__ in = cb.in[L.ent];
+        const unsigned c0 = 4u * (unsigned)min(L.x0 + lane, L.W - 1), c1 = 4u * (unsigned)min(L.x0 + min(lane + 64, PITCH - 1), L.W - 1),
+                       c2 = 4u * (unsigned)min(L.x0 + min(lane + 128, PITCH - 1), L.W - 1);
+        for (int rr = wv; rr < nrows; rr += 4) {
+            const int i = rr / trows, r = rr - i * trows;
+            const float *src = in + ((long long)i * L.H + min(L.y0 + r, L.H - 1)) * L.W;
+            float *dst = buf + rr * PITCH;
+            cb_glds4(c0, src, dst);
+            if (PITCH >= 128 || lane + 64 < PITCH) cb_glds4(c1, src, dst + 64);
+            if (PITCH > 128 && lane + 128 < PITCH) cb_glds4(c2, src, dst + 128);
         }
-    }
+    };
+    // (Tried: blocks that work through 2 or 4 consecutive (tile, output group) items, the next item's tile requested into a second LDS
+    //  buffer before the arithmetic of the current one -- with one item per block the 982 blocks of a VGA pyramid layer are all resident
+    //  at once and run load, arithmetic and store in lockstep.  Slower everywhere: VGA learned pyramid 0.175 -> 0.196 (2) / 0.244 (4),
+    //  version2 0.767 -> 1.225 / 1.54 ms: half / a quarter of the waves per CU hide less than the prefetch does.
+    //  profiles/r04_at_conv_items_per_block.txt)
+    const Loc L = locate(blockIdx.x);
+    const float *cur = conv_smem;
+    stage(L, conv_smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
-    const int o0 = grp * NT;
-    // Two pixels per instruction: the multiply and the add of a tap are v_pk_mul_f32 / v_pk_add_f32 on pixel pairs (the weight is an
-    // SGPR pair with op_sel broadcasting its low half) -- each element rounded exactly as the scalar multiply and add are, in the same
-    // order, so the results do not change; the odd taps' pixel pairs (v[k], v[k+1] with k odd: not an aligned register pair) are
-    // copies made once per input row and shared by every output plane.  The scalar form issued every operation on the VALU's slow
-    // path (SGPR operand: 0.9 per cycle and CU); this one issues half as many.
-    static_assert(CB_PX == 4, "two pixel pairs per thread");
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 acc[NT][2];
+    {
+        const int o0 = L.grp * NT;
+        // Two pixels per instruction: the multiply and the add of a tap are v_pk_mul_f32 / v_pk_add_f32 on pixel pairs (the weight is an
+        // SGPR pair with op_sel broadcasting its low half) -- each element rounded exactly as the scalar multiply and add are, in the same
+        // order, so the results do not change; the odd taps' pixel pairs (v[k], v[k+1] with k odd: not an aligned register pair) are
+        // copies made once per input row and shared by every output plane.  The scalar form issued every operation on the VALU's slow
+        // path (SGPR operand: 0.9 per cycle and CU); this one issues half as many.
+        static_assert(CB_PX == 4, "two pixel pairs per thread");
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 acc[NT][2];
 #pragma unroll
-    for (int o = 0; o < NT; ++o) {
-        const float b = cb.bias[ent] ? cb.bias[ent][o0 + o] : 0.f;
-        acc[o][0] = f2{b, b};
-        acc[o][1] = f2{b, b};
-    }
-    const float *__restrict__ w = cb.w[ent];
-    for (int i = 0; i < nIn; ++i)
-        for (int u = 0; u < kH; ++u) {
-            const float4 *row = reinterpret_cast<const float4 *>(conv_smem + (i * trows + ty + u) * PITCH + CB_PX * tx);
-            constexpr int NV4 = (CB_PX + KW - 1 + 3) / 4;                                  // 16-B pieces of the tile row this strip reads
-            float v[4 * NV4];
+        for (int o = 0; o < NT; ++o) {
+            const float b = cb.bias[L.ent] ? cb.bias[L.ent][o0 + o] : 0.f;
+            acc[o][0] = f2{b, b};
+            acc[o][1] = f2{b, b};
+        }
+        const float *__restrict__ w = cb.w[L.ent];
+        for (int i = 0; i < nIn; ++i)
+            for (int u = 0; u < kH; ++u) {
+                const float4 *row = reinterpret_cast<const float4 *>(cur + (i * trows + ty + u) * PITCH + CB_PX * tx);
+                constexpr int NV4 = (CB_PX + KW - 1 + 3) / 4;                                  // 16-B pieces of the tile row this strip reads
+                float v[4 * NV4];
 #pragma unroll
-            for (int j = 0; j < NV4; ++j) { const float4 t = row[j]; v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w; }
-            f2 pr[KW][2];
+                for (int j = 0; j < NV4; ++j) { const float4 tt = row[j]; v[4 * j] = tt.x; v[4 * j + 1] = tt.y; v[4 * j + 2] = tt.z; v[4 * j + 3] = tt.w; }
+                f2 pr[KW][2];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) { pr[k][0] = f2{v[k], v[k + 1]}; pr[k][1] = f2{v[k + 2], v[k + 3]}; }
+                for (int k = 0; k < KW; ++k) { pr[k][0] = f2{v[k], v[k + 1]}; pr[k][1] = f2{v[k + 2], v[k + 3]}; }
 #pragma unroll
-            for (int o = 0; o < NT; ++o) {
-                typedef const float __attribute__((address_space(4))) *cfp;               // constant address space: the backend selects SMEM
-                const cfp wr = (cfp)(w + (((long long)(o0 + o) * nIn + i) * kH + u) * KW);   // (the index is wave-uniform)
+                for (int o = 0; o < NT; ++o) {
+                    typedef const float __attribute__((address_space(4))) *cfp;               // constant address space: the backend selects SMEM
+                    const cfp wr = (cfp)(w + (((long long)(o0 + o) * nIn + i) * kH + u) * KW);   // (the index is wave-uniform)
 #pragma unroll
-                for (int k = 0; k < KW; ++k) {
-                    const float wk = wr[k];
-                    const f2 w2 = f2{wk, wk};
-                    acc[o][0] = acc[o][0] + w2 * pr[k][0];
-                    acc[o][1] = acc[o][1] + w2 * pr[k][1];
+                    for (int k = 0; k < KW; ++k) {
+                        const float wk = wr[k];
+                        const f2 w2 = f2{wk, wk};
+                        acc[o][0] = acc[o][0] + w2 * pr[k][0];
+                        acc[o][1] = acc[o][1] + w2 * pr[k][1];
+                    }
                 }
             }
+        const int Ho = L.H - kH + 1, Wo = L.W - KW + 1;
+        const int y = L.y0 + ty;
+        if (y < Ho) {
+            float *__restrict__ out = cb.out[L.ent];
+#pragma unroll
+            for (int o = 0; o < NT; ++o)
+#pragma unroll
+                for (int q = 0; q < CB_PX; ++q) {
+                    const int x = L.x0 + CB_PX * tx + q;
+                    const float a = acc[o][q >> 1][q & 1];
+                    if (x < Wo) out[((long long)(o0 + o) * Ho + y) * Wo + x] = TANH ? tanhf(a) : a;
+                }
         }
-    const int y = y0 + ty;
-    if (y < Ho) {
-        float *__restrict__ out = cb.out[ent];
-#pragma unroll
-        for (int o = 0; o < NT; ++o)
-#pragma unroll
-            for (int q = 0; q < CB_PX; ++q) {
-                const int x = x0 + CB_PX * tx + q;
-                const float a = acc[o][q >> 1][q & 1];
-                if (x < Wo) out[((long long)(o0 + o) * Ho + y) * Wo + x] = TANH ? tanhf(a) : a;
-            }
     }
 }
 
@@ -254,7 +268,20 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
             const int b = dfe_cdiv(W[e] - L0.kW + 1, 64) * dfe_cdiv(H[e] - L0.kH + 1, 8);
             if (b > maxblocks) maxblocks = b;
         }
-        const int nt = L0.nOut % 8 == 0 ? 8 : (L0.nOut % 10 == 0 && ctx->opt[DFE_OPT_CONV_NT10] != 0) ? 10 : L0.nOut % 5 == 0 ? 5 : L0.nOut % 4 == 0 ? 4 : 0;
+        // output planes per thread: the most that still leaves two blocks per CU (a 320 x 180 frame is 66 tiles: with all of a layer's
+        // planes in one block most of the chip idles -- tests/time_matching.lua's filter 0.131 -> 0.105 ms with 2 planes per thread)
+        long long tiles = 0;
+        const bool narrow_k = L0.kW >= 9 && L0.kH >= 9;
+        for (int e = 0; e < n; ++e) tiles += (long long)dfe_cdiv(W[e] - L0.kW + 1, narrow_k ? 64 : 128) * dfe_cdiv(H[e] - L0.kH + 1, narrow_k ? 16 : 8);
+        const int cand[6] = {10, 8, 5, 4, 2, 1};
+        int nt = 0;
+        for (int c = 0; c < 6; ++c) {
+            if (L0.nOut % cand[c]) continue;
+            if (cand[c] == 10 && ctx->opt[DFE_OPT_CONV_NT10] == 0) continue;
+            if (L0.kW == 17 && (cand[c] == 10 || cand[c] == 5 || cand[c] == 1)) continue;     // (instantiated for 17 x 17: 8, 4, 2)
+            nt = cand[c];
+            if (tiles * (L0.nOut / nt) >= 2ll * ctx->ncu) break;
+        }
         bool done = false;
 #define DFE_CB(KWV)                                                                                                                       \
     if (L0.kW == KWV) {                                                                                                                   \
@@ -262,9 +289,15 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
         else if (nt == 10) done = launch_conv_batch<KWV, 10>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);               \
         else if (nt == 5) done = launch_conv_batch<KWV, 5>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
         else if (nt == 4) done = launch_conv_batch<KWV, 4>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
+        else if (nt == 2) done = launch_conv_batch<KWV, 2>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
+        else if (nt == 1) done = launch_conv_batch<KWV, 1>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);                 \
     }
         if (ok && nt) { DFE_CB(3) DFE_CB(5) DFE_CB(7) }
-        if (ok && nt == 8 && L0.kW == 17) done = launch_conv_batch<17, 8>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);   // version2/network.lua's 17 x 17 x 32
+        if (ok && L0.kW == 17) {                                                                                   // version2/network.lua's 17 x 17 x 32
+            if (nt == 8) done = launch_conv_batch<17, 8>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);
+            else if (nt == 4) done = launch_conv_batch<17, 4>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);
+            else if (nt == 2) done = launch_conv_batch<17, 2>(ctx, cb, n, L0.nIn, L0.nOut, L0.kH, L0.tanh_after, maxblocks);
+        }
 #undef DFE_CB
         if (done) {
             DFE_LAUNCH_CHECK(ctx);
