@@ -1598,8 +1598,8 @@ static int launch_cv_rowimg_one(dfe_ctx *ctx, const float *I0, const float *I1, 
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(dfe_cdiv(a.Wo, TX), dfe_cdiv(a.Ho, ty));
     {
-        DfeProfScope prof(ctx);
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
+        DfeProfScope prof(ctx, true);
+        hipExtLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, prof.a, prof.b, 0, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
     }
     DFE_LAUNCH_CHECK(ctx);
     ctx->last_kernel = F16 ? (FUSE ? "ssd_cv_rowimg_kernel_f16+fused_tail" : "ssd_cv_rowimg_kernel_f16")
@@ -1679,8 +1679,8 @@ static int launch_cv_rowimg_sweep(dfe_ctx *ctx, const float *I0, const float *I1
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     dim3 grid(nblk, 1);
     {
-        DfeProfScope prof(ctx);
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
+        DfeProfScope prof(ctx, true);
+        hipExtLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, ctx->stream, prof.a, prof.b, 0, I0, I1, out, a, fa ? *fa : CvFuseArgs{});
     }
     DFE_LAUNCH_CHECK(ctx);
     ctx->last_kernel = FUSE ? "ssd_cv_rowimg_kernel+fused_tail" : "ssd_cv_rowimg_kernel";
