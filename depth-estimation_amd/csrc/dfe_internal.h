@@ -315,9 +315,13 @@ __device__ __forceinline__ void pair_depth_px(int i, int j, float dy, float dx, 
 // at M as well).  p: pixel index inside the band (row-major over Wo); (fi, fj): its frame position (frame mode).
 template <int M>
 __device__ __forceinline__ void dfe_finalize_rec_pixel(const float *__restrict__ rec, int rec_rows, const float *__restrict__ vol, long long p, int N,
-                                                       int hWin, int wWin, int middle, double threshold, const TailOut &o, int fi, int fj) {
+                                                       int hWin, int wWin, int middle, double threshold, const TailOut &o, int fi, int fj,
+                                                       int iy = -1, int ix = -1) {
+    // (iy, ix): the pixel's row / column inside the band where the caller has them (frame mode) -- else from p, as a 32-bit division
+    // (the 64-bit quotient and remainder of the first version were a hundred instructions of a kernel that has few others)
     const long long pg = o.p_off + p;
-    const int y = (int)(p / o.Wo) + o.row_off, x = (int)(p % o.Wo);
+    const int yb = iy >= 0 ? iy : (int)((unsigned)p / (unsigned)o.Wo), x = ix >= 0 ? ix : (int)((unsigned)p - (unsigned)yb * (unsigned)o.Wo);
+    const int y = yb + o.row_off;
     const int ncols = (o.Wo + 7) >> 3;
     const int g = min(x >> 3, ncols - 1), xb = g == ncols - 1 ? o.Wo - 8 : g << 3;   // (the last tile column is shifted inwards)
     const float *rp = rec + ((long long)g * rec_rows + y) * DFE_REC;
@@ -332,8 +336,8 @@ __device__ __forceinline__ void dfe_finalize_rec_pixel(const float *__restrict__
     if (o.idx) o.idx[pg] = id;
     if (o.best) o.best[pg] = b.x;
     const long long fo = (long long)(y + o.pad_t) * o.pitch + x + o.pad_l;
-    const long long fl = (id - 1) / wWin;
-    const float dyf = (float)(fl - (hWin - 1) / 2), dxf = (float)(id - 1 - fl * wWin - (wWin - 1) / 2);
+    const int id0 = (int)id - 1, fl = id0 / wWin;                               // (id <= hWin * wWin: 32-bit)
+    const float dyf = (float)(fl - (hWin - 1) / 2), dxf = (float)(id0 - fl * wWin - (wWin - 1) / 2);
     if (o.fy) o.fy[fo] = dyf;
     if (o.fx) o.fx[fo] = dxf;
     if (o.frame_H && o.depth) pair_depth_px(fi, fj, dyf, dxf, o.mw, o.mh, o.infty, &o.depth[fo], &o.conf[fo]);

@@ -180,6 +180,34 @@ __global__ void x2yx_multi_compat_kernel(CompatGeom g, const long long *__restri
 //  A9: decode.  A7: extractOutput looks for the first M values above the threshold among the pixel's first DFE_LEAD
 //      cells (for cost volumes they are there); only if fewer are found does it walk on through the volume in index
 //      order (extract_output.cpp:99-112 stops at M as well).
+// The record path by itself (the fused single-scale step: rec != nullptr): the same per-pixel code as flow_finalize_kernel's record
+// branch, without the three-plane branch next to it (its registers, its scalar spills and 1 900 lines of code that never run here).
+template <int M>
+__global__ __launch_bounds__(256) void flow_finalize_rec_kernel(const float *__restrict__ vol, long long Pband, int N, int hWin, int wWin, int middle,
+                                                                double threshold, TailOut o, const float *__restrict__ rec, int rec_rows) {
+    const long long nthreads_work = o.frame_H ? (long long)o.frame_H * o.frame_W : Pband;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nthreads_work; q += (long long)gridDim.x * blockDim.x) {
+        long long p = q;
+        int fi = 0, fj = 0;
+        if (o.frame_H) {
+            fi = (int)((unsigned)q / (unsigned)o.frame_W);
+            fj = (int)((unsigned)q - (unsigned)fi * (unsigned)o.frame_W);
+            const int iy = fi - o.pad_t, ix = fj - o.pad_l;
+            if (iy < 0 || ix < 0 || ix >= o.Wo || (long long)iy * o.Wo + ix >= Pband) {   // border pixel
+                o.fy[q] = 0.f;
+                o.fx[q] = 0.f;
+                if (o.scores) o.scores[q] = 0.f;
+                if (o.depth) pair_depth_px(fi, fj, 0.f, 0.f, o.mw, o.mh, o.infty, &o.depth[q], &o.conf[q]);
+                continue;
+            }
+            p = (long long)iy * o.Wo + ix;
+            dfe_finalize_rec_pixel<M>(rec, rec_rows, vol, p, N, hWin, wWin, middle, threshold, o, fi, fj, iy, ix);
+            continue;
+        }
+        dfe_finalize_rec_pixel<M>(rec, rec_rows, vol, p, N, hWin, wWin, middle, threshold, o, fi, fj);
+    }
+}
+
 template <int M>
 __global__ __launch_bounds__(256) void flow_finalize_kernel(const float2 *__restrict__ part, const float *__restrict__ centre,
                                                             const float *__restrict__ lead, int nchunks, long long Ptot,
@@ -492,6 +520,15 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
     const int N = hWin * wWin;
     const int middle = (wWin + 1) / 2 + wWin * ((hWin + 1) / 2 - 1);
     const int grid = grid_for(pd ? (long long)pd->H * pd->W : Pb, 256);
+    if (rec) {
+        DFE_REQUIRE(ctx, Pb < (1ll << 31), DFE_E_SHAPE, "flow finalize: %lld pixels in one band", Pb);   // (32-bit pixel arithmetic in the record path)
+        if (threshold < 0.2)   // extract_output.cpp:83-85
+            hipLaunchKernelGGL(flow_finalize_rec_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, vol, Pb, N, hWin, wWin, middle, threshold, o, rec, rec_rows);
+        else
+            hipLaunchKernelGGL(flow_finalize_rec_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, vol, Pb, N, hWin, wWin, middle, threshold, o, rec, rec_rows);
+        DFE_LAUNCH_CHECK(ctx);
+        return DFE_OK;
+    }
     if (threshold < 0.2)   // extract_output.cpp:83-85
         hipLaunchKernelGGL(flow_finalize_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, part, centre, lead, nchunks, Ptot, vol, Pb, N,
                            hWin, wWin, middle, threshold, o, rec, rec_rows);

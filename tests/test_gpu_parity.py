@@ -425,6 +425,36 @@ def test_fused_build_matches_build_plus_tail(dfe, cuda, hWin, wWin, C, thr, mode
         assert np.array_equal(imaxs.cpu().numpy(), im) and np.array_equal(scores.cpu().numpy(), sc)
 
 
+@pytest.mark.parametrize("delta", [0.0, -1e-9, 1e-9, -0.5])
+def test_fused_extract_threshold_boundary(dfe, cuda, delta):
+    """extractOutput's `value > threshold` compares a float with a double (extract_output.cpp:86).  Frames of a few small integer
+    values make costs that EQUAL the threshold: thresholds at a frequent cost value, a hair below and above it (not representable in
+    fp32) and half an integer below give the oracle's scores and indices."""
+    H, W, hWin = 60, 84, 33
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=5, max_flow=6)
+    f0, f1 = np.floor(f0 / 64).astype(np.float32), np.floor(f1 / 64).astype(np.float32)    # values 0 .. 3: many equal costs
+    ref = rp.dense_flow_oracle(f0, f1, hWin, hWin, 7, 7, thr=0.21)
+    Ho, Wo = ref["idx"].shape
+    lead = ref["cost"].reshape(Ho, Wo, -1)[:, :, :8]
+    vals, counts = np.unique(lead, return_counts=True)
+    v = float(vals[np.argmax(counts)])                                                      # the most frequent cost among the lead cells
+    thr = v + delta
+    ctx = dfe.get_ctx(0)
+    idx = torch.empty((Ho, Wo), dtype=torch.int64, device=cuda)
+    best = torch.empty((Ho, Wo), dtype=torch.float32, device=cuda)
+    fy, fx = torch.empty_like(best), torch.empty_like(best)
+    scores = torch.full((Ho, Wo), -2.0, device=cuda)
+    imaxs = torch.full((Ho, Wo), -5, dtype=torch.int64, device=cuda)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    ctx.check(dfe.lib().dfe_ssd_flow_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, 7, 7, hWin, hWin, thr, idx.data_ptr(), best.data_ptr(),
+                                        fy.data_ptr(), fx.data_ptr(), scores.data_ptr(), imaxs.data_ptr()))
+    assert ctx.last_kernel().startswith("ssd_cv_rowimg_kernel+fused_tail")
+    sc, im = np.full((Ho, Wo), -2.0, np.float32), np.full((Ho, Wo), -5, np.int64)
+    orc.extract_output(ref["cost"].reshape(Ho, Wo, -1), thr, im, sc)
+    assert (lead == np.float32(v)).sum() > 100                                             # the boundary is really exercised
+    assert np.array_equal(imaxs.cpu().numpy(), im) and np.array_equal(scores.cpu().numpy(), sc)
+
+
 # ------------------------------------------------------------------ per-pixel consumers
 def test_argbest_center_device(dfe, cuda):
     rng = np.random.default_rng(5)
