@@ -102,6 +102,20 @@ __device__ __forceinline__ void ff_glds4(unsigned voff, const void *sbase, const
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
 }
 
+// Both requests of a tile row (PITCH floats: 64 lanes' 16-B pieces + a tail of NT lanes) as ONE assembly block: M0 saved and restored
+// once, the tail request under an execution mask set and restored by two scalar instructions (as C++: save / move / restore of M0 per
+// request and a saveexec / branch / restore around the second one -- twelve scalar instructions where seven do; every instruction of
+// this kernel's plane loop costs 0.24 % of it).  Called with all 64 lanes active.
+template <int NT> __device__ __forceinline__ void ff_glds_row(unsigned voff0, unsigned voff1, const void *sbase, const lds_f *lds_dst) {
+    const unsigned la = (unsigned)(size_t)lds_dst;
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_and_saveexec_b64 %1, %6\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(voff0), "v"(voff1), "s"(la), "s"(sbase), "n"((1u << NT) - 1) : "memory", "scc");
+}
+
 // maxh <= 16: waves 0 .. maxh-1 each sweep one window row.  EXTRA (maxh == 17): 16 waves, row 16 as the extra task.
 // ARGMIN: no volume -- the arithmetic's result goes through the first-minimum decode of version2/test.lua:45-51 (FfArgs::idx / xflow /
 // yflow) instead of the copy-out: the volume of a 17 x 17 window on VGA features is 316 MB that the one-call model never reads back.
@@ -115,10 +129,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     const int nrows = EXTRA ? p.maxh + 1 : nd + 1;         // in2 rows of a (half) tile (EXTRA: 18 -- left a run-time value: as a constant it cost 160 B more scratch)
     const int WN = p.maxh * MW;                            // floats per window
     const int WL = (EXTRA ? 17 : nd) * MW;                 // ... of them this block's
-    // LDS: [3][nrows][PITCH] tile | [3][256] in1 pieces | [64] lane offsets (extra task) | [64][WNP] image
+    // LDS: 3 x ([nrows][PITCH] tile | [256] in1 piece) | [64] lane offsets (extra task) | [64][WNP] image.  A buffer is addressed by its
+    // float offset from `tile`; the plane loop carries the three offsets and rotates them (no index -> address arithmetic per plane)
     lds_f *tile = (lds_f *)ff_smem;
-    lds_f *abuf = tile + 3 * nrows * PITCH;
-    lds_i *gtab = (lds_i *)(abuf + 3 * 64 * PX);
+    const int aoff = nrows * PITCH, BUFSZ = aoff + 64 * PX;  // the in1 piece of a buffer, floats per buffer
+    lds_i *gtab = (lds_i *)(tile + 3 * BUFSZ);
     lds_f *img = (lds_f *)(gtab + 64);                    // [64][WNP]
 
     const int lane = threadIdx.x & 63;
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         const bool last0 = yr0 == p.H2 - 1, last1 = j1 < nrows ? yr1 == p.H2 - 1 : y_first + 2 >= p.H1;   // may end at the end of the buffer (plane K-1)
         unsigned voff_a = 0;                                              // my 16-B piece of the in1 slots
         if (j1 == nrows) { const int l = lane_fresh(); voff_a = 4u * (unsigned)(4 * l - (l >= nA ? padpx : 0)); }
-        auto stage_row = [&](const char *rowp, lds_f *dst, bool careful) {
+        auto stage_row = [&](const char *rowp, lds_f *dst, bool careful) __attribute__((always_inline)) {
             if (careful) {                                                // (wave-uniform, once per frame)
 #pragma unroll
                 for (int m = 0; m < NLOAD; ++m) {
@@ -217,24 +232,36 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 if (4 * (lane + 64) < PITCH) ff_glds16(voff16[1], rowp, dst + 256);
             }
         };
-        auto stage = [&](int k, int buf) {
-            lds_f *tb = tile + buf * nrows * PITCH;
-            stage_row(rp0 + k * pstep0, tb + wave * PITCH, last0 && k == p.K - 1);
-            if (j1 < nrows) {
-                stage_row(rp1 + k * pstep1, tb + j1 * PITCH, last1 && k == p.K - 1);
-            } else if (j1 == nrows) {
-                // the in1 values of the tile's 256 pixel slots (group l, pixel q at slot 4 l + q): row y_first from xA0, then row
-                // y_first + 1 from column 0 -- linear in memory except for the W1p - W1 padding slots at the end of row y_first
-                const char *src1 = rp1 + k * pstep1;
-                if (last1 && k == p.K - 1) {
-                    const int lim = (int)plane1 - 1 - (y_first * p.W1 + xA0);
+        // kslow: the plane (K - 1) in which this wave's rows may end at the end of the buffer, or -1 -- ONE comparison per plane decides
+        // between the clamped float-by-float path and the plain one; role: what my second task is
+        const int kslow = (last0 || last1) ? p.K - 1 : -1;
+        const int role = j1 < nrows ? 2 : j1 == nrows ? 1 : 0;
+        constexpr int NTAIL = (PITCH - 256) / 4;                          // lanes of a row's second request
+        static_assert(NTAIL > 0 && NTAIL < 64 && PITCH % 4 == 0, "a tile row is 64 + NTAIL 16-B pieces");
+        auto stage = [&](int k, lds_f *tb, const bool FAST) __attribute__((always_inline)) {   // tb: the buffer; FAST: k != kslow is known
+            const char *r0 = rp0 + k * pstep0, *r1 = rp1 + k * pstep1;
+            if (FAST || k != kslow) {                                     // (flat: two wave-uniform tests around straight-line requests)
+                if (role != 0) {                                          // (the second task's requests first: see the counted wait)
+                    if (role == 2) ff_glds_row<NTAIL>(voff16[0], voff16[1], r1, tb + j1 * PITCH);
+                    else ff_glds16(voff_a, r1, tb + aoff);
+                }
+                ff_glds_row<NTAIL>(voff16[0], voff16[1], r0, tb + wave * PITCH);
+            } else {
+                stage_row(r0, tb + wave * PITCH, last0);
+                if (role == 2) stage_row(r1, tb + j1 * PITCH, last1);
+                if (role == 1) {
+                    // the in1 values of the tile's 256 pixel slots (group l, pixel q at slot 4 l + q): row y_first from xA0, then row
+                    // y_first + 1 from column 0 -- linear in memory except for the W1p - W1 padding slots at the end of row y_first
+                    if (last1) {
+                        const int lim = (int)plane1 - 1 - (y_first * p.W1 + xA0);
 #pragma unroll
-                    for (int m = 0; m < PX; ++m) {
-                        const int e = lane_fresh() + 64 * m;
-                        ff_glds4(4u * (unsigned)min(e - (e >= nA * PX ? padpx : 0), lim), src1, abuf + buf * 64 * PX + 64 * m);
+                        for (int m = 0; m < PX; ++m) {
+                            const int e = lane_fresh() + 64 * m;
+                            ff_glds4(4u * (unsigned)min(e - (e >= nA * PX ? padpx : 0), lim), r1, tb + aoff + 64 * m);
+                        }
+                    } else {
+                        ff_glds16(voff_a, r1, tb + aoff);
                     }
-                } else {
-                    ff_glds16(voff_a, src1, abuf + buf * 64 * PX);
                 }
             }
         };
@@ -257,21 +284,20 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         static_assert(NB4 == 5, "16- / 17-wide windows, 4 pixels per lane: 19 / 20 floats of the window row");
         float b[4 * NB4], ax = 0.f, bx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         ff_f4 a4;
-        auto read_head = [&](int buf) {
-            a4 = *(const lds_f4 *)(abuf + buf * 64 * PX + PX * lane);
-            const lds_f4 *br = (const lds_f4 *)(tile + buf * nrows * PITCH + boff);
+        auto read_head = [&](const lds_f *tb) __attribute__((always_inline)) {
+            a4 = *(const lds_f4 *)(tb + aoff + PX * lane);
+            const lds_f4 *br = (const lds_f4 *)(tb + boff);
 #pragma unroll
             for (int j = 0; j < NB4 - 1; ++j) {
                 const ff_f4 v = br[j];
                 b[4 * j] = v[0]; b[4 * j + 1] = v[1]; b[4 * j + 2] = v[2]; b[4 * j + 3] = v[3];
             }
         };
-        auto read_tail = [&](int buf) {
-            const lds_f *bt = tile + buf * nrows * PITCH;
+        auto read_tail = [&](const lds_f *bt) __attribute__((always_inline)) {
             const ff_f4 v = ((const lds_f4 *)(bt + boff))[NB4 - 1];
             b[16] = v[0]; b[17] = v[1]; b[18] = v[2]; b[19] = v[3];
             if constexpr (EXTRA) {
-                ax = abuf[buf * 64 * PX + 16 * wave + (lane >> 2)];     // (slot of pixel (lane >> 2) & 3 of group 4 wave + (lane >> 4))
+                ax = bt[aoff + 16 * wave + (lane >> 2)];                // (slot of pixel (lane >> 2) & 3 of group 4 wave + (lane >> 4))
 #pragma unroll
                 for (int j = 0; j < 5; ++j) bx[j] = bt[xoff_b + j];
             }
@@ -283,13 +309,14 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         }
         // ONE loop over kk = 0 .. K+1: iteration kk requests plane kk, does the arithmetic of plane kk-2 and reads the operands of plane
         // kk-1 (the two fill iterations included, so that the staging code exists once: inlined three times it cost 40 spilled scalars)
-        int bs = 0;                                                       // kk % 3
-        for (int kk = 0; kk < p.K + 2; ++kk) {
-            const int bc = bs == 2 ? 0 : bs + 1;                          // (kk - 2) % 3: the plane of this iteration's arithmetic
-            const int bp = bs == 0 ? 2 : bs - 1;                          // (kk - 1) % 3: complete since the previous barrier
+        const int kplain = kslow >= 0 ? kslow : p.K;
+        // (Tried: the loop once per role -- what a wave's second staging task is -- so that the role tests fold away: with three inlined
+        //  copies the staging pointers came out as vector registers and the requests' scalar-base form did not assemble.)
+        lds_f *bs = tile, *bc = tile + BUFSZ, *bp = tile + 2 * BUFSZ;     // buffers of plane kk (requested now), kk - 2 (this iteration's arithmetic), kk - 1
+        auto plane = [&](int kk, const bool STEADY) __attribute__((always_inline)) {   // STEADY: 2 <= kk < kplain, a constant at the call
             if (FF_DEEP) read_head(bc);
             read_tail(bc);                                                // (kk < 2: nothing there yet, nothing is computed from it)
-            if (kk < p.K) stage(kk, bs);
+            if (STEADY || kk < p.K) stage(kk, bs, STEADY);
             __builtin_amdgcn_sched_barrier(0);
             // the (pixel, cell) pairs in batches of FF_BATCH: all differences, then all squares, then all adds
             auto pairs = [&](auto first_part) {
@@ -309,7 +336,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     });
                 });
             };
-            if (kk >= 2) {
+            if (STEADY || kk >= 2) {
                 pairs(std::true_type{});
                 __builtin_amdgcn_sched_barrier(0);
                 pairs(std::false_type{});
@@ -327,15 +354,22 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             // my requests of plane kk have landed; behind the barrier everyone's have, and every wave is past its reads of plane kk-3
             if (FF_DEEP) {
                 // all but THIS iteration's requests have landed: the plane of the next iteration's arithmetic
-                const bool plain = kk < p.K && !((last0 || last1) && kk == p.K - 1);
-                const int nld = 2 + (j1 < nrows ? 2 : j1 == nrows ? 1 : 0);
-                if (plain && nld == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-                else if (plain && nld == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-                else if (plain && nld == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                // (plain planes: kk < K, or < K - 1 where the last plane takes the clamped path, whose request count differs)
+                // vmcnt(2) whatever the wave's role: everything but the LAST two requests has landed -- all of the previous plane's, and, for
+                // the waves with a second task, that task's requests of this plane, which went out first, a whole plane of arithmetic ago
+                // (counting the role's own 2 / 3 / 4 requests took a compare-and-branch chain per plane)
+                if (!STEADY && kk >= kplain) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            bs = bs == 2 ? 0 : bs + 1;
-        }
+            { lds_f *const t = bs; bs = bc; bc = bp; bp = t; }            // (kk + 1) % 3, (kk - 1) % 3, kk % 3
+        };
+        // fill (planes 0, 1 requested), steady planes (request + arithmetic + counted wait, none of the per-plane tests), the rest (the
+        // clamped last plane where this wave has one, and the two drain iterations)
+        plane(0, false);
+        plane(1, false);
+        int kk = 2;
+        for (; kk < kplain; ++kk) plane(kk, true);
+        for (; kk < p.K + 2; ++kk) plane(kk, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // ---- copy-out: one phase per pixel q of the groups -- ALL lanes deposit their pixel q's window row (an LDS instruction costs its
