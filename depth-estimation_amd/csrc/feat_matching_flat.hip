@@ -236,15 +236,16 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         // between the clamped float-by-float path and the plain one; role: what my second task is
         const int kslow = (last0 || last1) ? p.K - 1 : -1;
         const int role = j1 < nrows ? 2 : j1 == nrows ? 1 : 0;
+        const bool is_row1 = role == 2, is_piece = role == 1;
         constexpr int NTAIL = (PITCH - 256) / 4;                          // lanes of a row's second request
         static_assert(NTAIL > 0 && NTAIL < 64 && PITCH % 4 == 0, "a tile row is 64 + NTAIL 16-B pieces");
         auto stage = [&](int k, lds_f *tb, const bool FAST) __attribute__((always_inline)) {   // tb: the buffer; FAST: k != kslow is known
             const char *r0 = rp0 + k * pstep0, *r1 = rp1 + k * pstep1;
             if (FAST || k != kslow) {                                     // (flat: two wave-uniform tests around straight-line requests)
-                if (role != 0) {                                          // (the second task's requests first: see the counted wait)
-                    if (role == 2) ff_glds_row<NTAIL>(voff16[0], voff16[1], r1, tb + j1 * PITCH);
-                    else ff_glds16(voff_a, r1, tb + aoff);
-                }
+                // (the second task's requests first: see the counted wait; two independent tests -- nested, the compiler spent eight
+                //  scalar instructions on the role of a wave that has no second task)
+                if (is_row1) ff_glds_row<NTAIL>(voff16[0], voff16[1], r1, tb + j1 * PITCH);
+                if (is_piece) ff_glds16(voff_a, r1, tb + aoff);
                 ff_glds_row<NTAIL>(voff16[0], voff16[1], r0, tb + wave * PITCH);
             } else {
                 stage_row(r0, tb + wave * PITCH, last0);
