@@ -109,13 +109,28 @@ extern __shared__ __attribute__((aligned(16))) float conv_smem[];
 // NARROW: tiles of 64 x 16 outputs (16 x 16 threads) instead of 128 x 8: less halo per output for large kernels (the launcher's
 // rule and the measurement behind it: launch_conv_batch).  Same strips, same order of operations per output: the results do not
 // depend on the shape.
-// One LDS-DMA load of 64 floats: lane l fetches the float at sbase + voff (bytes) into LDS at lds_dst + 4 l (M0 = the destination base,
-// saved and restored around the instruction: cdna_hip_programming.md, LDS-DMA recipe).
-__device__ __forceinline__ void cb_glds4(unsigned voff, const void *sbase, const float *lds_dst) {
+// The LDS-DMA requests of one tile row of PITCH floats as ONE assembly block: lane l fetches the floats at sbase + voff{0,1,2} (bytes)
+// into LDS at lds_dst + 4 l, + 256 + 4 l, + 512 + 4 l; the last request covers PITCH - 64 (N - 1) lanes under an execution mask set
+// and restored by scalar instructions; M0 (the destination base) saved and restored once (cdna_hip_programming.md, LDS-DMA recipe).
+// Called with all 64 lanes active.  (One block per request, a branch around the partial one: twice the scalar instructions -- and in
+// these kernels every instruction costs issue time)
+template <int PITCH> __device__ __forceinline__ void cb_glds_row(unsigned v0, unsigned v1, unsigned v2, const void *sbase, const float *lds_dst) {
     const unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds_dst;
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
+    unsigned long long ex;
+    static_assert(PITCH > 64 && PITCH <= 192, "two or three requests per row");
+    if constexpr (PITCH > 128) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %2, %6\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_nop 0\n\tglobal_load_lds_dword %3, %6\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_and_saveexec_b64 %1, %7\n\tglobal_load_lds_dword %4, %6\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(v0), "v"(v1), "v"(v2), "s"(la), "s"(sbase), "s"((1ull << (PITCH - 128)) - 1) : "memory", "scc");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, %5\n\t"
+                     "s_add_u32 m0, m0, 0x100\n\ts_and_saveexec_b64 %1, %6\n\tglobal_load_lds_dword %3, %5\n\t"
+                     "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(v0), "v"(v1), "s"(la), "s"(sbase), "s"(PITCH == 128 ? ~0ull : (1ull << (PITCH - 64)) - 1) : "memory", "scc");
+    }
 }
 
 template <int KW, int NT, bool TANH, bool NARROW = false>
@@ -149,13 +164,14 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
         const float *__restrict__ in = cb.in[L.ent];
         const unsigned c0 = 4u * (unsigned)min(L.x0 + lane, L.W - 1), c1 = 4u * (unsigned)min(L.x0 + min(lane + 64, PITCH - 1), L.W - 1),
                        c2 = 4u * (unsigned)min(L.x0 + min(lane + 128, PITCH - 1), L.W - 1);
+        // (plane i, tile row r) of tile row rr = wave, wave + 4, ...: carried, not divided out (trows >= 8 > 4); the row's element
+        // index in 32 bits (the launcher checks nIn * H * W)
+        int i = 0, r = wv;
         for (int rr = wv; rr < nrows; rr += 4) {
-            const int i = rr / trows, r = rr - i * trows;
-            const float *src = in + ((long long)i * L.H + min(L.y0 + r, L.H - 1)) * L.W;
-            float *dst = buf + rr * PITCH;
-            cb_glds4(c0, src, dst);
-            if (PITCH >= 128 || lane + 64 < PITCH) cb_glds4(c1, src, dst + 64);
-            if (PITCH > 128 && lane + 128 < PITCH) cb_glds4(c2, src, dst + 128);
+            const unsigned e0 = (unsigned)(i * L.H + min(L.y0 + r, L.H - 1)) * (unsigned)L.W;
+            cb_glds_row<PITCH>(c0, c1, c2, in + e0, buf + rr * PITCH);
+            r += 4;
+            if (r >= trows) { r -= trows; ++i; }
         }
     };
     // (Tried: blocks that work through 2 or 4 consecutive (tile, output group) items, the next item's tile requested into a second LDS
@@ -264,6 +280,7 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
         for (int e = 0; e < n; ++e) {
             DFE_REQUIRE(ctx, in[e] && out[e] && L[e]->weight && H[e] >= L0.kH && W[e] >= L0.kW, DFE_E_SHAPE, "filter layer batch: entry %d: %dx%d kernel on %dx%d", e,
                         L0.kH, L0.kW, H[e], W[e]);
+            if ((long long)L0.nIn * H[e] * W[e] >= (1ll << 32)) ok = false;       // (32-bit element indices in the staging)
             cb.in[e] = in[e]; cb.out[e] = out[e]; cb.w[e] = L[e]->weight; cb.bias[e] = L[e]->bias; cb.H[e] = H[e]; cb.W[e] = W[e];
             const int b = dfe_cdiv(W[e] - L0.kW + 1, 64) * dfe_cdiv(H[e] - L0.kH + 1, 8);
             if (b > maxblocks) maxblocks = b;
