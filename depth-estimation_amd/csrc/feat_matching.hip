@@ -245,46 +245,75 @@ __device__ __forceinline__ void feat_matching_win64_body(const FmBatch &fb, int 
 #pragma unroll
         for (int x = 0; x < FM_TX; ++x) acc[t][x] = 0.f;
     const float *a_base = fb.in1[z] + (long long)y0 * W1 + x0;
+    // (a row base per task + a 32-bit plane offset, which the scalar load takes as its offset operand: the 64-bit k * plane + row * W
+    //  of the first version was a dozen scalar instructions per load; the launcher checks K * plane bytes < 2^32)
+    const char *const rb0 = reinterpret_cast<const char *>(a_base + (long long)wave * W1);
+    const char *const rb1 = reinterpret_cast<const char *>(a_base + (long long)(wave + 8) * W1);
+    const unsigned p1b = (unsigned)plane1 * 4u;
     auto lda = [&](int k, int row) -> fm_f8 {
-        return *(const __attribute__((address_space(4))) fm_f8u *)(fm_cfptr)(a_base + (long long)k * plane1 + (long long)row * W1);   // s_load_dwordx8
+        return *(const __attribute__((address_space(4))) fm_f8u *)(fm_cfptr)((row == wave ? rb0 : rb1) + (unsigned long long)((unsigned)k * p1b));   // s_load_dwordx8
     };
-    fm_f8 a[2][2];                                         // [task][plane parity]
+    // Two planes per step, the frame-1 values of the NEXT two planes requested (scalar loads) behind this step's LDS reads.  The steps
+    // alternate between two sets of scalars (a / an) instead of copying the new set over the old one, and the loop runs over whole pairs
+    // of planes only, an odd last plane behind it: the first version's loop body was 96 arithmetic instructions in 300 -- 32 scalar moves
+    // for the copy, a select and a branch per element for `is there a second plane` (profiles/r04_au: 1.28e7 scalar instructions per
+    // launch for 2.33e7 vector ones), and these kernels pay for every instruction issued.
+    fm_f8 a[2][2], an[2][2];                               // [task][plane parity]
 #pragma unroll
     for (int t = 0; t < 2; ++t) { a[t][0] = lda(0, wave + 8 * t); a[t][1] = lda(K > 1 ? 1 : 0, wave + 8 * t); }
-    for (int k = 0; k < K; k += 2) {
-        const bool two = k + 1 < K;                        // (wave-uniform)
+    auto step2 = [&](const fm_f8 (&cur)[2][2], fm_f8 (&nxt)[2][2], int k) __attribute__((always_inline)) {
         float b[2][2][FM_TX];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const float *bp = fm_smem + (wave + 8 * t + dy) * pitch + dx + k * pl;
 #pragma unroll
-            for (int x = 0; x < FM_TX; ++x) { b[t][0][x] = bp[x]; b[t][1][x] = two ? bp[pl + x] : 0.f; }
+            for (int x = 0; x < FM_TX; ++x) { b[t][0][x] = bp[x]; b[t][1][x] = bp[pl + x]; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this step's LDS data (and the scalars requested a step ago) are in
         __builtin_amdgcn_sched_barrier(0);
-        fm_f8 an[2][2];
         const int k2 = min(k + 2, K - 1), k3 = min(k + 3, K - 1);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { an[t][0] = lda(k2, wave + 8 * t); an[t][1] = lda(k3, wave + 8 * t); }
+        for (int t = 0; t < 2; ++t) { nxt[t][0] = lda(k2, wave + 8 * t); nxt[t][1] = lda(k3, wave + 8 * t); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int x = 0; x < FM_TX; ++x) {
-                const float df = a[t][0][x] - b[t][0][x];
+                const float df = cur[t][0][x] - b[t][0][x];
                 acc[t][x] = acc[t][x] + df * df;
             }
-            if (two) {
 #pragma unroll
-                for (int x = 0; x < FM_TX; ++x) {
-                    const float df = a[t][1][x] - b[t][1][x];
-                    acc[t][x] = acc[t][x] + df * df;
-                }
+            for (int x = 0; x < FM_TX; ++x) {
+                const float df = cur[t][1][x] - b[t][1][x];
+                acc[t][x] = acc[t][x] + df * df;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    int k = 0;
+    for (; k + 3 < K; k += 4) { step2(a, an, k); step2(an, a, k + 2); }
+    if (k + 1 < K) {
+        step2(a, an, k);
+        k += 2;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { a[t][0] = an[t][0]; a[t][1] = an[t][1]; }
+        for (int t = 0; t < 2; ++t) a[t][0] = an[t][0];
+    }
+    if (k < K) {                                           // an odd last plane: its frame-1 values are a[.][0] (requested as min(k, K - 1) above)
+        float b[2][FM_TX];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *bp = fm_smem + (wave + 8 * t + dy) * pitch + dx + k * pl;
+#pragma unroll
+            for (int x = 0; x < FM_TX; ++x) b[t][x] = bp[x];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int x = 0; x < FM_TX; ++x) {
+                const float df = a[t][0][x] - b[t][x];
+                acc[t][x] = acc[t][x] + df * df;
+            }
     }
     if constexpr (MODE != 0) {
 #pragma unroll
@@ -356,6 +385,7 @@ int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, 
     size_t vol = 0;
     for (int i = 0; i < n; ++i) {
         if (H1[i] < F64_TY || W1[i] < FM_TX || ((uintptr_t)in1[i] & 3) || (!fine && ((uintptr_t)out[i] & 15))) return DFE_OK;
+        if ((long long)K * H1[i] * W1[i] * 4 >= (1ll << 32)) return DFE_OK;           // (32-bit plane offsets of the frame-1 scalar loads)
         fb.in1[i] = in1[i]; fb.in2[i] = in2[i]; fb.out[i] = fine ? nullptr : out[i]; fb.H1[i] = H1[i]; fb.W1[i] = W1[i];
         gx = gx > dfe_cdiv(W1[i], FM_TX) ? gx : dfe_cdiv(W1[i], FM_TX);
         gy = gy > dfe_cdiv(H1[i], F64_TY) ? gy : dfe_cdiv(H1[i], F64_TY);
