@@ -405,6 +405,7 @@ int dfe_feat_matching_fast(dfe_ctx *ctx, const float *in1, const float *in2, int
 int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled);
 int dfe_feat_matching_flat_argmin(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, long long *idx, float *xflow,
                                   float *yflow, bool *handled);
+bool dfe_feat_matching_flat_argmin_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw);
 bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw);   // the ctx / window conditions of the launcher below
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
                                   int maxw, float *const *out, float f16_scale, bool *handled, const struct CvFineArgs *fine = nullptr);

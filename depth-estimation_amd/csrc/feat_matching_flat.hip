@@ -25,6 +25,7 @@
 //     EXTRA task, row 16 for the 16 pixels of lanes 4w .. 4w+3 (lane <-> (pixel, 4-cell group): 5 accumulators, 15 vector
 //     instructions a plane next to the main task's 204) -- the seventeenth row costs 7 % instead of a second round.
 #include "dfe_internal.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             // Every (lane, pixel, window row) leaves its row's minimum and the first cell attaining it (strict '<' in cell order) in LDS --
             // cand[slot 4 l + q][row] -- the extra task's lanes one candidate per 4-cell group of row 16 (cand[..][16 + c]); then one
             // thread per pixel slot walks its candidates in window order, again with strict '<': the first minimum of the whole window,
-            // exactly what the arg-min over the stored volume finds (NaN never wins, as in torch.min).
+            // exactly what v2_argmin_decode_kernel finds in the stored volume (a NaN never wins; torch.min would return the NaN:
+            // equality with the staged host path is for volumes without NaN).
             constexpr int NC = EXTRA ? 20 : 16;                           // candidates per pixel slot
             lds_f *cv = img;                                              // [256][NC] values
             lds_i *ci = (lds_i *)(img + 256 * NC);                        // [256][NC] window indices (0-based)
@@ -519,19 +521,31 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 
 }  // namespace
 
+// the shapes this kernel takes (the pointers' alignment apart): 16- / 17-wide windows of 4 .. 17 rows on frames at least 64 groups wide
+static bool ff_shape_ok(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw) {
+    if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || ctx->opt[DFE_OPT_FM_FLAT] == 0) return false;
+    if (maxw != 16 && maxw != 17) return false;
+    if (maxh < 4 || maxh > 17 || (maxh == 17 && maxw != 17)) return false;
+    const int G = dfe_cdiv(W1, FF_PX);
+    if (G < FF_GROUPS || K < 1 || H1 < 1) return false;                    // (a tile must not touch more than two image rows)
+    const long long NGl = (long long)H1 * G;
+    if (NGl > (1ll << 30) || (long long)H1 * W1 * maxh * maxw >= (1ll << 40)) return false;
+    return true;
+}
+
+// whether dfe_feat_matching_flat_argmin will take the shape (4-byte aligned feature maps assumed): the one-call models decide with it
+// whether the volume needs a place in the scratch arena at all
+bool dfe_feat_matching_flat_argmin_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw) { return ff_shape_ok(ctx, K, H1, W1, maxh, maxw); }
+
 // *handled stays false when the shape is not this kernel's (the caller goes on to the round-3 kernels)
 static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, long long *idx, float *xflow,
                      float *yflow, bool *handled) {
     const bool argmin = out == nullptr;
     *handled = false;
-    if (ctx->cv_mode == 1 || ctx->cv_mode == 2 || ctx->opt[DFE_OPT_FM_FLAT] == 0) return DFE_OK;
-    if (maxw != 16 && maxw != 17) return DFE_OK;
-    if (maxh < 4 || maxh > 17 || (maxh == 17 && maxw != 17)) return DFE_OK;
+    if (!ff_shape_ok(ctx, K, H1, W1, maxh, maxw)) return DFE_OK;
     const int G = dfe_cdiv(W1, FF_PX);
-    if (G < FF_GROUPS || K < 1 || H1 < 1) return DFE_OK;                   // (a tile must not touch more than two image rows)
     if (((uintptr_t)in1 | (uintptr_t)in2 | (uintptr_t)out) & 3) return DFE_OK;
     const long long NGl = (long long)H1 * G;
-    if (NGl > (1ll << 30) || (long long)H1 * W1 * maxh * maxw >= (1ll << 40)) return DFE_OK;
     FfArgs a{};
     a.in1 = in1; a.in2 = in2; a.out = out;
     a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;
@@ -551,7 +565,10 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
     const int NW = a.nd;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
     const int WNP = ff_wnp((extra ? 17 : a.nd) * maxw);
-    const size_t lds = ((size_t)3 * (extra ? 18 : a.nd + 1) * PITCH + 3 * 64 * FF_PX + 64 + (size_t)64 * WNP) * sizeof(float);
+    // the copy-out image [64][WNP]; the arg-min form keeps its candidates there instead -- cv[256][NC] and ci[256][NC], NC = 16 (20 with
+    // the extra task) whatever the window's height: larger than the image of a window of fewer than 8 rows
+    const size_t img_floats = std::max((size_t)64 * WNP, argmin ? (size_t)2 * 256 * (extra ? 20 : 16) : (size_t)0);
+    const size_t lds = ((size_t)3 * (extra ? 18 : a.nd + 1) * PITCH + 3 * 64 * FF_PX + 64 + img_floats) * sizeof(float);
     if (lds * a.S > 160 * 1024) return DFE_OK;
     void (*kern)(FfArgs) = argmin ? (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, true> : feat_matching_flat_kernel<17, false, true>)
                                                 : feat_matching_flat_kernel<16, false, true>)

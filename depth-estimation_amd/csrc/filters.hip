@@ -288,7 +288,7 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
         // output planes per thread: the most that still leaves two blocks per CU (a 320 x 180 frame is 66 tiles: with all of a layer's
         // planes in one block most of the chip idles -- tests/time_matching.lua's filter 0.131 -> 0.105 ms with 2 planes per thread)
         long long tiles = 0;
-        const bool narrow_k = L0.kW >= 9 && L0.kH >= 9;
+        const bool narrow_k = ctx->opt_bool(DFE_OPT_CONV_NARROW, L0.kW >= 9 && L0.kH >= 9);   // (the tile shape launch_conv_batch picks)
         for (int e = 0; e < n; ++e) tiles += (long long)dfe_cdiv(W[e] - L0.kW + 1, narrow_k ? 64 : 128) * dfe_cdiv(H[e] - L0.kH + 1, narrow_k ? 16 : 8);
         const int cand[6] = {10, 8, 5, 4, 2, 1};
         int nt = 0;

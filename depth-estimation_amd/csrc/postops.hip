@@ -522,6 +522,7 @@ int dfe_flow_finalize(dfe_ctx *ctx, const float2 *part, const float *centre, con
     const int grid = grid_for(pd ? (long long)pd->H * pd->W : Pb, 256);
     if (rec) {
         DFE_REQUIRE(ctx, Pb < (1ll << 31), DFE_E_SHAPE, "flow finalize: %lld pixels in one band", Pb);   // (32-bit pixel arithmetic in the record path)
+        DFE_REQUIRE(ctx, !pd || (long long)pd->H * pd->W < (1ll << 31), DFE_E_SHAPE, "flow finalize: frame of %d x %d pixels", pd ? pd->H : 0, pd ? pd->W : 0);
         if (threshold < 0.2)   // extract_output.cpp:83-85
             hipLaunchKernelGGL(flow_finalize_rec_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, vol, Pb, N, hWin, wWin, middle, threshold, o, rec, rec_rows);
         else

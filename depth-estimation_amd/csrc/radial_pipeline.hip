@@ -381,7 +381,9 @@ static int radial_filter(dfe_ctx *ctx, const dfe_radial_params *p, const float *
     const int W = Wp - p->kW1 + 1, Ho = H - p->kH2 + 1;
     int rc = DFE_OK;
     bool done = false;
-    if ((size_t)p->C * (256 + p->kW1 - 1) * sizeof(float) <= 48 * 1024) {
+    // (the 17-tap kernel stages two interleaved rows: twice the LDS of the one-row kernel; both stay within the 64 KB a launch gets
+    //  without hipFuncAttributeMaxDynamicSharedMemorySize)
+    if ((size_t)p->C * (256 + p->kW1 - 1) * sizeof(float) * (p->kW1 == 17 ? 2 : 1) <= 48 * 1024) {
         switch (p->n1) {
             case 4: rc = launch_conv_rows<4>(ctx, polar, w1, b1, p->C, H, Wp, p->kW1, p->tanh_between != 0, tmp); done = true; break;
             case 5: rc = launch_conv_rows<5>(ctx, polar, w1, b1, p->C, H, Wp, p->kW1, p->tanh_between != 0, tmp); done = true; break;

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void v2_argmin_decode_kernel(const float *__re
         int bi = 0x7fffffff;
         for (int i = lane; i < N; i += 64) {
             const float c = v[i];
-            if (c < best) { best = c; bi = i; }       // (strict: the lane keeps its first minimum; NaN never wins, as in torch.min)
+            if (c < best) { best = c; bi = i; }       // (strict: the lane keeps its first minimum; a NaN never wins -- torch.min would return it: the
+                                                      //  equality with the staged host path holds for volumes without NaN)
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -75,7 +76,10 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
     for (int i = 0; i < nlayers; ++i) maxplanes = maxplanes > layers[i].nOut ? maxplanes : layers[i].nOut;
     const size_t f_cn = ((size_t)C + 3) * P, f_n = (size_t)C * P, f_c = (size_t)C * Hc * Wc;
     const size_t f_fa = (size_t)maxplanes * Hc * Wc, f_fb = (size_t)maxplanes * P;
-    const size_t f_vol = volume ? 0 : (size_t)P1 * N;
+    // (the volume needs a place in the arena only when nobody gave one AND the matcher + arg-min kernel will not take the shape:
+    //  316 MB at VGA, 2.4 GB at 1080p that the lean path never touches)
+    const bool lean = !volume && (xflow || yflow || idx) && dfe_feat_matching_flat_argmin_takes(ctx, K, H1, W1, hWin, wWin);
+    const size_t f_vol = (volume || lean) ? 0 : (size_t)P1 * N;
     auto al = [](size_t f) { return (f + 63) / 64 * 64; };
     void *scr = nullptr;
     int rc = dfe_scratch(ctx, (al(f_cn) + al(f_n) + al(f_c) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_vol)) * sizeof(float), &scr);
@@ -111,6 +115,7 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
         bool done = false;
         rc = dfe_feat_matching_flat_argmin(ctx, ia, ib, K, H1, W1, hWin, wWin, (long long *)idx, xflow, yflow, &done);
         if (rc || done) return rc;
+        DFE_REQUIRE(ctx, !lean, DFE_E_UNSUPPORTED, "dfe_version2_flow_pair_f32: the matcher declined a shape its predicate took");
     }
     {
         DfeStageScope st(ctx, DFE_STAGE_MATCH);
@@ -124,5 +129,37 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
             DFE_LAUNCH_CHECK(ctx);
         }
     }
+    return DFE_OK;
+}
+
+// nn.SpatialMatching(maxh, maxw) followed by `output:min(3)` and the decode of version2/test.lua:45-51 (radial_opticalflow_groundtruth.lua:88-100
+// without the centre override), on feature maps that are already there: matcher and first-minimum decode in one kernel where the flat-tile
+// matcher takes the shape, the matcher into the scratch arena + the decode kernel otherwise -- the same sums and the same first minimum
+// either way.
+extern "C" int dfe_spatial_matching_argmin_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                               int64_t *idx, float *xflow, float *yflow) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, in1 && in2 && (idx || xflow || yflow), DFE_E_ARG, "dfe_spatial_matching_argmin_f32: NULL argument");
+    DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_ARG, "dfe_spatial_matching_argmin_f32: K=%d %dx%d window %dx%d", K, H1, W1, maxh, maxw);
+    const int lWin = (maxw + 1) / 2 - 1, tWin = (maxh + 1) / 2 - 1;
+    bool done = false;
+    {
+        DfeStageScope st(ctx, DFE_STAGE_MATCH);
+        int rc = dfe_feat_matching_flat_argmin(ctx, in1, in2, K, H1, W1, maxh, maxw, (long long *)idx, xflow, yflow, &done);
+        if (rc || done) return rc;
+    }
+    const long long P1 = (long long)H1 * W1;
+    const int N = maxh * maxw;
+    void *scr = nullptr;
+    int rc = dfe_scratch(ctx, (size_t)P1 * N * sizeof(float), &scr);
+    if (rc) return rc;
+    {
+        DfeStageScope st(ctx, DFE_STAGE_MATCH);
+        rc = dfe_spatial_matching_dispatch(ctx, in1, in2, K, H1, W1, maxh, maxw, (float *)scr);
+        if (rc) return rc;
+    }
+    DfeStageScope st(ctx, DFE_STAGE_EXTRACT);
+    hipLaunchKernelGGL(v2_argmin_decode_kernel, dim3(v2_grid(P1, 4)), dim3(256), 0, ctx->stream, (const float *)scr, P1, N, maxw, lWin, tWin, (long long *)idx, xflow, yflow);
+    DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

@@ -84,6 +84,7 @@ int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val
 int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth, float *depth_conf);
 int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx);
 int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const float *cur, int C, int H, int W, const float *norm_kernel_host, int norm_k, float threshold, float thresval, const dfe_filter_layer *layers, int nlayers, int hWin, int wWin, float *xflow, float *yflow, int64_t *idx, float *volume);
+int dfe_spatial_matching_argmin_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, int64_t *idx, float *xflow, float *yflow);
 int dfe_spatial_convolution_mfma_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, int tanh_after, float *out);
 int dfe_spatial_convolution_grad_input_f32(dfe_ctx *ctx, const float *gradOut, const float *weight, int nIn, int nOut, int H, int W, int kH, int kW, float *gradIn);
 int dfe_spatial_convolution_acc_grad_f32(dfe_ctx *ctx, const float *in, const float *gradOut, int nIn, int nOut, int H, int W, int kH, int kW, float scale, float *gradWeight, float *gradBias);

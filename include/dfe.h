@@ -476,6 +476,14 @@ int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *
 int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const float *cur, int C, int H, int W, const float *norm_kernel_host,
                                int norm_k, float threshold, float thresval, const dfe_filter_layer *layers, int nlayers, int hWin,
                                int wWin, float *xflow, float *yflow, int64_t *idx, float *volume);
+/* replaces: nn.SpatialMatching(maxh, maxw, false) followed by `output:min(3)` and the index -> displacement decode, as
+ *   version2/test.lua:45-51 and tests/time_matching.lua:18,41-43 run them on feature maps (in1 [K][H1][W1], in2 [K][H1+maxh-1][W1+maxw-1]):
+ *   idx [H1][W1] int64 1-based first minimum of the window (index order), yflow = floor((idx-1) / maxw) - (ceil(maxh/2) - 1),
+ *   xflow = (idx-1) mod maxw - (ceil(maxw/2) - 1); any of the three may be NULL.  The volume is never written where the flat-tile
+ *   matcher takes the shape (16- / 17-wide windows on maps at least 253 columns wide); the results are those of
+ *   dfe_spatial_matching_f32 + the first minimum, bit for bit. */
+int dfe_spatial_matching_argmin_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                    int64_t *idx, float *xflow, float *yflow);
 /* nn.SpatialConvolution [+ nn.Tanh] as an implicit GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: f32 in, f32
  * accumulate, an fmaf chain in the reference's (input plane, ky, kx) order).  Same layouts as dfe_spatial_convolution_f32;
  * results differ from it by the fusing of each multiply-add only (<= 1e-5 relative to sum |terms|).  kH x kW up to what

@@ -276,3 +276,30 @@ def version2_flow_oracle(prev, cur, datap, weights, biases, threshold=1e-4, thre
     H1, W1 = vol.shape[:2]
     idx0 = vol.reshape(H1, W1, -1).argmin(axis=2)               # numpy: the first minimum
     return {"volume": vol, "index": idx0 + 1, "yflow": (idx0 // wWin - tWin).astype(np.float32), "xflow": (idx0 % wWin - lWin).astype(np.float32)}
+
+
+def version2_band_oracle(prev, cur, datap, weights, biases, y0, y1, threshold=1e-4, thresval=1e-4):
+    """version2_flow_oracle for the output rows y0 .. y1-1 only: the normalisation on the whole frames (its estimators see the frame's
+    borders), then the convolution stack and the matcher on the rows the band needs -- both are 'valid' operators, so the band's values
+    are exactly the full frame's.  Returns the same keys, [y1 - y0][W1]..."""
+    import math
+    from tests import oracle as orc
+
+    k = datap["normalization_k"]
+    i = np.arange(1, k + 1, dtype=np.float64)
+    g = np.exp(-(((i - (k / 2 + 0.5)) / (0.25 * k)) ** 2) / 2).astype(np.float32)
+    n0 = orc.contrastive_normalization(prev, g, threshold, thresval)
+    n1 = orc.contrastive_normalization(cur, g, threshold, thresval)
+    hWin, wWin = datap["hWin"], datap["wWin"]
+    lWin, tWin = math.ceil(wWin / 2) - 1, math.ceil(hWin / 2) - 1
+    H, W = prev.shape[1:]
+    hk = 1 + sum(w.shape[2] - 1 for w in weights)
+    a = np.ascontiguousarray(n0[:, tWin + y0 : tWin + y1 + hk - 1, lWin : lWin + W - (wWin - 1)])
+    b = np.ascontiguousarray(n1[:, y0 : y1 + hk - 1 + hWin - 1])
+    for w, bb in zip(weights, biases):
+        a = orc.spatial_convolution(a, w, bb)
+        b = orc.spatial_convolution(b, w, bb)
+    assert a.shape[1] == y1 - y0 and b.shape[1] == y1 - y0 + hWin - 1
+    vol = orc.spatial_matching(a, b, hWin, wWin)
+    idx0 = vol.reshape(vol.shape[0], vol.shape[1], -1).argmin(axis=2)
+    return {"volume": vol, "index": idx0 + 1, "yflow": (idx0 // wWin - tWin).astype(np.float32), "xflow": (idx0 % wWin - lWin).astype(np.float32)}
