@@ -406,6 +406,20 @@ int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int
 int dfe_feat_matching_flat_argmin(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, long long *idx, float *xflow,
                                   float *yflow, bool *handled);
 bool dfe_feat_matching_flat_argmin_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw);
+int dfe_feat_matching_flat_strided(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                   float *out, bool *handled);
+// what getModel's tail + processOutput leave per pair (opticalflow_model.lua:201-252): the centre-pasted full-frame flow and confidences,
+// optionally the per-pixel class index and extractOutput score over the model's own output region
+struct DfeSoftOut {
+    int use_threshold;             // 0: processOutput(geometry, out, true, nil);  1: ...(geometry, out, true, threshold)
+    float threshold;
+    int hFull, wFull;              // geometry.hImg, geometry.wImg
+    float *full, *full_conf;       // [2][hFull][wFull] (plane 0 = y), [hFull][wFull]: ZEROED by the caller; the kernel writes the pasted region
+    long long *index;              // [H1][W1] or NULL
+    float *scores;                 // [H1][W1] or NULL
+};
+int dfe_feat_matching_flat_soft(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                const DfeSoftOut *soft, bool *handled);
 bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw);   // the ctx / window conditions of the launcher below
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
                                   int maxw, float *const *out, float f16_scale, bool *handled, const struct CvFineArgs *fine = nullptr);
@@ -540,6 +554,34 @@ __device__ __forceinline__ float wave_sum_f32_ordered(float v) {
     DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);   // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
 #undef DFE_STEP
     return v;
+}
+
+// Reductions over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), partners at distance 8, 4, 2, 1: the soft-max of windows of more
+// than 64 cells gives a pixel to 16 lanes (softmin_body in multiscale.hip and the feature matcher's soft-max epilogue share this order,
+// so the one-call single-scale model equals the staged modules bit for bit)
+__device__ __forceinline__ float row16_max_f32(float v) {
+#define DFE_STEP(ctrl) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false)))
+    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);   // row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2]
+#undef DFE_STEP
+    return v;
+}
+__device__ __forceinline__ float row16_sum_f32_ordered(float v) {
+#pragma clang fp contract(off)
+#define DFE_STEP(ctrl) v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);
+#undef DFE_STEP
+    return v;
+}
+// (value, index) -> the row's largest value and, among equal values, the smallest index
+__device__ __forceinline__ void row16_argmax_first(float &b, int &bi) {
+#define DFE_STEP(ctrl)                                                                                        \
+    {                                                                                                         \
+        const float ob = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), ctrl, 0xf, 0xf, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(0, bi, ctrl, 0xf, 0xf, false);                             \
+        if (ob > b || (ob == b && oi < bi)) { b = ob; bi = oi; }                                              \
+    }
+    DFE_STEP(0x128); DFE_STEP(0x124); DFE_STEP(0x4E); DFE_STEP(0xB1);
+#undef DFE_STEP
 }
 
 // Eight wave reductions at once, "transposed": v[x] is pixel x's value in this lane's cell; the butterfly's first three steps pair

@@ -69,7 +69,17 @@ struct FfArgs {
     int lWin, tWin;
     int S;            // blocks per tile (1, or 2: the window's rows dealt to two half blocks that share a CU)
     int nd;           // window rows of a block = maxh / S
+    int pitch1;       // floats between rows of in1 (W1 for a contiguous map; more for a narrowed view: opticalflow_model.lua:147-149)
+    long long plane1; // floats between planes of in1
+    // SOFT (FF_SOFT): getModel's Minus -> SoftMax over the window and processOutput on it (opticalflow_model.lua:94-109,153-252)
+    int middle;       // 1-based index of the window's centre cell: ceil(maxw/2) + maxw * (ceil(maxh/2) - 1)
+    int use_thr;      // 0: arg-max with the centre tie-break, confidences 1;  1: extractOutput(p, 0.11) and scores > thr
+    float thr;
+    int wFull, ho, wo;                 // the centre paste: full / full_conf are [..][hFull][wFull], the output's pixel (y, x) lands at (ho + y, wo + x)
+    long long fullplane;               // hFull * wFull
+    float *full, *full_conf, *scores;  // [2][hFull][wFull] (plane 0 = y), [hFull][wFull], [H1][W1]; each may be NULL (idx above: [H1][W1])
 };
+enum { FF_VOLUME = 0, FF_ARGMIN = 1, FF_SOFT = 2 };
 
 template <int MW> struct FfGeom {
     static constexpr int PITCH = (64 * FF_PX + 2 * (MW - 1) + 8 + 3) / 4 * 4;   // floats per LDS tile row (piece A | piece B)
@@ -120,9 +130,10 @@ template <int NT> __device__ __forceinline__ void ff_glds_row(unsigned voff0, un
 // maxh <= 16: waves 0 .. maxh-1 each sweep one window row.  EXTRA (maxh == 17): 16 waves, row 16 as the extra task.
 // ARGMIN: no volume -- the arithmetic's result goes through the first-minimum decode of version2/test.lua:45-51 (FfArgs::idx / xflow /
 // yflow) instead of the copy-out: the volume of a 17 x 17 window on VGA features is 316 MB that the one-call model never reads back.
-template <int MW, bool EXTRA, bool ARGMIN = false>
+template <int MW, bool EXTRA, int MODE = FF_VOLUME>
 __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
 #pragma clang fp contract(off)
+    constexpr bool ARGMIN = MODE == FF_ARGMIN, SOFT = MODE == FF_SOFT;
     constexpr int PX = FF_PX;
     constexpr int PITCH = FfGeom<MW>::PITCH, NLOAD = FfGeom<MW>::NLOAD, NB4 = FfGeom<MW>::NB4;
     const int nd = EXTRA ? 16 : p.nd;                      // window rows of this block (a half tile: maxh / 2)
@@ -140,7 +151,8 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int dy = wave;
-    const long long plane1 = (long long)p.H1 * p.W1, plane2 = (long long)p.H2 * p.W2;
+    const long long plane1 = p.plane1, plane2 = (long long)p.H2 * p.W2;
+    const int pgap = p.pitch1 - p.W1;                       // floats between the end of an in1 row and the start of the next
     // Tiles of this block: tile (round r, virtual block vb) = r * gridDim.x + vb, where the virtual index puts the 32 blocks of an XCD
     // (the hardware deals linear block ids round-robin to the 8 XCDs) on 32 CONSECUTIVE tiles -- about 13 output rows of the frame,
     // all planes of whose in2 rows (2.4 MB) stay in that XCD's 4-MB L2 while its CUs, in step with each other, walk through the planes.
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
     //  L2 requests missed, 790 MB were fetched for 39 MB of in2 and every plane waited out a memory round trip: r04_g, r04_j.)
     const int nbx = gridDim.x;
     int vb = (int)blockIdx.x;
-    const int S = (!ARGMIN && !EXTRA) ? p.S : 1, lgS = S == 4 ? 2 : S == 2 ? 1 : 0;   // (the arg-min form and the 17-row window: always whole tiles)
+    const int S = (MODE == FF_VOLUME && !EXTRA) ? p.S : 1, lgS = S == 4 ? 2 : S == 2 ? 1 : 0;   // (the arg-min form and the 17-row window: always whole tiles)
     if (S > 1 && !(nbx & (8 * S - 1))) {
         // two blocks per CU: the dispatcher fills every CU once (blocks 0 .. nbx/2 - 1), then a second time (blocks b and b + nbx/2
         // share a CU: tools/ubench/cuid.hip, profiles/r04_ah_cu_residency.txt).  The second set takes the upper half of every round's
@@ -216,11 +228,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
         const int yr0 = min(y_first + dy0 + wave, p.H2 - 1), yr1 = min(y_first + dy0 + j1, p.H2 - 1);
         const char *rp0 = reinterpret_cast<const char *>(p.in2) + (long long)yr0 * p.W2 * 4;
         const char *rp1 = j1 < nrows ? reinterpret_cast<const char *>(p.in2) + (long long)yr1 * p.W2 * 4
-                                     : reinterpret_cast<const char *>(p.in1) + ((long long)y_first * p.W1 + xA0) * 4;
+                                     : reinterpret_cast<const char *>(p.in1) + ((long long)y_first * p.pitch1 + xA0) * 4;
         const long long pstep0 = plane2 * 4, pstep1 = (j1 < nrows ? plane2 : plane1) * 4;
         const bool last0 = yr0 == p.H2 - 1, last1 = j1 < nrows ? yr1 == p.H2 - 1 : y_first + 2 >= p.H1;   // may end at the end of the buffer (plane K-1)
         unsigned voff_a = 0;                                              // my 16-B piece of the in1 slots
-        if (j1 == nrows) { const int l = lane_fresh(); voff_a = 4u * (unsigned)(4 * l - (l >= nA ? padpx : 0)); }
+        if (j1 == nrows) { const int l = lane_fresh(); voff_a = 4u * (unsigned)(4 * l - (l >= nA ? padpx - pgap : 0)); }
         auto stage_row = [&](const char *rowp, lds_f *dst, bool careful) __attribute__((always_inline)) {
             if (careful) {                                                // (wave-uniform, once per frame)
 #pragma unroll
@@ -255,11 +267,11 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     // the in1 values of the tile's 256 pixel slots (group l, pixel q at slot 4 l + q): row y_first from xA0, then row
                     // y_first + 1 from column 0 -- linear in memory except for the W1p - W1 padding slots at the end of row y_first
                     if (last1) {
-                        const int lim = (int)plane1 - 1 - (y_first * p.W1 + xA0);
+                        const int lim = (p.H1 - 1 - y_first) * p.pitch1 + p.W1 - 1 - xA0;   // the map's last element, from the piece's first
 #pragma unroll
                         for (int m = 0; m < PX; ++m) {
                             const int e = lane_fresh() + 64 * m;
-                            ff_glds4(4u * (unsigned)min(e - (e >= nA * PX ? padpx : 0), lim), r1, tb + aoff + 64 * m);
+                            ff_glds4(4u * (unsigned)min(e - (e >= nA * PX ? padpx - pgap : 0), lim), r1, tb + aoff + 64 * m);
                         }
                     } else {
                         ff_glds16(voff_a, r1, tb + aoff);
@@ -439,6 +451,146 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                 if (p.xflow) p.xflow[px] = (float)(bi - fy * MW - p.lWin);
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the next tile's tables / planes overwrite the candidates
+        } else if constexpr (SOFT) {
+            // getModel's tail and processOutput on the costs while they are on the chip (opticalflow_model.lua:94-109: Minus -> SoftMax over
+            // the window; :153-169 getOutputConfidences; :201-252 decode and centre paste) -- the 300-MB volume of a VGA pair is never written,
+            // never re-read by three more passes.  One phase per pixel q of the groups, as in the copy-out: every lane deposits pixel q's window
+            // row in the LDS image [lane][WNP]; then SIXTEEN lanes take a window -- lane t of them the cells 64 j + 4 t + i (b128 reads) --
+            // and run softmin_body's arithmetic on it (multiscale.hip, windows of more than 64 cells: the same maximum, the same exponential,
+            // the same order of the sum, e * (1 / sum)), so the probabilities are the staged modules' bit for bit.  On them: the first maximum
+            // with the centre override (argbest_kernel<true>), or extractOutput's first 8 values above 0.11 in index order, its sorting
+            // network and its score (extract_kernel<8>), and the confidence score > threshold; the index is decoded (x2yx minus
+            // centered2onebased(0, 0)) and lands, with the confidence, at its place in the full-frame planes.
+            constexpr int NJ4 = (17 * MW + 63) / 64;                      // b128 pieces per lane, at most
+            lds_f *cand = img + 64 * WNP;                                 // [64 windows][8 values | 8 indices]
+            const int yoffc = (p.maxh + 1) / 2, xoffc = (MW + 1) / 2;     // centered2onebased(geometry, 0, 0)
+            static_for_q<0, PX>([&](auto qphase) {
+                constexpr int q = decltype(qphase)::value;
+                {
+                    lds_f *w = img + lane_fresh() * WNP + dy * MW;
+                    if constexpr (MW % 4 == 0) {
+#pragma unroll
+                        for (int d = 0; d < MW; d += 4) *(lds_f4 *)(w + d) = ff_f4{acc[q][d], acc[q][d + 1], acc[q][d + 2], acc[q][d + 3]};
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < MW; ++d) w[d] = acc[q][d];
+                    }
+                }
+                if constexpr (EXTRA) {
+                    const int pp = lane >> 2, lg = 4 * wave + (pp >> 2), c = lane & 3;
+                    if ((pp & 3) == q) {
+                        lds_f *w = img + lg * WNP + 16 * MW + 4 * c;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = accx[j];
+                        if (c == 3) w[4] = accx[4];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int l0 = 4 * wave; l0 < 64; l0 += 4 * NW) {          // (wave-uniform trip count: the ballots below need every lane)
+                    const int lf = lane_fresh(), g = lf >> 4, t = lf & 15, ll = l0 + g;
+                    const lds_f *wv = img + ll * WNP + 4 * t;
+                    float v[4 * NJ4];
+                    float m = -__int_as_float(0x7f800000);
+#pragma unroll
+                    for (int j = 0; j < NJ4; ++j) {
+                        ff_f4 c4 = ff_f4{0.f, 0.f, 0.f, 0.f};
+                        if (64 * j + 4 * t < WN) c4 = *(const lds_f4 *)(wv + 64 * j);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[4 * j + i] = c4[i];
+                            if (64 * j + 4 * t + i < WN) m = fmaxf(m, -c4[i]);
+                        }
+                    }
+                    m = row16_max_f32(m);
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const bool on = 64 * j + 4 * t + i < WN;
+                            const float e = on ? dfe_exp_nonpos(-v[4 * j + i] - m) : 0.f;
+                            v[4 * j + i] = e;
+                            if (on) s = s + e;
+                        }
+                    s = row16_sum_f32_ordered(s);
+                    const float inv = 1.0f / s;
+#pragma unroll
+                    for (int n = 0; n < 4 * NJ4; ++n) v[n] = v[n] * inv;   // (cells beyond the window: 0 * inv = 0, below every probability's use)
+                    const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
+                    const bool live = g0 + ll < p.NG && xg + q < p.W1;
+                    long long id;
+                    float score = 0.f, conf = 1.f;
+                    if (!p.use_thr) {
+                        // input:max(3), first maximum; where it equals the centre cell's probability the index is the centre's (:156-160)
+                        float b = v[0];
+                        int bi = 4 * t;
+#pragma unroll
+                        for (int j = 0; j < NJ4; ++j)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (64 * j + 4 * t + i < WN && v[4 * j + i] > b) { b = v[4 * j + i]; bi = 64 * j + 4 * t + i; }
+                        row16_argmax_first(b, bi);
+                        const float pc = dfe_exp_nonpos(-img[ll * WNP + p.middle - 1] - m) * inv;
+                        id = b == pc ? (long long)p.middle : (long long)bi + 1;
+                    } else {
+                        // extractoutput.extractOutput(input, scores, 0.11, imaxs): the first 8 probabilities above 0.11 in index order
+                        // (extract_output.cpp:83-110), sorted by its network, imaxs = the largest one's index, scores = the sum of the prefix sums
+                        lds_f *cw = cand + ll * 16;
+                        cw[t] = 0.f;
+                        int n = 0;
+#pragma unroll
+                        for (int j = 0; j < NJ4; ++j) {
+                            int before = 0, mine = 0;
+                            bool hit[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                hit[i] = 64 * j + 4 * t + i < WN && (double)v[4 * j + i] > 0.11;
+                                const unsigned gm = (unsigned)(__ballot(hit[i]) >> (16 * g)) & 0xffffu;
+                                before += __popc(gm & ((1u << t) - 1u));
+                                mine += __popc(gm);
+                            }
+                            int r = n + before;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (hit[i]) {
+                                    if (r < 8) { cw[r] = v[4 * j + i]; cw[8 + r] = (float)(64 * j + 4 * t + i + 1); }
+                                    ++r;
+                                }
+                            n += mine;
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the group's 16 lanes are lanes of this wave: its LDS operations are in order)
+                        float hv[8], hi[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { hv[k] = cw[k]; hi[k] = cw[8 + k]; }
+                        id = p.middle;                                     // nothing above 0.11: the reference leaves imaxs / scores as they were --
+                        if (hv[0] > 0) {                                   // defined here as the centre index and a zero score
+                            dfe_sort8(hv, hi);
+                            id = (long long)hi[0];
+#pragma unroll
+                            for (int k = 1; k < 8; ++k) hv[k] += hv[k - 1];
+                            double a = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) a += hv[k];
+                            score = (float)a;
+                        }
+                        conf = score > p.thr ? 1.f : 0.f;                  // scores:gt(threshold)
+                    }
+                    if (live && t == 0) {
+                        const int py = y_first + (ll >= nA ? 1 : 0), pxc = xg + q;
+                        const long long px = (long long)py * p.W1 + pxc;
+                        const int i0 = (int)id - 1, ty = i0 / MW;
+                        if (p.idx) p.idx[px] = id;
+                        if (p.scores) p.scores[px] = score;
+                        const long long fo = (long long)(p.ho + py) * p.wFull + p.wo + pxc;
+                        if (p.full) {
+                            p.full[fo] = (float)(ty + 1 - yoffc);
+                            p.full[p.fullplane + fo] = (float)(i0 - ty * MW + 1 - xoffc);
+                        }
+                        if (p.full_conf) p.full_conf[fo] = conf;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // before the next phase (or tile) overwrites the image
+            });
         } else
         static_for_q<0, PX>([&](auto qphase) {
             constexpr int q = decltype(qphase)::value;
@@ -538,42 +690,57 @@ static bool ff_shape_ok(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int
 bool dfe_feat_matching_flat_argmin_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw) { return ff_shape_ok(ctx, K, H1, W1, maxh, maxw); }
 
 // *handled stays false when the shape is not this kernel's (the caller goes on to the round-3 kernels)
-static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, long long *idx, float *xflow,
-                     float *yflow, bool *handled) {
-    const bool argmin = out == nullptr;
+static int ff_launch(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out,
+                     long long *idx, float *xflow, float *yflow, const DfeSoftOut *soft, bool *handled) {
+    const int mode = soft ? FF_SOFT : out ? FF_VOLUME : FF_ARGMIN;
+    const bool argmin = mode == FF_ARGMIN;
     *handled = false;
     if (!ff_shape_ok(ctx, K, H1, W1, maxh, maxw)) return DFE_OK;
     const int G = dfe_cdiv(W1, FF_PX);
     if (((uintptr_t)in1 | (uintptr_t)in2 | (uintptr_t)out) & 3) return DFE_OK;
+    if (pitch1 < W1 || plane1 < (long long)(H1 - 1) * pitch1 + W1 || plane1 >= (1ll << 29)) return DFE_OK;
     const long long NGl = (long long)H1 * G;
     FfArgs a{};
     a.in1 = in1; a.in2 = in2; a.out = out;
+    a.pitch1 = pitch1; a.plane1 = plane1;
     a.K = K; a.H1 = H1; a.W1 = W1; a.maxh = maxh; a.H2 = H1 + maxh - 1; a.W2 = W1 + maxw - 1;
     a.G = G; a.NG = (int)NGl; a.ntiles = dfe_cdiv(NGl, FF_GROUPS);
     a.idx = idx; a.xflow = xflow; a.yflow = yflow;
     a.lWin = (maxw + 1) / 2 - 1; a.tWin = (maxh + 1) / 2 - 1;            // version2/test.lua:18-19
+    if (soft) {
+        a.middle = (maxw + 1) / 2 + maxw * ((maxh + 1) / 2 - 1);           // getMiddleIndex: yx2x(centered2onebased(0, 0)), opticalflow_model.lua:12-14,28-43
+        a.use_thr = soft->use_threshold; a.thr = soft->threshold;
+        a.wFull = soft->wFull; a.fullplane = (long long)soft->hFull * soft->wFull;
+        a.ho = (soft->hFull - H1) / 2; a.wo = (soft->wFull - W1) / 2;    // processOutput: floor((hImg - h) / 2), :228-230
+        a.full = soft->full; a.full_conf = soft->full_conf; a.scores = soft->scores; a.idx = soft->index;
+        if ((soft->full || soft->full_conf) && (soft->hFull < H1 || soft->wFull < W1)) return DFE_OK;
+    }
     const bool extra = maxh == 17;
-    // two half blocks per tile and CU where the window's rows split evenly into halves of >= 4 waves (the arg-min form needs the whole
-    // window in one block; 17 rows = 17 waves do not fit a CU's registers as 9 + 8)
+    // two half blocks per tile and CU where the window's rows split evenly into halves of >= 4 waves (the arg-min and soft-max forms need
+    // the whole window in one block; 17 rows = 17 waves do not fit a CU's registers as 9 + 8)
     // (option fm_split: 0 whole tiles, 1 / 2 halves, 4 quarters; the launcher's own choice: quarters for few planes -- the copy-out is
     //  then a larger share of a tile, K = 10: 0.102 -> 0.098 ms, time_matching.lua's shape 0.024 -> 0.022 -- else halves, which cost
     //  less staging: profiles/r04_ao_fm_quarters.txt)
     const int want = ctx->opt[DFE_OPT_FM_SPLIT] < 0 ? (K <= 16 ? 4 : 2) : ctx->opt[DFE_OPT_FM_SPLIT] == 1 ? 2 : ctx->opt[DFE_OPT_FM_SPLIT];
-    const bool can = !argmin && !extra;
+    const bool can = mode == FF_VOLUME && !extra;
     a.S = can && want >= 4 && maxh == 16 ? 4 : can && want >= 2 && maxh >= 8 && maxh % 2 == 0 ? 2 : 1;
     a.nd = extra ? 16 : maxh / a.S;
     const int NW = a.nd;
     const int PITCH = maxw == 17 ? FfGeom<17>::PITCH : FfGeom<16>::PITCH;
     const int WNP = ff_wnp((extra ? 17 : a.nd) * maxw);
     // the copy-out image [64][WNP]; the arg-min form keeps its candidates there instead -- cv[256][NC] and ci[256][NC], NC = 16 (20 with
-    // the extra task) whatever the window's height: larger than the image of a window of fewer than 8 rows
-    const size_t img_floats = std::max((size_t)64 * WNP, argmin ? (size_t)2 * 256 * (extra ? 20 : 16) : (size_t)0);
+    // the extra task) whatever the window's height: larger than the image of a window of fewer than 8 rows; the soft-max form reads its
+    // windows in 16-B pieces up to cell 4 * 16 * ceil(WN / 64) of the last window and keeps extractOutput's candidates [64][16] behind
+    const size_t img_floats = mode == FF_SOFT ? (size_t)64 * WNP + 64 * 16 + 64
+                                              : std::max((size_t)64 * WNP, argmin ? (size_t)2 * 256 * (extra ? 20 : 16) : (size_t)0);
     const size_t lds = ((size_t)3 * (extra ? 18 : a.nd + 1) * PITCH + 3 * 64 * FF_PX + 64 + img_floats) * sizeof(float);
     if (lds * a.S > 160 * 1024) return DFE_OK;
-    void (*kern)(FfArgs) = argmin ? (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, true> : feat_matching_flat_kernel<17, false, true>)
-                                                : feat_matching_flat_kernel<16, false, true>)
-                                  : (maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>)
-                                                : feat_matching_flat_kernel<16, false>);
+    void (*kern)(FfArgs);
+    if (mode == FF_SOFT) kern = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, FF_SOFT> : feat_matching_flat_kernel<17, false, FF_SOFT>)
+                                           : feat_matching_flat_kernel<16, false, FF_SOFT>;
+    else if (argmin) kern = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true, FF_ARGMIN> : feat_matching_flat_kernel<17, false, FF_ARGMIN>)
+                                       : feat_matching_flat_kernel<16, false, FF_ARGMIN>;
+    else kern = maxw == 17 ? (extra ? feat_matching_flat_kernel<17, true> : feat_matching_flat_kernel<17, false>) : feat_matching_flat_kernel<16, false>;
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nblk = (a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu) * a.S;
     {
@@ -581,7 +748,7 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
         hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), lds, ctx->stream, a);
     }
     DFE_LAUNCH_CHECK(ctx);
-    ctx->last_kernel = argmin ? "feat_matching_flat_kernel+argmin" : "feat_matching_flat_kernel";
+    ctx->last_kernel = mode == FF_SOFT ? "feat_matching_flat_kernel+softmax" : argmin ? "feat_matching_flat_kernel+argmin" : "feat_matching_flat_kernel";
     *handled = true;
     return DFE_OK;
 }
@@ -589,11 +756,27 @@ static int ff_launch(dfe_ctx *ctx, const float *in1, const float *in2, int K, in
 int dfe_feat_matching_flat(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out, bool *handled) {
     *handled = false;
     if (!out) return DFE_OK;
-    return ff_launch(ctx, in1, in2, K, H1, W1, maxh, maxw, out, nullptr, nullptr, nullptr, handled);
+    return ff_launch(ctx, in1, W1, (long long)H1 * W1, in2, K, H1, W1, maxh, maxw, out, nullptr, nullptr, nullptr, nullptr, handled);
+}
+
+// in1 as a view: rows pitch1 floats apart, planes plane1 floats apart (prepareInput's narrow of a feature map, opticalflow_model.lua:147-149)
+int dfe_feat_matching_flat_strided(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                   float *out, bool *handled) {
+    *handled = false;
+    if (!out) return DFE_OK;
+    return ff_launch(ctx, in1, pitch1, plane1, in2, K, H1, W1, maxh, maxw, out, nullptr, nullptr, nullptr, nullptr, handled);
 }
 
 // nn.SpatialMatching(maxh, maxw) + `min` over the window + the decode of version2/test.lua:45-51, without the volume
 int dfe_feat_matching_flat_argmin(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, long long *idx, float *xflow,
                                   float *yflow, bool *handled) {
-    return ff_launch(ctx, in1, in2, K, H1, W1, maxh, maxw, nullptr, idx, xflow, yflow, handled);
+    return ff_launch(ctx, in1, W1, (long long)H1 * W1, in2, K, H1, W1, maxh, maxw, nullptr, idx, xflow, yflow, nullptr, handled);
+}
+
+// nn.SpatialMatching -> nn.Minus -> SoftMax over the window -> processOutput, without the volume (the FF_SOFT epilogue)
+int dfe_feat_matching_flat_soft(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
+                                const DfeSoftOut *soft, bool *handled) {
+    *handled = false;
+    if (!soft) return DFE_OK;
+    return ff_launch(ctx, in1, pitch1, plane1, in2, K, H1, W1, maxh, maxw, nullptr, nullptr, nullptr, nullptr, soft, handled);
 }

@@ -251,23 +251,29 @@ __device__ __forceinline__ void softmin_body(const float *__restrict__ cost, lon
         }
         return;
     }
-    for (long long p = (long long)blockIdx.x * kWaves + (threadIdx.x >> 6); p < P; p += (long long)gridDim.x * kWaves) {
+    // windows of more than 64 cells (the single-scale models: 16 x 16, 17 x 17, 33 x 33): SIXTEEN lanes per pixel, lane t of them takes
+    // the cells 64 j + 4 t + i (i < 4) -- 256 contiguous bytes per 16 lanes and step -- and sums their exponentials in that order; the
+    // 16 partial sums meet over partners at distance 8, 4, 2, 1.  The feature matcher's soft-max epilogue (feat_matching_flat.hip,
+    // FF_SOFT) reads a pixel's window from LDS in the same pattern: the same association, the same bits.
+    const int t = lane & 15;
+    for (long long p = ((long long)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 4 + (lane >> 4); p < P; p += (long long)gridDim.x * kWaves * 4) {
         const float *c = cost + p * N;
         float *o = prob + p * N;
         float m = -INFINITY;
-        for (int n = lane; n < N; n += 64) m = fmaxf(m, -c[n]);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        for (int n0 = 4 * t; n0 < N; n0 += 64)
+            for (int i = 0; i < 4 && n0 + i < N; ++i) m = fmaxf(m, -c[n0 + i]);
+        m = row16_max_f32(m);
         float s = 0.f;
-        for (int n = lane; n < N; n += 64) {
-            float e = dfe_exp_nonpos(-c[n] - m);
-            o[n] = e;
-            s += e;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        for (int n0 = 4 * t; n0 < N; n0 += 64)
+            for (int i = 0; i < 4 && n0 + i < N; ++i) {
+                const float e = dfe_exp_nonpos(-c[n0 + i] - m);
+                o[n0 + i] = e;
+                s = s + e;
+            }
+        s = row16_sum_f32_ordered(s);
         const float inv = 1.0f / s;
-        for (int n = lane; n < N; n += 64) o[n] *= inv;
+        for (int n0 = 4 * t; n0 < N; n0 += 64)
+            for (int i = 0; i < 4 && n0 + i < N; ++i) o[n0 + i] *= inv;
     }
 }
 
@@ -1352,7 +1358,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
         nsoft = nratios - 1;
     }
     if (soft_max > 0 && nsoft > 0 && !soft_done) {   // (soft_done: the volume launch has taken the coarser scales' soft-mins)
-        hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 1)), nsoft), dim3(kWaves * 64), 0, ctx->stream, ss, N);
+        hipLaunchKernelGGL(softmin_scales_kernel, dim3(grid1d(soft_max, kWaves * (N <= 64 ? 8 : 4)), nsoft), dim3(kWaves * 64), 0, ctx->stream, ss, N);
         DFE_LAUNCH_CHECK(ctx);
     }
     g.H = H; g.W = W;
@@ -1408,7 +1414,7 @@ int dfe_softmin_f32(dfe_ctx *ctx, const float *cost, int64_t P, int N, float *pr
     DFE_REQUIRE(ctx, P >= 0 && N > 0, DFE_E_SHAPE, "dfe_softmin_f32: P=%lld N=%d", (long long)P, N);
     if (P == 0) return DFE_OK;
     DFE_REQUIRE(ctx, cost && prob, DFE_E_ARG, "dfe_softmin_f32: NULL tensor");
-    hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves * (N <= 64 ? 8 : 1))), dim3(kWaves * 64), 0, ctx->stream, cost, (long long)P, N, prob);
+    hipLaunchKernelGGL(softmin_kernel, dim3(grid1d(P, kWaves * (N <= 64 ? 8 : 4))), dim3(kWaves * 64), 0, ctx->stream, cost, (long long)P, N, prob);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

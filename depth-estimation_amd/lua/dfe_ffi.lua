@@ -64,6 +64,8 @@ int dfe_cascade_flow_f32(dfe_ctx *ctx, const float *const *prob, const int *rati
 int dfe_multiscale_flow_pair_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float *flow, int64_t *idx);
 int dfe_multiscale_flow_pair_f16(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float scale, float *flow, int64_t *idx);
 int dfe_multiscale_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, int maxh, int maxw, const int *ratios, int nratios, const dfe_filter_layer *layers, int nlayers, int share_filters, float f16_scale, float *flow, int64_t *idx);
+int dfe_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, const dfe_filter_layer *layers, int nlayers, int maxh, int maxw, int use_threshold, double threshold, int hImg, int wImg, float *full, float *full_conf, int64_t *index, float *scores);
+int dfe_spatial_matching_strided_f32(dfe_ctx *ctx, const float *in1, int in1_pitch, int64_t in1_plane, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *out);
 int dfe_cascading_add_backward_f32(dfe_ctx *ctx, const float *const *gradOut, const int *ratios, int nratios, int64_t P, int maxh, int maxw, float *const *gradIn);
 int dfe_cascade_ring_f32(dfe_ctx *ctx, const float *const *prob, const int *ratios, int nratios, int H, int W, int maxh, int maxw, float *out);
 int dfe_polar_grid_c2p_f32(dfe_ctx *ctx, int wsrc, int hsrc, int wdst, int hdst, float xcenter, float ycenter, int lpadding, int rpadding, float rmax, float alpha, float *mask);

@@ -399,4 +399,67 @@ def getModel(geometry, full_image=True, prefiltered=False, device="cuda", genera
         model.add(glue.Log2(1e-10))
     # model:getWeights() (:119-125): the first filter branch's, nothing when prefiltered
     model.getWeights = (lambda: {}) if prefiltered else (lambda: filter_weights(model.modules[0].modules[0]))
+    model.forwardFlow = lambda input, threshold=None, one_call=True: single_scale_forward_flow(model, g, input, threshold, one_call, prefiltered)
     return model
+
+
+def single_scale_forward_flow(model, geometry, input, threshold=None, one_call=True, prefiltered=False):
+    """What the drivers do with a single-scale model per frame pair (depth_estimation_opticalflow.lua:103-116, depth_estimation_api.lua:
+    164-168): input = prepareInput(geometry, patch1, patch2); moutput = model:forward(input); processOutput(geometry, moutput, true,
+    threshold).  `input` here is the PAIR BEFORE prepareInput -- frames [C][H][W] for getModel(geometry, true, false), feature maps for
+    the prefiltered model -- because the narrow is part of what the one-call entry fuses.
+      one_call=True: dfe_flow_pair_filtered_f32 -- filter stack of both frames, the narrow, matcher, Minus / SoftMax, the arg-max with the
+        centre tie-break or extractOutput, decode and centre paste; with 16- / 17-wide windows the volume is never written;
+      one_call=False: the modules, then processOutput -- the same results bit for bit.
+    Returns processOutput's table: index, confidences, y, x, full, full_confidences (+ scores with a threshold)."""
+    from .opticalflow_model import prepareInput, processOutput, _g
+    from .multiscale import filter_layers_array
+
+    a, b = input
+    g = geometry
+    maxh, maxw = _g(g, "maxh"), _g(g, "maxw")
+    if _g(g, "output_extraction_method", "max") != "max" or len(model.modules) != (3 if prefiltered else 4) or not one_call:
+        # ('mean' extraction, training mode, or a model whose module list a caller has patched: module by module)
+        if prefiltered:
+            inp = prepareInput(dict(g, prefilter=True) if isinstance(g, dict) else g, a, b)
+        else:
+            # the narrow applies to the FEATURES (prepareInput is called on filter outputs, depth_estimation_opticalflow.lua:66-106): the
+            # frames go through the model's own filter branches whole and patch 1's features are narrowed in between
+            par = model.modules[0]
+            f1, f2 = par.modules[0].forward(a), par.modules[1].forward(b)
+            y0, x0 = math.ceil(maxh / 2) - 1, math.ceil(maxw / 2) - 1
+            inp = [f1[:, y0 : y0 + f1.shape[1] - maxh + 1, x0 : x0 + f1.shape[2] - maxw + 1], f2]
+        out = inp
+        for m in (model.modules if prefiltered else model.modules[1:]):
+            out = m.forward(out)
+        return processOutput(g, out, True, threshold)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or tuple(a.shape) != tuple(b.shape) or a.dim() != 3:
+        raise TypeError("forwardFlow: two float32 C x H x W tensors of one size expected")
+    a, b = a.contiguous(), b.contiguous()
+    Cc, H, W = a.shape
+    if prefiltered:
+        arr, nl, keep, hk, wk = None, 0, None, 1, 1
+    else:
+        arr, nl, keep = filter_layers_array([model.modules[0].modules[0]])
+        layers = _g(g, "layers")
+        hk, wk = 1 + sum(l[2] - 1 for l in layers), 1 + sum(l[1] - 1 for l in layers)
+    H1, W1 = H - hk + 1 - maxh + 1, W - wk + 1 - maxw + 1
+    if H1 <= 0 or W1 <= 0:
+        raise ValueError("forwardFlow: frame %dx%d too small" % (H, W))
+    hImg, wImg = _g(g, "hImg"), _g(g, "wImg")
+    dev = a.device
+    full = torch.empty((2, hImg, wImg), dtype=torch.float32, device=dev)
+    fc = torch.empty((hImg, wImg), dtype=torch.float32, device=dev)
+    idx = torch.empty((H1, W1), dtype=torch.int64, device=dev)
+    sc = torch.empty((H1, W1), dtype=torch.float32, device=dev) if threshold is not None else None
+    ctx = get_ctx(a)
+    ctx.check(lib().dfe_flow_pair_filtered_f32(ctx.handle, ptr(a), ptr(b), Cc, H, W, arr, nl, maxh, maxw, 0 if threshold is None else 1,
+                                               float(threshold or 0.0), hImg, wImg, ptr(full), ptr(fc), ptr(idx), ptr(sc)))
+    del keep
+    ho, wo = (hImg - H1) // 2, (wImg - W1) // 2
+    ret = {"index": idx, "full": full, "full_confidences": fc,
+           "y": full[0, ho : ho + H1, wo : wo + W1].to(torch.int64), "x": full[1, ho : ho + H1, wo : wo + W1].to(torch.int64),
+           "confidences": fc[ho : ho + H1, wo : wo + W1]}
+    if sc is not None:
+        ret["scores"] = sc
+    return ret

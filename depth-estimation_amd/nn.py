@@ -78,7 +78,13 @@ class SpatialMatching(Module):
 
     def updateOutput(self, input):
         in1, in2 = input
-        in1, in2 = _f32c(in1, "input[1]"), _f32c(in2, "input[2]")
+        # patch 1 is usually prepareInput's narrow of a feature map (opticalflow_model.lua:147-149), i.e. a VIEW: rows and planes at the
+        # parent's strides.  It is handed to the matcher as it is (dfe_spatial_matching_strided_f32) instead of being copied first.
+        view = (in1.dim() == 3 and in1.dtype == torch.float32 and not in1.is_contiguous() and in1.stride(2) == 1 and in1.stride(1) >= in1.shape[2]
+                and in1.stride(0) >= (in1.shape[1] - 1) * in1.stride(1) + in1.shape[2])
+        if not view:
+            in1 = _f32c(in1, "input[1]")
+        in2 = _f32c(in2, "input[2]")
         K, H1, W1 = in1.shape
         if tuple(in2.shape) != (K, H1 + self.maxh - 1, W1 + self.maxw - 1):
             raise ValueError(
@@ -87,7 +93,10 @@ class SpatialMatching(Module):
             )
         ctx = get_ctx(in1)
         out = torch.empty((H1, W1, self.maxh, self.maxw), dtype=torch.float32, device=in1.device)
-        ctx.check(lib().dfe_spatial_matching_f32(ctx.handle, ptr(in1), ptr(in2), K, H1, W1, self.maxh, self.maxw, ptr(out)))
+        if view:
+            ctx.check(lib().dfe_spatial_matching_strided_f32(ctx.handle, in1.data_ptr(), in1.stride(1), in1.stride(0), ptr(in2), K, H1, W1, self.maxh, self.maxw, ptr(out)))
+        else:
+            ctx.check(lib().dfe_spatial_matching_f32(ctx.handle, ptr(in1), ptr(in2), K, H1, W1, self.maxh, self.maxw, ptr(out)))
         self.output = out
         return out
 

@@ -145,7 +145,8 @@ def prepareInput(geometry, patch1, patch2, literal_rgb2y=False):
         return [patch1, patch2]
     maxh, maxw = _g(geometry, "maxh"), _g(geometry, "maxw")
     y0, x0 = math.ceil(maxh / 2) - 1, math.ceil(maxw / 2) - 1                  # narrow(2, ceil(maxh/2), H - maxh + 1), 1-based
-    p1 = patch1[:, y0 : y0 + patch1.shape[1] - maxh + 1, x0 : x0 + patch1.shape[2] - maxw + 1].contiguous()
+    # (a view, as torch's narrow is: nn.SpatialMatching reads it in place -- dfe_spatial_matching_strided_f32)
+    p1 = patch1[:, y0 : y0 + patch1.shape[1] - maxh + 1, x0 : x0 + patch1.shape[2] - maxw + 1]
     return [p1, patch2]
 
 

@@ -357,6 +357,32 @@ int dfe_multiscale_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const f
                                           const int *ratios, int nratios, const dfe_filter_layer *layers, int nlayers,
                                           int share_filters, float f16_scale, float *flow, int64_t *idx);
 
+/* ---- the single-scale trained model in one call: A15 + A1 + A3 + A6/A7 + A9 + A11 ------------------------------------------- */
+/* replaces: what depth_estimation_opticalflow.lua:66-116 (and depth_estimation_api.lua:164-168, test_opticalflow.lua:347-355) run per
+ *   frame pair for a model that is not multiscale --
+ *     filter:forward(frame) of both frames          getFilter(geometry), opticalflow_model.lua:45-79
+ *     prepareInput(geometry, last_im, im)           :131-151: patch 1 narrowed to rows ceil(maxh/2) .. (H - maxh + 1 of them), columns alike
+ *     model:forward(input)                          getModel(geometry, true, true), :81-129: SpatialMatching(maxh, maxw) -> Minus -> SoftMax over the window
+ *     processOutput(geometry, moutput, true, thr)   :201-252: without threshold the first maximum with the centre tie-break (:153-161), confidences 1;
+ *                                                   with one extractoutput.extractOutput(p, scores, 0.11, imaxs) and confidences = scores > thr (:163-167);
+ *                                                   y, x = x2yx(index) - centered2onebased(0, 0); both pasted at floor((hImg - h) / 2), floor((wImg - w) / 2)
+ *   I0, I1 [C][H][W] frames; layers: HOST array of the filter stack (C = layers[0].nIn).  nlayers == 0: I0 / I1 ARE the feature maps
+ *   (geometry.prefilter: the caller keeps each frame's features for the next pair, as the script does) and patch 1's narrow is taken as a
+ *   view of I0, no copy.  The output region is H1 x W1 = (H - hKernel + 1 - maxh + 1) x (W - wKernel + 1 - maxw + 1).
+ *   Outputs (each may be NULL): full [2][hImg][wImg] (plane 0 = y, plane 1 = x; zero outside the pasted region), full_conf [hImg][wImg],
+ *   index [H1][W1] int64 1-based class ids, scores [H1][W1] extractOutput's score (0 without threshold).  Pixels where no probability
+ *   exceeds 0.11 -- imaxs / scores uninitialised in the reference -- get index = the centre class and score 0.
+ *   16- / 17-wide windows on maps at least 253 columns wide never write the volume (the matcher's soft-max epilogue); other shapes go
+ *   through the stand-alone ops.  Either way the results equal the module path's (getModel():forward + processOutput) bit for bit. */
+int dfe_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const float *I1, int C, int H, int W, const dfe_filter_layer *layers, int nlayers,
+                               int maxh, int maxw, int use_threshold, double threshold, int hImg, int wImg, float *full, float *full_conf,
+                               int64_t *index, float *scores);
+/* replaces: nn.SpatialMatching(maxh, maxw, false):forward({patch1, patch2}) where patch1 is the NARROW of a larger map
+ *   (prepareInput, opticalflow_model.lua:147-149: `patch1:narrow(2, ..):narrow(3, ..)` is a view; nnx made it contiguous inside the
+ *   module): in1 is read in place, rows in1_pitch floats apart and planes in1_plane floats apart.  Same output as dfe_spatial_matching_f32. */
+int dfe_spatial_matching_strided_f32(dfe_ctx *ctx, const float *in1, int in1_pitch, int64_t in1_plane, const float *in2, int K, int H1, int W1,
+                                     int maxh, int maxw, float *out);
+
 /* ---- A4b: nn.CascadingAddTable:updateGradInput --------------------------------------------- */
 /* replaces: CascadingAddTable.lua:137-154 (HEAD's graph has no trainable parameters in it: Mul2 / Power are
  *   commented out, :29,46,57 -- accGradParameters is a no-op).  gradOut[s], gradIn[s]: [P][maxh][maxw];

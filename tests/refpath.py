@@ -303,3 +303,42 @@ def version2_band_oracle(prev, cur, datap, weights, biases, y0, y1, threshold=1e
     vol = orc.spatial_matching(a, b, hWin, wWin)
     idx0 = vol.reshape(vol.shape[0], vol.shape[1], -1).argmin(axis=2)
     return {"volume": vol, "index": idx0 + 1, "yflow": (idx0 // wWin - tWin).astype(np.float32), "xflow": (idx0 % wWin - lWin).astype(np.float32)}
+
+
+def single_scale_flow_oracle(f0, f1, layers, maxh, maxw, hImg, wImg, threshold=None):
+    """depth_estimation_opticalflow.lua:66-116 for a single-scale model, on the oracle: filter:forward of both frames (layers: list of
+    dicts as filter_stack_oracle takes them; empty = the inputs are feature maps already), prepareInput's narrow of patch 1
+    (opticalflow_model.lua:147-149), getModel(geometry, true, true):forward = SpatialMatching -> Minus -> SoftMax over the window
+    (:81-129), processOutput(geometry, out, true, threshold) (:201-252): the first maximum with the centre tie-break, or
+    extractOutput(p, 0.11) and scores > threshold (imaxs = centre, scores = 0 where nothing exceeds 0.11: SURVEY appendix A); the
+    decode x2yx - centered2onebased(0, 0); the centre paste.  Returns dict(volume, prob, index, scores, y, x, confidences, full,
+    full_confidences)."""
+    import math
+    from tests import oracle as orc
+
+    a = filter_stack_oracle(f0, layers) if layers else np.ascontiguousarray(f0, np.float32)
+    b = filter_stack_oracle(f1, layers) if layers else np.ascontiguousarray(f1, np.float32)
+    y0, x0 = math.ceil(maxh / 2) - 1, math.ceil(maxw / 2) - 1
+    a = np.ascontiguousarray(a[:, y0 : y0 + a.shape[1] - maxh + 1, x0 : x0 + a.shape[2] - maxw + 1])
+    vol = orc.spatial_matching(a, b, maxh, maxw)
+    H1, W1 = vol.shape[:2]
+    N = maxh * maxw
+    prob = orc.softmin(vol.reshape(-1, N)).reshape(H1, W1, N)
+    middle = math.ceil(maxw / 2) + maxw * (math.ceil(maxh / 2) - 1)
+    scores = np.zeros((H1, W1), np.float32)
+    if threshold is None:
+        idx, _ = orc.argbest_center(prob, middle, True)
+        conf = np.ones((H1, W1), np.float32)
+    else:
+        idx = np.full((H1, W1), middle, np.int64)
+        orc.extract_output(prob, 0.11, idx, scores)
+        conf = (scores > np.float32(threshold)).astype(np.float32)
+    y = (idx - 1) // maxw + 1 - math.ceil(maxh / 2)
+    x = (idx - 1) % maxw + 1 - math.ceil(maxw / 2)
+    ho, wo = (hImg - H1) // 2, (wImg - W1) // 2
+    full = np.zeros((2, hImg, wImg), np.float32)
+    full[0, ho : ho + H1, wo : wo + W1] = y
+    full[1, ho : ho + H1, wo : wo + W1] = x
+    fc = np.zeros((hImg, wImg), np.float32)
+    fc[ho : ho + H1, wo : wo + W1] = conf
+    return dict(volume=vol, prob=prob, index=idx, scores=scores, y=y, x=x, confidences=conf, full=full, full_confidences=fc)

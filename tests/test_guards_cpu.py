@@ -66,9 +66,8 @@ def test_flat_matcher_kernels_do_not_spill_in_the_plane_loop():
     extra task at <= 16 B (three values parked around the plane loop, none inside it: checked on the ISA when it was written)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kres.py"), os.path.join(ROOT, "depth-estimation_amd", "csrc", "feat_matching_flat.hip"), "flat"],
                          capture_output=True, text=True).stdout
-    vals = [tuple(int(x) for x in m) for m in re.findall(r"VGPR (\d+) scratch (\d+) sgpr-spill (\d+)", out)]
-    assert len(vals) == 6, out
-    # (instantiation order in the object: the arg-min forms <17, true>, <17, false>, <16, false>, then the volume forms in the same order)
-    assert all(v[0] <= 128 for v in vals)
-    assert vals[0][1] <= 40 and vals[3][1] <= 16, vals
-    assert all(vals[i][1] == 0 for i in (1, 2, 4, 5)), vals
+    vals = {m[0]: tuple(int(x) for x in m[1:]) for m in re.findall(r"feat_matching_flat_kernel<([^>]*)>\s+VGPR (\d+) scratch (\d+) sgpr-spill (\d+)", out)}
+    assert len(vals) == 9, out          # <MW, EXTRA, MODE>: 16 / 17 wide, 17 wide with the extra row; volume (0), arg-min (1), soft-max (2)
+    assert all(v[0] <= 128 for v in vals.values())
+    assert vals["17, true, 1"][1] <= 40 and vals["17, true, 0"][1] <= 16 and vals["17, true, 2"][1] <= 16, vals
+    assert all(v[1] == 0 for k, v in vals.items() if "true" not in k), vals

@@ -23,4 +23,7 @@ for line in out.splitlines():
         cur[k] = v
         if k.startswith("LDS") and pat in cur["name"]:
             n = subprocess.run(["c++filt", cur["name"]], capture_output=True, text=True).stdout.strip()
-            print("%-70s VGPR %s scratch %s sgpr-spill %s" % (n.split("(")[0][-70:], cur.get("VGPRs"), cur.get("ScratchSize [bytes/lane]"), cur.get("SGPRs Spill")))
+            n = n.replace("(anonymous namespace)::", "")
+            short = re.sub(r"^void ", "", n)
+            short = short[: short.rindex("(")] if "(" in short else short
+            print("%-70s VGPR %s scratch %s sgpr-spill %s" % (short[-70:], cur.get("VGPRs"), cur.get("ScratchSize [bytes/lane]"), cur.get("SGPRs Spill")))
