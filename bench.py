@@ -76,6 +76,12 @@ LEARNED_SINGLE = {
     "version2-vga": (480, 640, 17, [(3, 17, 17, 32)], 17),
     "version2-180p": (180, 320, 17, [(3, 17, 17, 32)], 17),      # version2/test.lua's own datap: 320 x 180
     "time-matching": (180, 320, 0, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
+    # getModel + processOutput as depth_estimation_opticalflow.lua:103-116 runs them for a single-scale model, in ONE call
+    # (dfe_flow_pair_filtered_f32): the stack of time_matching.lua:13 on both frames, prepareInput's narrow, SpatialMatching(16, 16),
+    # Minus / SoftMax, arg-max with the centre tie-break (nk = -1) or extractOutput + threshold 0.11 (nk = -2), decode, centre paste
+    "vga-learned": (480, 640, -1, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
+    "vga-learned-thr": (480, 640, -2, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
+    "720p-learned": (720, 1280, -1, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
 }
 VALU_RATE_PER_CU = 1.6   # wave-instructions per cycle and CU for plain fp32 register ops (tools/ubench/valu2.hip), 256 CUs at 2.4 GHz
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -590,6 +596,21 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
                 ev[3].record()
                 torch.cuda.synchronize()
                 stage["filter"] += ev[0].elapsed_time(ev[1]); stage["match"] += ev[1].elapsed_time(ev[2]); stage["min"] += ev[2].elapsed_time(ev[3]); stage["n"] += 1
+    elif nk < 0:
+        geometry = dict(maxh=win, maxw=win, layers=[list(l) for l in layers], multiscale=False, output_extraction_method="max", hImg=H, wImg=W)
+        model = d.getModel(geometry, True, False, device=dev, generator=g)
+        f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=rank, max_flow=6)
+        prev, cur = torch.from_numpy(f0 / np.float32(255)).to(dev), torch.from_numpy(f1 / np.float32(255)).to(dev)
+        from depth_estimation_amd.multiscale import filter_layers_array
+
+        arr, nl, keep = filter_layers_array([model.modules[0].modules[0]])
+        H1, W1 = H - (hk - 1) - (win - 1), W - (wk - 1) - (win - 1)
+        full, fconf = torch.empty((2, H, W), device=dev), torch.empty((H, W), device=dev)
+        use_thr, thr = (1, 0.11) if nk == -2 else (0, 0.0)
+
+        def step(timed=False):
+            ctx.check(lib.dfe_flow_pair_filtered_f32(ctx.handle, prev.data_ptr(), cur.data_ptr(), 3, H, W, arr, nl, win, win, use_thr, thr, H, W,
+                                                     full.data_ptr(), fconf.data_ptr(), None, None))
     else:
         datap = d.version2.defaultDatap(wImg=W, hImg=H, normalization_k=nk, layers=layers, wWin=win, hWin=win)
         net = d.version2.getNetwork(datap, device=dev, generator=g)
@@ -631,7 +652,8 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
         stages = {nm: round(sm[i] / 10, 4) for i, nm in enumerate(("load", "filter", "match", "extract"))}
     if rank == 0:
         out_elems = H1 * W1 * win * win
-        balg = (K * H1 * W1 + K * (H1 + win - 1) * (W1 + win - 1) + out_elems) * 4
+        fused_tail = nk < 0 or (nk > 0 and kernel.endswith("+argmin"))        # no volume leaves the matcher: its HBM bytes are the two feature maps
+        balg = (K * H1 * W1 + K * (H1 + win - 1) * (W1 + win - 1) + (0 if fused_tail else out_elems) + (4 * H1 * W1 if fused_tail else 0)) * 4
         kern_s = ms.value / 1e3 / max(n.value, 1)
         step_s = elapsed / args.steps
         laneops = 3.0 * K * out_elems
@@ -640,12 +662,15 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
         bound = "valu" if valu_s > hbm_s else "hbm"
         print(json.dumps({
             "metric": "Mpixels/s dense flow, %dx%d pair, learned single-scale model (%s), %dx%d window" % (
-                W, H, "tests/time_matching.lua" if tm else "version2/network.lua", win, win),
+                W, H, "tests/time_matching.lua" if tm else "opticalflow_model.lua getModel + processOutput" if nk < 0 else "version2/network.lua", win, win),
             "value": round(world * args.steps * H * W / elapsed / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(step_s * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("tests/time_matching.lua:5-47: getFilter %s (tanh between, random-init) on two randn 3x%dx%d frames, prepareInput narrow, "
                                     "nn.SpatialMatching(%d,%d) on %d planes %dx%d, min over the script's Reshape(256, %d, %d) view" % (layers, H, W, win, win, K, W1, H1, W1, H1)) if tm else
+                                   ("depth_estimation_opticalflow.lua:103-116 for a single-scale model in one call (dfe_flow_pair_filtered_f32): getFilter %s (tanh between, "
+                                    "random-init) on both frames, prepareInput narrow, SpatialMatching(%d,%d) on %d planes %dx%d -> Minus -> SoftMax, processOutput(geometry, out, "
+                                    "true, %s), no volume in HBM" % (layers, win, win, K, W1, H1, "0.11" if nk == -2 else "nil")) if nk < 0 else
                                    ("version2/test.lua:40-53 in one call (dfe_version2_flow_pair_f32): SpatialContrastiveNormalization(3, gaussian1D(%d)) on both frames, crop, "
                                     "SpatialConvolution %s (shared, random-init), SpatialMatching(%d,%d) on %d planes %dx%d, first-min decode" % (nk, layers, win, win, K, W1, H1)),
                        "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single", "stage_ms": stages},

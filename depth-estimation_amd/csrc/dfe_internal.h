@@ -171,6 +171,8 @@ int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_lay
 // the same layer position of n independent inputs (both frames of every pyramid scale) in ONE launch where a batched kernel exists
 int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W,
                                    float *const *out);
+int dfe_filter_layer_forward_batch_view(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, const int *in_pitch,
+                                        const long long *in_plane, float *const *out, bool *done);
 // nn.SpatialContrastiveNormalization with caller-provided scratch ((C + 3) * H * W floats): for the one-call pipelines (filters.hip)
 int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
                                       float thresval, float *scratch, float *out);

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
             // with the centre override (argbest_kernel<true>), or extractOutput's first 8 values above 0.11 in index order, its sorting
             // network and its score (extract_kernel<8>), and the confidence score > threshold; the index is decoded (x2yx minus
             // centered2onebased(0, 0)) and lands, with the confidence, at its place in the full-frame planes.
-            constexpr int NJ4 = (17 * MW + 63) / 64;                      // b128 pieces per lane, at most
+            constexpr int NJ4 = ((EXTRA ? 17 : 16) * MW + 63) / 64;       // b128 pieces per lane, at most (16 x 16: 4; 17 wide: 5)
             lds_f *cand = img + 64 * WNP;                                 // [64 windows][8 values | 8 indices]
             const int yoffc = (p.maxh + 1) / 2, xoffc = (MW + 1) / 2;     // centered2onebased(geometry, 0, 0)
             static_for_q<0, PX>([&](auto qphase) {

@@ -100,6 +100,7 @@ struct ConvBatch {
     float *out[2 * DFE_MAX_RATIOS];
     const float *w[2 * DFE_MAX_RATIOS], *bias[2 * DFE_MAX_RATIOS];
     int H[2 * DFE_MAX_RATIOS], W[2 * DFE_MAX_RATIOS];
+    unsigned pitch[2 * DFE_MAX_RATIOS], plane[2 * DFE_MAX_RATIOS];   // floats between rows / planes of in[e] (W, H * W unless the input is a view)
     int blk0[2 * DFE_MAX_RATIOS + 1];   // first block of entry e (tiles x output groups each): the grid holds no idle blocks
     int n;
 };
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_batch_kernel(ConvBatch cb, int nIn, 
         // index in 32 bits (the launcher checks nIn * H * W)
         int i = 0, r = wv;
         for (int rr = wv; rr < nrows; rr += 4) {
-            const unsigned e0 = (unsigned)(i * L.H + min(L.y0 + r, L.H - 1)) * (unsigned)L.W;
+            const unsigned e0 = (unsigned)i * cb.plane[L.ent] + (unsigned)min(L.y0 + r, L.H - 1) * cb.pitch[L.ent];
             cb_glds_row<PITCH>(c0, c1, c2, in + e0, buf + rr * PITCH);
             r += 4;
             if (r >= trows) { r -= trows; ++i; }
@@ -267,7 +268,8 @@ static bool launch_conv_batch(dfe_ctx *ctx, const ConvBatch &cb, int n, int nIn,
 
 // n inputs through ONE layer (full connection): in[e] [nIn][H[e]][W[e]] -> out[e]; per-entry weights (the scales may have their own).
 // Falls back to one dfe_filter_layer_forward launch per entry for shapes without a batched instantiation.
-static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, float *const *out, bool *done_out) {
+static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, float *const *out, bool *done_out,
+                          const int *in_pitch = nullptr, const long long *in_plane = nullptr) {
     *done_out = false;
     const dfe_filter_layer &L0 = *L[0];
     bool same = true;
@@ -280,8 +282,11 @@ static int conv_batch_try(dfe_ctx *ctx, int n, const float *const *in, const dfe
         for (int e = 0; e < n; ++e) {
             DFE_REQUIRE(ctx, in[e] && out[e] && L[e]->weight && H[e] >= L0.kH && W[e] >= L0.kW, DFE_E_SHAPE, "filter layer batch: entry %d: %dx%d kernel on %dx%d", e,
                         L0.kH, L0.kW, H[e], W[e]);
-            if ((long long)L0.nIn * H[e] * W[e] >= (1ll << 32)) ok = false;       // (32-bit element indices in the staging)
+            const long long pit = in_pitch ? in_pitch[e] : W[e], pla = in_plane ? in_plane[e] : (long long)H[e] * W[e];
+            if (pit < W[e] || pla < (long long)(H[e] - 1) * pit + W[e]) ok = false;
+            if ((long long)L0.nIn * pla >= (1ll << 32)) ok = false;                // (32-bit element indices in the staging)
             cb.in[e] = in[e]; cb.out[e] = out[e]; cb.w[e] = L[e]->weight; cb.bias[e] = L[e]->bias; cb.H[e] = H[e]; cb.W[e] = W[e];
+            cb.pitch[e] = (unsigned)pit; cb.plane[e] = (unsigned)pla;
             const int b = dfe_cdiv(W[e] - L0.kW + 1, 64) * dfe_cdiv(H[e] - L0.kH + 1, 8);
             if (b > maxblocks) maxblocks = b;
         }
@@ -335,6 +340,16 @@ int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, 
         if (rc) return rc;
     }
     return DFE_OK;
+}
+
+// the batched kernel on inputs that are VIEWS (rows in_pitch[e] floats apart, planes in_plane[e] floats apart): the single-scale model's
+// first branch reads the part of frame 0 its narrowed features come from in place.  *done = false: no batched instantiation takes the
+// layer (the caller makes the view contiguous and goes through dfe_filter_layer_forward_batch)
+int dfe_filter_layer_forward_batch_view(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, const int *in_pitch,
+                                        const long long *in_plane, float *const *out, bool *done) {
+    *done = false;
+    DFE_REQUIRE(ctx, n >= 1 && n <= 2 * DFE_MAX_RATIOS, DFE_E_ARG, "filter layer batch: n=%d", n);
+    return conv_batch_try(ctx, n, in, L, H, W, out, done, in_pitch, in_plane);
 }
 
 int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out) {

@@ -45,6 +45,18 @@ __global__ __launch_bounds__(256) void ss_paste_kernel(const long long *__restri
     }
 }
 
+// torch.Tensor(2, hImg, wImg):zero() / full_confidences:zero() (opticalflow_model.lua:236,243) where the paste does not write: the frame
+// around the pasted region (two hipMemsetAsync of the whole planes cost 10 us of a 200-us step)
+__global__ __launch_bounds__(256) void ss_border_kernel(float *__restrict__ full, float *__restrict__ full_conf, int hImg, int wImg, int ho, int wo, int H1, int W1) {
+    const long long P = (long long)hImg * wImg;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(p / wImg), x = (int)(p - (long long)y * wImg);
+        if (y >= ho && y < ho + H1 && x >= wo && x < wo + W1) continue;
+        if (full) { full[p] = 0.f; full[P + p] = 0.f; }
+        if (full_conf) full_conf[p] = 0.f;
+    }
+}
+
 // imaxs = middle, scores = 0 where extractOutput will write nothing (the reference passes uninitialised tensors: SURVEY appendix A)
 __global__ __launch_bounds__(256) void ss_fill_kernel(long long *__restrict__ idx, float *__restrict__ scores, long long P, long long middle) {
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
@@ -112,17 +124,29 @@ extern "C" int dfe_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const f
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
         // the first branch filters only what the narrow keeps: a convolution is 'valid' and shift-invariant, so the features of the cropped
         // frame ARE the narrowed features of the whole frame, bit for bit
-        hipLaunchKernelGGL(ss_crop_kernel, dim3(ss_grid((long long)C * Hc * Wc)), dim3(256), 0, ctx->stream, I0, (long long)H * W, W, ny, nx, Hc, Wc,
-                           (long long)C * Hc * Wc, c0);
-        DFE_LAUNCH_CHECK(ctx);
-        const float *ia = c0, *ib = I1;
+        // -- and the first layer reads that part of frame 0 in place (rows W apart, planes H * W apart) where the batched kernel takes the
+        // layer; otherwise it is copied out first
+        const float *ia = I0 + (long long)ny * W + nx, *ib = I1;
         int ha = Hc, wa = Wc, hb = H, wb = W;
         for (int i = 0; i < nlayers; ++i) {
             const float *in_[2] = {ia, ib};
             const dfe_filter_layer *L2[2] = {&layers[i], &layers[i]};
             const int H2[2] = {ha, hb}, W2[2] = {wa, wb};
             float *o2[2] = {fa[i & 1], fb[i & 1]};
-            rc = dfe_filter_layer_forward_batch(ctx, 2, in_, L2, H2, W2, o2);
+            bool viewed = false;
+            if (i == 0) {
+                const int pit[2] = {W, W};
+                const long long pla[2] = {(long long)H * W, (long long)H * W};
+                rc = dfe_filter_layer_forward_batch_view(ctx, 2, in_, L2, H2, W2, pit, pla, o2, &viewed);
+                if (rc) return rc;
+                if (!viewed) {
+                    hipLaunchKernelGGL(ss_crop_kernel, dim3(ss_grid((long long)C * Hc * Wc)), dim3(256), 0, ctx->stream, I0, (long long)H * W, W, ny, nx, Hc, Wc,
+                                       (long long)C * Hc * Wc, c0);
+                    DFE_LAUNCH_CHECK(ctx);
+                    in_[0] = c0;
+                }
+            }
+            if (!viewed) rc = dfe_filter_layer_forward_batch(ctx, 2, in_, L2, H2, W2, o2);
             if (rc) return rc;
             ia = o2[0]; ib = o2[1];
             ha -= layers[i].kH - 1; wa -= layers[i].kW - 1; hb -= layers[i].kH - 1; wb -= layers[i].kW - 1;
@@ -134,9 +158,11 @@ extern "C" int dfe_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const f
         in1 = I0 + (long long)ny * W + nx; pitch1 = W; plane1 = (long long)H * W;
         in2 = I1;
     }
-    if (full) DFE_HIP(ctx, hipMemsetAsync(full, 0, (size_t)2 * hImg * wImg * sizeof(float), ctx->stream));        // torch.Tensor(2, hImg, wImg):zero()
-    if (full_conf) DFE_HIP(ctx, hipMemsetAsync(full_conf, 0, (size_t)hImg * wImg * sizeof(float), ctx->stream));
     const int ho = (hImg - H1) / 2, wo = (wImg - W1) / 2;
+    if ((full || full_conf) && (hImg > H1 || wImg > W1)) {
+        hipLaunchKernelGGL(ss_border_kernel, dim3(ss_grid((long long)hImg * wImg)), dim3(256), 0, ctx->stream, full, full_conf, hImg, wImg, ho, wo, H1, W1);
+        DFE_LAUNCH_CHECK(ctx);
+    }
     if (lean) {
         DfeStageScope st(ctx, DFE_STAGE_MATCH);
         DfeSoftOut so{};
