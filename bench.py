@@ -583,7 +583,7 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
         def step(timed=False):
             # tests/time_matching.lua:30-45 (the script filters im1 and im2 with the same module; prepareInput narrows the first)
             if timed: ev[0].record()
-            f1 = filt.forward(im1).clone()
+            f1 = filt.forward(im1)          # (a module's forward returns a fresh tensor here: no clone needed to keep im1's features)
             f2 = filt.forward(im2)
             p1, p2 = d.prepareInput(geometry, f1, f2)
             if timed: ev[1].record()

@@ -389,6 +389,25 @@ int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weig
     return DFE_OK;
 }
 
+// nn.SpatialConvolution followed by nn.Tanh as one launch (getFilter puts a Tanh behind every layer but the last): the batched kernel's
+// epilogue applies the same tanhf dfe_tanh_f32 does -- bit-identical to the two calls
+int dfe_spatial_convolution_tanh_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW,
+                                     float *out) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, in && weight && out, DFE_E_ARG, "dfe_spatial_convolution_tanh_f32: NULL tensor");
+    DFE_REQUIRE(ctx, nIn > 0 && nOut > 0 && kH > 0 && kW > 0 && H >= kH && W >= kW, DFE_E_SHAPE,
+                "dfe_spatial_convolution_tanh_f32: %d->%d planes, %dx%d kernel on %dx%d", nIn, nOut, kH, kW, H, W);
+    dfe_filter_layer L{};
+    L.weight = weight; L.bias = bias; L.nIn = nIn; L.nOut = nOut; L.kH = kH; L.kW = kW; L.tanh_after = 1;
+    if (ctx->cv_mode != 1 && ctx->opt[DFE_OPT_CONV_BATCH] != 0) {
+        const dfe_filter_layer *Lp = &L;
+        bool done = false;
+        int rc = conv_batch_try(ctx, 1, &in, &Lp, &H, &W, &out, &done);
+        if (rc != DFE_OK || done) return rc;
+    }
+    return dfe_filter_layer_forward(ctx, in, L, H, W, out);
+}
+
 int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, const int32_t *conn, int nConn,
                                     int nIn, int nOut, int H, int W, int kH, int kW, float *out) {
     DFE_ENTER(ctx);

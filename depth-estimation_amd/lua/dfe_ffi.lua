@@ -77,6 +77,7 @@ int dfe_postprocess_image_f32(dfe_ctx *ctx, const float *flow, const float *mask
 int dfe_enlarge_mask_f32(dfe_ctx *ctx, float *mask, int H, int W, int ix, int iy);
 int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int maxh, int maxw, float *x, float *y);
 int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
+int dfe_spatial_convolution_tanh_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
 int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW, float *out);
 int dfe_tanh_f32(dfe_ctx *ctx, const float *in, int64_t n, float *out);
 int dfe_contrastive_normalization_f32(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold, float thresval, float *out);

@@ -197,11 +197,34 @@ class Sequential(Module):
         self.modules.append(m)
         return self
 
+    # nn.SpatialConvolution directly followed by nn.Tanh (every layer of getFilter but the last) runs as ONE launch -- the convolution
+    # kernel's epilogue applies the tanh, same bits as the two modules -- so the pair's pre-activation is not materialised: the
+    # convolution module's .output stays None (nothing on the path reads it: Tanh's gradient needs its own output only).  fuse = False on
+    # the instance gives the module-by-module evaluation back.
+    fuse = True
+
     def updateOutput(self, input):
         self._inputs = []
-        for m in self.modules:
+        mods = self.modules
+        i = 0
+        while i < len(mods):
+            m = mods[i]
             self._inputs.append(input)
+            if (self.fuse and i + 1 < len(mods) and isinstance(mods[i + 1], Tanh) and isinstance(m, SpatialConvolution)
+                    and not isinstance(m, SpatialConvolutionMap) and m.kernel == "exact" and input.dim() == 3 and input.shape[0] == m.nInputPlane):
+                x = _f32c(input, "input")
+                nIn, H, W = x.shape
+                out = torch.empty((m.nOutputPlane, H - m.kH + 1, W - m.kW + 1), dtype=torch.float32, device=x.device)
+                ctx = get_ctx(x)
+                ctx.check(lib().dfe_spatial_convolution_tanh_f32(ctx.handle, ptr(x), ptr(m.weight), ptr(m.bias), nIn, m.nOutputPlane, H, W, m.kH, m.kW, ptr(out)))
+                m.output = None
+                mods[i + 1].output = out
+                self._inputs.append(None)
+                input = out
+                i += 2
+                continue
             input = m.forward(input)
+            i += 1
         self.output = input
         return input
 
@@ -345,14 +368,8 @@ class _SharedFilter(Module):
         self.filt = filt
         self.modules = [shared_clone(m) if isinstance(m, (SpatialConvolution, SpatialConvolutionMap)) else type(m)() for m in filt.modules]
 
-    def updateOutput(self, input):
-        self._inputs = []
-        out = input
-        for mm in self.modules:
-            self._inputs.append(out)
-            out = mm.forward(out)
-        self.output = out
-        return out
+    fuse = True
+    updateOutput = Sequential.updateOutput          # (with its convolution + tanh pairs in one launch)
 
     def backward(self, input, gradOutput, scale=1.0):
         g = gradOutput

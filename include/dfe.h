@@ -456,6 +456,10 @@ int dfe_output_extractor_f32(dfe_ctx *ctx, const float *input, int64_t P, int ma
  *   an implicit-GEMM MFMA kernel belongs). */
 int dfe_spatial_convolution_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut,
                                 int H, int W, int kH, int kW, float *out);
+/* replaces: nn.SpatialConvolution followed by nn.Tanh, as getFilter chains them (opticalflow_model.lua:48-64), in one launch; results equal
+ *   dfe_spatial_convolution_f32 + dfe_tanh_f32 bit for bit. */
+int dfe_spatial_convolution_tanh_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W,
+                                     int kH, int kW, float *out);
 int dfe_spatial_convolution_map_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias,
                                     const int32_t *conn, int nConn, int nIn, int nOut, int H, int W, int kH, int kW,
                                     float *out);

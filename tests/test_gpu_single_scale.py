@@ -199,3 +199,26 @@ def test_single_scale_vga_learned_workload_one_call_equals_staged(dfe, cuda):
     srt = np.sort(ref["prob"], axis=2)
     near = (srt[..., -1] - srt[..., -2] <= 4 * soft_tol(mh * mw)) | (np.abs(ref["prob"] - 0.11) <= 2 * soft_tol(mh * mw)).any(axis=2)
     assert ((gi == ref["index"]) | near).all()
+
+
+def test_sequential_runs_convolution_and_tanh_as_one_launch(dfe, cuda):
+    """getFilter's nn.SpatialConvolution -> nn.Tanh pairs (opticalflow_model.lua:48-64) are one launch in nn.Sequential
+    (dfe_spatial_convolution_tanh_f32: the convolution kernel's epilogue applies the tanh): same features and same gradients as the
+    module-by-module evaluation (fuse = False), bit for bit; the fused pair leaves the convolution's .output unset."""
+    gen = torch.Generator().manual_seed(5)
+    geo = dict(layers=[list(l) for l in TM_LAYERS], maxh=16, maxw=16, multiscale=False)
+    filt = dfe.getFilter(geo, device=cuda, generator=gen)
+    x = torch.randn((3, 50, 70), generator=gen).to(cuda)
+    go = torch.randn((10, 38, 58), generator=gen).to(cuda)
+    res = {}
+    for fuse in (True, False):
+        filt.fuse = fuse
+        filt.zeroGradParameters()
+        out = filt.forward(x)
+        assert (filt.modules[0].output is None) == fuse and filt.modules[1].output is not None
+        gi = filt.backward(x, go)
+        res[fuse] = (out.clone(), gi.clone(), [g.clone() for g in filt.parameters()[1]])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[True][2], res[False][2]))
+    layers = [dict(weight=m.weight.cpu().numpy(), bias=m.bias.cpu().numpy(), tanh=i < 2) for i, m in enumerate(filt.modules[::2])]
+    assert np.allclose(res[True][0].cpu().numpy(), rp.filter_stack_oracle(x.cpu().numpy(), layers), rtol=0, atol=2e-6)
