@@ -751,6 +751,18 @@ def test_celiu_car_pair_hip_equals_oracle(dfe, cuda, size, win):
     assert np.array_equal(flow.cpu().numpy(), eflow)
     ed, ec = orc.flow_to_depth_cartesian(eflow, cx, cy)
     assert np.allclose(depth.cpu().numpy(), ed, rtol=1e-6, atol=0) and np.array_equal(dconf.cpu().numpy(), ec)
+    # ... and against the celiu flow the reference ships for this pair (celiu/output/car_flow.jpg decoded by tests/flowcolor.py: direction
+    # and relative magnitude; tests/test_real_image_cpu.py has the oracle's twin of this check): the HIP path's confident pixels point the way
+    # celiu's flow does, the car blob carries the large leftward displacements
+    from tests.test_real_image_cpu import agreement_with_celiu, celiu_field
+
+    U, V, R = celiu_field(half=(size == (320, 240)))
+    gflow, gconf = flow.cpu().numpy(), scores.cpu().numpy() > 0
+    frac, fx_car, fx_bg, n, ncar = agreement_with_celiu(gflow[0], gflow[1], gconf, U, V, R)
+    full = 1 if size == (320, 240) else 2
+    assert n > 30000 * full * full and ncar > 3000 * full * full
+    assert frac >= 0.70, frac
+    assert fx_car < -3.0 * full and -1.0 * full < fx_bg < 1.5 * full, (fx_car, fx_bg)
 
 
 def test_patch_mode_spatial_matching_equals_oracle(dfe, cuda):
