@@ -1227,7 +1227,18 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
     if constexpr (ROLES) {   // the record's tail (8 zeros per buffer) is written once per piece; the scans fill the rest
         if (wave == 0 && lane < 16) recbuf[(lane >> 3) * DFE_REC + 24 + (lane & 7)] = 0.f;
     }
-    long long G0_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D;      // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
+    // (the run's global position is carried in BYTES: the image offset a0 is then one mask of its low word and the copy waves add it to
+    //  the output pointer as it is -- round 5: every scalar instruction of the row loop costs ~0.2 % of the kernel)
+    constexpr int ES = F16 ? 2 : 4;                                          // bytes per cell of the volume
+    long long G0b_run = ((long long)(y0 - (K - 1)) * p.Wo + x0) * D * ES;    // row r = 0 is output row y0 - (K-1) (a warm-up row, not stored)
+    const long long G0b_step = (long long)p.Wo * D * ES;
+    // (b) rows from which on the piece stores: r >= K - 1 (the box filter is warm) and output row y0 + r - (K-1) >= y0n (a shifted last
+    //  static tile leaves its first rows to its neighbour) -- one per-piece scalar instead of two compares and an and per row
+    const int r_store = (K - 1) + max(0, y0n - y0);
+    // (a) byte offset of the NEXT row's frame-0 window from a_base, carried: + W * 4 per row.  No clamp at the piece's end: the row after
+    //  the last sweep row, y0 + oy + nsweep <= Ho + oy + K - 1 = H - ceil((hWin - 1) / 2), is inside the frame for every window of >= 2
+    //  rows (its values are loaded and never used).
+    unsigned a_roff = (unsigned)p.W * 4u;
     long long pg_next = FUSE ? (long long)(fa.row_off + y0 - (K - 1)) * p.Wo + x0 : 0;
     // ROLES: record of the row BEFORE row r = 0 of this piece (output row y0 - K of column group bx); + DFE_REC per row step
     const float *rec_prev = ROLES ? fa.rec + ((long long)bx * fa.rec_rows + (fa.row_off + y0 - (K - 1) - 1)) * DFE_REC : nullptr;
@@ -1237,16 +1248,15 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             constexpr int m = decltype(mc)::value;
             const int r = q * U + m;
             if (SWEEP && r >= nsweep) return;                                // block-uniform (static tiles: nsweep is a multiple of U)
-            const bool emit = (K == 7) ? (q > 0) : (q > 0 || m == K - 1);   // r >= K-1
             const int y = y0 + r - (K - 1);
-            const bool store_row = emit && y >= y0n;                         // block-uniform
+            const bool store_row = r >= r_store;                             // block-uniform
             // (G0 = ((long long)y * p.Wo + x0) * D, the global float index of the run, and pg_run, the row's first entry of the
             //  fused per-pixel planes, are carried from row to row: one 64-bit add each instead of two 64-bit multiplies)
-            const long long G0 = G0_run;
-            G0_run += (long long)p.Wo * D;     // (tried as a 32-bit unsigned step, one scalar fewer: the allocator answered with a vector spill reloaded in every row)
+            const long long G0b = G0b_run;
+            G0b_run += G0b_step;     // (tried as a 32-bit unsigned step, one scalar fewer: the allocator answered with a vector spill reloaded in every row)
             const long long pg_run = pg_next;
             if constexpr (FUSE) pg_next += p.Wo;
-            const int a0 = (int)(G0 & LM);
+            const int a0 = (int)(((unsigned)G0b / (unsigned)ES) & (unsigned)LM);
             float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
             const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
@@ -1268,7 +1278,8 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         // (32-bit unsigned row / plane offsets next to ONE 64-bit base: the scalar loads take them as soffset, and the
                         //  sweep keeps 3 scalars fewer than with a running 64-bit pointer and two 64-bit plane offsets)
                         const char *ab = reinterpret_cast<const char *>(I0 + a_base);
-                        const unsigned roff = (unsigned)rn * (unsigned)p.W * 4u, hwb = (unsigned)HW * 4u;
+                        const unsigned roff = a_roff, hwb = (unsigned)HW * 4u;
+                        a_roff += (unsigned)p.W * 4u;
 #pragma unroll
                         for (int c = 0; c < C; ++c) uload<NE>((cfptr)(ab + (unsigned long long)(roff + (unsigned)c * hwb)), av[c]);
 #else
@@ -1440,7 +1451,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                         const int nbody8 = ((RUN - ov - head) >> 6) << 3;    // 8-cell pieces in whole 128-B lines
                         nbody4 = nbody8 << 1;                                // (in 4-cell units, for the tail below)
                         const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
-                        const _Float16 *gb = reinterpret_cast<const _Float16 *>(out) + G0 + ov + head;
+                        const _Float16 *gb = reinterpret_cast<const _Float16 *>(reinterpret_cast<const char *>(out) + G0b) + (ov + head);
                         constexpr int NPC = ((TX * 1096 + 64) / 8 + STR - 1) / STR;
                         const float sc = p.scale;
                         f4_t lo[NPC], hi[NPC];
@@ -1466,7 +1477,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     const int ntl = has_next ? (-(a0 + RUN)) & 31 : 0;       // cells of the next pixel that complete the last line
                     nbody4 = ((RUN - ov - head + ntl) >> 5) << 3;            // float4 pieces in whole 128-B lines
                     const f4_t *sb = reinterpret_cast<const f4_t *>(st + ov + head);
-                    const float *gb = out + G0 + ov + head;
+                    const float *gb = reinterpret_cast<const float *>(reinterpret_cast<const char *>(out) + G0b) + (ov + head);
                     // at most 3 (4 with 10 copier waves) pieces per thread: all LDS reads first, then the
                     // stores -- one exposed LDS latency instead of three (every wave of the block is in this phase at once,
                     // nothing else hides it: -6 % on the whole kernel).  Tried on top: the scan's reads issued together with
@@ -1512,12 +1523,13 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
                     {     // the run's two partial lines: head by wave 5, tail by wave 6
                         const int tail0 = ov + head + (nbody4 << 2), ntail = RUN - tail0;   // (tail line owned: ntail <= 0)
                         if constexpr (F16) {
-                            _Float16 *oh = reinterpret_cast<_Float16 *>(out);
-                            if (wave == CW0 && lane < head) oh[G0 + ov + lane] = (_Float16)(st[ov + lane] * p.scale);
-                            if (wave == CW0 + 1 && lane < ntail) oh[G0 + tail0 + lane] = (_Float16)(st[tail0 + lane] * p.scale);
+                            _Float16 *oh = reinterpret_cast<_Float16 *>(reinterpret_cast<char *>(out) + G0b);
+                            if (wave == CW0 && lane < head) oh[ov + lane] = (_Float16)(st[ov + lane] * p.scale);
+                            if (wave == CW0 + 1 && lane < ntail) oh[tail0 + lane] = (_Float16)(st[tail0 + lane] * p.scale);
                         } else {
-                            if (wave == CW0 && lane < head && !skip_head) out[G0 + ov + lane] = st[ov + lane];
-                            if (wave == CW0 + 1 && lane < ntail) out[G0 + tail0 + lane] = st[tail0 + lane];
+                            float *og = reinterpret_cast<float *>(reinterpret_cast<char *>(out) + G0b);
+                            if (wave == CW0 && lane < head && !skip_head) og[ov + lane] = st[ov + lane];
+                            if (wave == CW0 + 1 && lane < ntail) og[tail0 + lane] = st[tail0 + lane];
                         }
                     }
                 }
