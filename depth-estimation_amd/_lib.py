@@ -11,7 +11,7 @@ DFE_MAX_RATIOS = 10
 
 # keys of dfe_set_option / dfe_get_option (include/dfe.h)
 OPTION_KEYS = ("cascade_px", "fine_fuse", "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10",
-               "fm64", "fm_rows", "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "graphs")
+               "fm64", "fm_rows", "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "graphs")
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)

@@ -74,7 +74,196 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float *__restrict_
     }
 }
 
+// ---- round 5: weights RESIDENT in LDS, K flattened, persistent blocks ------------------------------------------------------------
+// The kernel above restages a plane's weights with every input tile, pads every kernel row to a multiple of 4 taps (17 -> 20: 15 % of
+// the MFMAs multiply zeros), gives a block 16 output planes (version2's 32 planes: every tile staged twice) and runs at 61 TFLOP/s on
+// version2's 17 x 17 x 3 -> 32 layer (0.246 ms per VGA frame -- no faster than the exact VALU kernel).  This one:
+//   * K = (input plane, ky, kx) is ONE flat index, padded once at its end (867 -> 896 = 28 chunks of 8 steps): lane (m, kq) walks
+//     k = 4 s + kq through the tile by a table of tap offsets in LDS (first version: a carried (v, u, offset) triple with compares
+//     and selects per step -- their issue time exceeded the MFMAs': 0.455 ms for both VGA frames, no faster than the exact kernel);
+//   * the whole weight matrix [K4][16][NT] (NT = 1 or 2 groups of 16 output planes, interleaved so that a lane's two B operands are
+//     one 8-byte read) is staged ONCE per block: 111 KB for version2's layer;
+//   * one block of 16 waves per CU walks tiles of 4 rows x 64 columns (both frames of a pair in one launch): wave w owns row w / 4
+//     and the 16 pixels w % 4 of it for all output planes -- one A read feeds NT MFMAs; the next tile's pixels are loaded into
+//     registers before the step loop and written to the other LDS buffer behind it (one barrier per tile).
+// The chain per output is the same k-ordered fmaf chain (bias first, padded taps add exact zeros at the END of the chain): bit-exact
+// against the oracle's fmaf variant, like the kernel above.
+struct CmBatch {
+    const float *in[2];
+    float *out[2];
+    int H[2], W[2];                 // input size of entry e (output: H - kH + 1, W - kW + 1)
+    unsigned pitch[2], plane[2];    // floats between rows / planes of in[e] (a view is allowed)
+    int tx[2];                      // tiles per output row
+    int t0[3];                      // first tile of entry e; t0[n] = number of tiles
+    int n;
+};
+
+template <int NT, bool TANH>
+__global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const float *__restrict__ w, const float *__restrict__ bias, int nIn, int nOut, int kH,
+                                                             int kW) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TR = 4, TC = 64;                                  // output rows / columns of a tile
+    constexpr int CH = 8;                                           // steps per chunk: a chunk's LDS reads are all issued before its MFMAs
+    const int K = nIn * kH * kW, steps = ((K + 3) / 4 + CH - 1) / CH * CH;
+    const int TH = TR + kH - 1, TW = TC + kW - 1, TPL = TH * TW, TSZ = nIn * TPL;
+    float *wl = smem;                                               // [4 steps][16][NT]
+    int *ktab = reinterpret_cast<int *>(smem + (size_t)steps * 4 * 16 * NT);   // [4 steps]: BYTE offset of tap k inside a tile
+    float *tile0 = reinterpret_cast<float *>(ktab + steps * 4);     // [2][nIn][TH][TW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    // ---- weights and the tap table, once: thread t takes the (plane, group) pair t % (16 NT) and every 1024 / (16 NT)-th k
+    {
+        constexpr int PP = 16 * NT;
+        const int pn = tid % PP, mm = pn / NT, nt = pn - mm * NT, plane = nt * 16 + mm;
+        for (int k = tid / PP; k < steps * 4; k += 1024 / PP)
+            wl[k * PP + pn] = (k < K && plane < nOut) ? w[(long long)plane * K + k] : 0.f;
+        // (the flat index k = (input plane, ky, kx) walks the tile in steps of 4 taps that straddle kernel rows and planes: the walk's
+        //  per-lane carry chain -- compare / select per step -- cost more issue time than the MFMAs; a table read does not)
+        for (int k = tid; k < steps * 4; k += 1024) {
+            const int kk = k < K ? k : 0;                           // (padded taps: zero weights, any initialised element)
+            const int i = kk / (kH * kW), r = kk - i * kH * kW, u = r / kW, v = r - u * kW;
+            ktab[k] = 4 * (i * TPL + u * TW + v);
+        }
+    }
+    // ---- this thread's share of a tile's staging: elements e = tid + 1024 j of [nIn][TH][TW]
+    constexpr int NLD = 6;                                          // (launcher: nIn * TH * TW <= 6 * 1024)
+    int er[NLD], ec[NLD];
+    unsigned ep[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int e = tid + 1024 * j, i = e / TPL, rem = e - i * TPL;
+        er[j] = rem / TW; ec[j] = rem - er[j] * TW;
+        ep[j] = (unsigned)i;                                        // (times the entry's plane stride at the load)
+    }
+    auto tile_geom = [&](int t, int &ent, int &x0, int &y0) {
+        ent = (cb.n > 1 && t >= cb.t0[1]) ? 1 : 0;
+        const int rel = t - cb.t0[ent], by = rel / cb.tx[ent];
+        x0 = (rel - by * cb.tx[ent]) * TC; y0 = by * TR;
+    };
+    float stg[NLD];
+    auto load_tile = [&](int t) {
+        int ent, x0, y0;
+        tile_geom(t, ent, x0, y0);
+        const float *__restrict__ in = cb.in[ent];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (tid + 1024 * j < TSZ)
+                stg[j] = in[(size_t)ep[j] * cb.plane[ent] + (size_t)min(y0 + er[j], cb.H[ent] - 1) * cb.pitch[ent] + min(x0 + ec[j], cb.W[ent] - 1)];
+    };
+    auto store_tile = [&](float *buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j)
+            if (tid + 1024 * j < TSZ) buf[tid + 1024 * j] = stg[j];
+    };
+    const int ntiles = cb.t0[cb.n];
+    int t = blockIdx.x;
+    if (t < ntiles) { load_tile(t); store_tile(tile0); }
+    __syncthreads();
+    const int row = wave >> 2, tsel = wave & 3;
+    const int abase = row * TW + 16 * tsel + m;
+    typedef float bv_t __attribute__((ext_vector_type(NT)));
+    int cur = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        if (tn < ntiles) load_tile(tn);                             // (in flight behind the step loop)
+        const char *tb = reinterpret_cast<const char *>(tile0 + cur * TSZ + abase);
+        f4v acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int plane = nt * 16 + m;
+            const float b = (bias && plane < nOut) ? bias[plane] : 0.f;
+            acc[nt] = f4v{b, b, b, b};
+        }
+        const int *kp = ktab + kq;                                  // lane (m, kq) walks k = 4 s + kq
+        const float *wp = wl + (kq * 16 + m) * NT;
+        int off[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];
+        for (int s = 0; s < steps; s += CH) {
+            float a[CH];
+            bv_t b[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = *reinterpret_cast<const float *>(tb + off[j]);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) b[j] = *reinterpret_cast<const bv_t *>(wp + j * 4 * 16 * NT);
+            wp += CH * 4 * 16 * NT;
+            kp += 4 * CH;
+            if (s + CH < steps) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];    // the next chunk's taps: in flight behind this chunk's MFMAs
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][nt], acc[nt], 0, 0, 0);
+        }
+        {
+            int ent, x0, y0;
+            tile_geom(t, ent, x0, y0);
+            const int Ho = cb.H[ent] - kH + 1, Wo = cb.W[ent] - kW + 1;
+            const int y = y0 + row, x = x0 + 16 * tsel + 4 * kq;    // D[pixel 4 kq + r][plane = lane & 15]
+            if (y < Ho) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int plane = nt * 16 + m;
+                    if (plane >= nOut) continue;
+                    float *o = cb.out[ent] + ((size_t)plane * Ho + y) * Wo + x;
+                    f4v r = acc[nt];
+                    if constexpr (TANH) r = f4v{tanhf(r[0]), tanhf(r[1]), tanhf(r[2]), tanhf(r[3])};
+                    if (x + 3 < Wo && !(((uintptr_t)o) & 15)) *reinterpret_cast<f4v *>(o) = r;
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (x + q < Wo) o[q] = r[q];
+                    }
+                }
+            }
+        }
+        if (tn < ntiles) store_tile(tile0 + (cur ^ 1) * TSZ);
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 }  // namespace
+
+static size_t conv_mfma_res_lds(int nIn, int nOut, int kH, int kW) {
+    const int NT = nOut > 16 ? 2 : 1, steps = ((nIn * kH * kW + 3) / 4 + 7) / 8 * 8;
+    return ((size_t)steps * 4 * 16 * NT + (size_t)steps * 4 + (size_t)2 * nIn * (4 + kH - 1) * (64 + kW - 1)) * sizeof(float);
+}
+// n <= 2 inputs (the two frames of a pair) through ONE layer in one launch; *handled = false: not this kernel's shape
+int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const int *H, const int *W, const int *in_pitch, const long long *in_plane,
+                            const dfe_filter_layer &L, float *const *out, bool *handled) {
+    *handled = false;
+    if (n < 1 || n > 2 || L.conn || L.nOut > 32) return DFE_OK;
+    const size_t lds = conv_mfma_res_lds(L.nIn, L.nOut, L.kH, L.kW);
+    if (lds > 160 * 1024 || (size_t)L.nIn * (4 + L.kH - 1) * (64 + L.kW - 1) > 6 * 1024) return DFE_OK;
+    CmBatch cb{};
+    cb.n = n;
+    int nt = 0;
+    for (int e = 0; e < n; ++e) {
+        if (H[e] < L.kH || W[e] < L.kW) return DFE_OK;
+        const long long pit = in_pitch ? in_pitch[e] : W[e], pla = in_plane ? in_plane[e] : (long long)H[e] * W[e];
+        if (pit >= (1ll << 31) || pla >= (1ll << 31)) return DFE_OK;
+        cb.in[e] = in[e]; cb.out[e] = out[e]; cb.H[e] = H[e]; cb.W[e] = W[e]; cb.pitch[e] = (unsigned)pit; cb.plane[e] = (unsigned)pla;
+        cb.tx[e] = dfe_cdiv(W[e] - L.kW + 1, 64);
+        cb.t0[e] = nt;
+        nt += cb.tx[e] * dfe_cdiv(H[e] - L.kH + 1, 4);
+    }
+    cb.t0[n] = nt;
+    const int grid = nt < ctx->ncu ? nt : ctx->ncu;
+    auto kern = L.nOut > 16 ? (L.tanh_after ? conv_mfma_res_kernel<2, true> : conv_mfma_res_kernel<2, false>)
+                            : (L.tanh_after ? conv_mfma_res_kernel<1, true> : conv_mfma_res_kernel<1, false>);
+    DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        DfeProfScope prof(ctx);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, cb, L.weight, L.bias, L.nIn, L.nOut, L.kH, L.kW);
+    }
+    DFE_LAUNCH_CHECK(ctx);
+    ctx->last_kernel = "conv_mfma_res_kernel";
+    *handled = true;
+    return DFE_OK;
+}
 
 size_t conv_mfma_lds_bytes(int kH, int kW) {
     const int kWp = (kW + 3) & ~3;
@@ -84,6 +273,12 @@ size_t conv_mfma_lds_bytes(int kH, int kW) {
 int dfe_conv_mfma_launch(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW,
                          int tanh_after, float *out, bool *handled) {
     *handled = false;
+    {   // the resident-weights kernel where the layer's weight matrix fits LDS next to two input tiles
+        dfe_filter_layer L{};
+        L.nIn = nIn; L.nOut = nOut; L.kH = kH; L.kW = kW; L.weight = weight; L.bias = bias; L.tanh_after = tanh_after;
+        int rc = dfe_conv_mfma_res_batch(ctx, 1, &in, &H, &W, nullptr, nullptr, L, &out, handled);
+        if (rc || *handled) return rc;
+    }
     const size_t lds = conv_mfma_lds_bytes(kH, kW);
     if (lds > 96 * 1024) return DFE_OK;
     const int Ho = H - kH + 1, Wo = W - kW + 1;

@@ -13,7 +13,7 @@ const DfeOptName dfe_opt_names[DFE_NOPT] = {
     {"conv_batch", "DFE_NO_CONV_BATCH", true}, {"conv_nt10", "DFE_CONV_NT5", true},           {"fm64", "DFE_NO_FM64", true},
     {"fm_rows", "DFE_FM_ROWS", false},         {"sweep_ovh", "DFE_SWEEP_OVH", false},         {"sweep_blocks", "DFE_SWEEP_BLOCKS", false},
     {"debug_arena", "DFE_DEBUG_ARENA", false}, {"fm_flat", "DFE_FM_FLAT", false},             {"fm_split", "DFE_FM_SPLIT", false},
-    {"conv_narrow", "DFE_CONV_NARROW", false},
+    {"conv_narrow", "DFE_CONV_NARROW", false}, {"conv_mfma", "DFE_CONV_MFMA", false},         {"fm_mfma", "DFE_FM_MFMA", false},
 };
 
 int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...) {

@@ -30,6 +30,8 @@ enum DfeOpt {
     DFE_OPT_FM_FLAT,          // feature matcher: the flat-tile kernel for 16- / 17-wide windows (0: the round-3 row / chunk kernels)
     DFE_OPT_FM_SPLIT,         // ... a tile's window rows dealt to two co-resident half blocks (0: one block per tile)
     DFE_OPT_CONV_NARROW,      // batched convolution: 64 x 16 output tiles (0: 128 x 8; automatic: for kernels of 9 x 9 and larger)
+    DFE_OPT_CONV_MFMA,        // one-call models: filter layers as implicit GEMMs on the matrix cores (fused multiply-adds; default 0 = exact kernels)
+    DFE_OPT_FM_MFMA,          // feature matcher as a banded GEMM on the matrix cores, |a|^2 + |b|^2 - 2 a.b (default 0 = exact k-ordered sums)
     DFE_NOPT
 };
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };
@@ -173,6 +175,10 @@ int dfe_filter_layer_forward_batch(dfe_ctx *ctx, int n, const float *const *in, 
                                    float *const *out);
 int dfe_filter_layer_forward_batch_view(dfe_ctx *ctx, int n, const float *const *in, const dfe_filter_layer *const *L, const int *H, const int *W, const int *in_pitch,
                                         const long long *in_plane, float *const *out, bool *done);
+// the same layer of up to two inputs (views allowed) as an implicit GEMM on the matrix cores, weights resident in LDS (conv_mfma.hip):
+// fused multiply-adds in the reference's (input plane, ky, kx) order -- results differ from the exact kernels by that fusing only
+int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const int *H, const int *W, const int *in_pitch, const long long *in_plane,
+                            const dfe_filter_layer &L, float *const *out, bool *handled);
 // nn.SpatialContrastiveNormalization with caller-provided scratch ((C + 3) * H * W floats): for the one-call pipelines (filters.hip)
 int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
                                       float thresval, float *scratch, float *out);

@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
             if constexpr (FUSE) pg_next += p.Wo;
             const int a0 = (int)(((unsigned)G0b / (unsigned)ES) & (unsigned)LM);
             float *st = stage + (r & 1) * g_stage_len + a0;                  // image of the run, congruent mod 32
-            const int rn = min(r + 1, nsweep - 1);   // next frame-0 row (the row after the last is never used)
+            [[maybe_unused]] const int rn = min(r + 1, nsweep - 1);   // next frame-0 row of the non-A32 form (clamped: the row after the last is never used)
             const int t0r = (SWEEP ? (r & (R0 - 1)) : r) * kT0W;
             auto do_main = [&]() {
                 {

@@ -101,7 +101,12 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
             const dfe_filter_layer *L2[2] = {&layers[i], &layers[i]};
             const int H2[2] = {ha, hb}, W2[2] = {wa, wb};
             float *o2[2] = {fa[i & 1], fb[i & 1]};
-            rc = dfe_filter_layer_forward_batch(ctx, 2, in2, L2, H2, W2, o2);
+            bool mm = false;
+            if (ctx->opt[DFE_OPT_CONV_MFMA] > 0) {   // opt-in: the layer as an implicit GEMM on the matrix cores (fused multiply-adds)
+                rc = dfe_conv_mfma_res_batch(ctx, 2, in2, H2, W2, nullptr, nullptr, layers[i], o2, &mm);
+                if (rc) return rc;
+            }
+            if (!mm) rc = dfe_filter_layer_forward_batch(ctx, 2, in2, L2, H2, W2, o2);
             if (rc) return rc;
             ia = o2[0]; ib = o2[1];
             ha -= layers[i].kH - 1; wa -= layers[i].kW - 1; hb -= layers[i].kH - 1; wb -= layers[i].kW - 1;

@@ -78,8 +78,12 @@ int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* Behaviour switches of the launchers (tuning and tests; none is needed for correct results -- every choice has a parity test or is
  * a pure scheduling choice).  value >= 0 forces, -1 restores the launcher's own choice per shape.  Keys: "cascade_px", "fine_fuse",
  * "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10", "fm64", "fm_rows",
- * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
+ * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
  * (DFE_<KEY> variables of the tuning scripts) -- never inside an op, so an op's behaviour depends on its ctx only.
+ * Two keys trade the exact arithmetic for the matrix cores, both OFF unless set to 1: "conv_mfma" (the one-call models' filter layers as
+ * implicit GEMMs, v_mfma_f32_16x16x4_f32: the reference's (input plane, ky, kx) order with FUSED multiply-adds, <= 1e-5 relative to
+ * sum |terms|) and "fm_mfma" (nn.SpatialMatching as a banded GEMM, |a|^2 + |b|^2 - 2 a.b: costs within 1e-5 |c| + 1e-6 max |c| of the
+ * exact k-ordered sums, arg-min indices equal except where two costs lie within that band).
  * replaces: the option tables the reference's drivers pass down (opticalflow.lua:138-198 `geometry`), for the switches that have no
  * counterpart there.  Unknown key: DFE_E_ARG. */
 int dfe_set_option(dfe_ctx *ctx, const char *key, int value);

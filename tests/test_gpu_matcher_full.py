@@ -213,3 +213,33 @@ def test_learned_pyramid_above_1p5_megapixels_reference_order_equals_staged(dfe,
         assert torch.equal(one[k], dflt[k]), k
     inner = (slice(150, -150), slice(150, -150))
     assert float((one["y"][inner] == dflt["y"][inner]).float().mean()) == 1.0
+
+
+def test_version2_with_matrix_core_convolution_at_vga(dfe, cuda):
+    """dfe_set_option("conv_mfma", 1): version2's 17 x 17 x 3 -> 32 layer of BOTH frames as one launch of the resident-weights implicit
+    GEMM (v_mfma_f32_16x16x4_f32, csrc/conv_mfma.hip) inside dfe_version2_flow_pair_f32 at 480 x 640.  Its features are the fmaf
+    chain in the reference's (input plane, ky, kx) order: the volume stays within 1e-4 relative of the exact path's (1e-5 on the
+    features, squared differences on top), the flows agree wherever the exact volume's two best costs are not within that band."""
+    v2 = dfe.version2
+    H, W = 480, 640
+    datap = v2.defaultDatap(wImg=W, hImg=H)
+    g = torch.Generator().manual_seed(3)
+    net = v2.getNetwork(datap, device=cuda, generator=g)
+    f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=5, max_flow=7, noise_sigma=1.0)
+    tp, tc = T(f0 / np.float32(255), cuda), T(f1 / np.float32(255), cuda)
+    ctx = dfe.get_ctx(0)
+    exact = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=True)
+    with ctx.options(conv_mfma=1):
+        mm = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=True)
+        lean = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=False)
+    for k in ("index", "xflow", "yflow"):
+        assert torch.equal(lean[k], mm[k]), k
+    ve, vm = exact["volume"], mm["volume"]
+    amax = float(ve.abs().max())
+    assert bool(((vm - ve).abs() <= 1e-4 * ve.abs() + 1e-5 * amax).all())
+    srt = torch.sort(ve.reshape(ve.shape[0], ve.shape[1], -1), dim=2).values
+    clear = (srt[..., 1] - srt[..., 0]) > 2e-4 * srt[..., 1] + 2e-5 * amax
+    assert float(clear.float().mean()) > 0.8
+    assert torch.equal(mm["index"][clear], exact["index"][clear])
+    differ = int((mm["index"] != exact["index"]).sum())
+    assert differ <= 0.02 * mm["index"].numel(), differ

@@ -1154,7 +1154,9 @@ def test_single_scale_model_training_chain_backward(dfe, cuda):
 
 # ------------------------------------------------------------------ next-row N1: implicit-GEMM convolution on the matrix cores
 @pytest.mark.parametrize("nIn,nOut,kH,kW,H,W", [(3, 4, 5, 5, 60, 90), (4, 4, 5, 5, 37, 101), (4, 10, 5, 5, 64, 64), (3, 32, 17, 17, 48, 150),
-                                              (3, 5, 1, 17, 40, 100), (5, 10, 17, 1, 40, 70), (2, 17, 3, 2, 9, 20)])
+                                              (3, 5, 1, 17, 40, 100), (5, 10, 17, 1, 40, 70), (2, 17, 3, 2, 9, 20),
+                                              (3, 32, 17, 17, 120, 700),     # several tiles per persistent block would need > 256 tiles: 26 x 11 = 286
+                                              (3, 20, 7, 5, 33, 131), (1, 16, 4, 4, 21, 67), (4, 32, 9, 6, 30, 77)])
 def test_convolution_mfma_equals_fma_oracle(dfe, cuda, nIn, nOut, kH, kW, H, W):
     """dfe_spatial_convolution_mfma_f32 (v_mfma_f32_16x16x4_f32 implicit GEMM): bit-exact against the oracle's fmaf chain in
     (input plane, ky, kx) order, and within 1e-5 * sum|terms| of nn.SpatialConvolution's separately rounded loop; the layer
@@ -1167,7 +1169,9 @@ def test_convolution_mfma_equals_fma_oracle(dfe, cuda, nIn, nOut, kH, kW, H, W):
     ctx = dfe.get_ctx(0)
     tx, tw, tb = T(x, cuda), T(w, cuda), T(b, cuda)
     ctx.check(dfe.lib().dfe_spatial_convolution_mfma_f32(ctx.handle, tx.data_ptr(), tw.data_ptr(), tb.data_ptr(), nIn, nOut, H, W, kH, kW, 0, out.data_ptr()))
-    assert ctx.last_kernel() == "conv_mfma_kernel"
+    # (up to 32 output planes whose weight matrix fits LDS: the resident-weights kernel of round 5)
+    res = nOut <= 32 and nIn * (kH + 3) * (kW + 63) <= 6 * 1024     # (a tile of the resident kernel: six staged elements per thread at most)
+    assert ctx.last_kernel() == ("conv_mfma_res_kernel" if res else "conv_mfma_kernel"), ctx.last_kernel()
     g = out.cpu().numpy()
     assert np.array_equal(g, orc.spatial_convolution_fma(x, w, b))
     ref = orc.spatial_convolution(x, w, b)
