@@ -75,6 +75,9 @@ LEARNED_SINGLE = {
     # name: (H, W, normalization_k, layers {nIn, kW, kH, nOut}, window)
     "version2-vga": (480, 640, 17, [(3, 17, 17, 32)], 17),
     "version2-180p": (180, 320, 17, [(3, 17, 17, 32)], 17),      # version2/test.lua's own datap: 320 x 180
+    # the same model with both opt-in matrix-core forms (dfe_set_option conv_mfma = 1, fm_mfma = 1): fused multiply-adds in the convolution,
+    # |a|^2 + |b|^2 - 2 a.b in the matcher -- results within the tolerances of include/dfe.h, not bit-identical to the exact line above
+    "version2-vga-mfma": (480, 640, 17, [(3, 17, 17, 32)], 17),
     "time-matching": (180, 320, 0, [(3, 5, 5, 4), (4, 5, 5, 4), (4, 5, 5, 10)], 16),
     # getModel + processOutput as depth_estimation_opticalflow.lua:103-116 runs them for a single-scale model, in ONE call
     # (dfe_flow_pair_filtered_f32): the stack of time_matching.lua:13 on both frames, prepareInput's narrow, SpatialMatching(16, 16),
@@ -612,6 +615,9 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
             ctx.check(lib.dfe_flow_pair_filtered_f32(ctx.handle, prev.data_ptr(), cur.data_ptr(), 3, H, W, arr, nl, win, win, use_thr, thr, H, W,
                                                      full.data_ptr(), fconf.data_ptr(), None, None))
     else:
+        if args.workload.endswith("-mfma"):
+            ctx.set_option("conv_mfma", 1)
+            ctx.set_option("fm_mfma", 1)
         datap = d.version2.defaultDatap(wImg=W, hImg=H, normalization_k=nk, layers=layers, wWin=win, hWin=win)
         net = d.version2.getNetwork(datap, device=dev, generator=g)
         f0, f1, _, _ = rp.synth_pair(H, W, C=3, seed=rank, max_flow=6)
@@ -660,6 +666,20 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
         valu_s = laneops / 64.0 / (VALU_RATE_PER_CU * 256 * 2.4e9)
         hbm_s = balg / (HBM_PEAK_GBS * 1e9)
         bound = "valu" if valu_s > hbm_s else "hbm"
+        mfma = None
+        if args.workload.endswith("-mfma"):
+            # both matrix-core kernels of a step together: the convolution's implicit GEMM (32 planes x 896 padded taps per output pixel of both
+            # frames) and the matcher's banded GEMM (per 16 pixels and window row two 16 x 16 tiles over K + 4 taps); executed MFMA flops,
+            # padding and the band's unused half included, against the dense f32 matrix-core peak
+            pxa, pxb = (H - 16 - 16) * (W - 16 - 16), (H - 16) * (W - 16)
+            conv_fl = 2.0 * 32 * 896 * (pxa + pxb)
+            fm_fl = 2.0 * (-(-H1 // 8) * 8) * (-(-W1 // 16) * 16) * win * 32 * (K + 4)
+            both_s = ms.value / 1e3 / args.steps                        # (profile scopes: one per matrix-core kernel, two per step)
+            mfma = {"bound": "mfma", "kernel": "conv_mfma_res_kernel + fmm_kernel+argmin", "kernel_ms": round(both_s * 1e3, 5), "launches_timed": n.value,
+                    "achieved": round((conv_fl + fm_fl) / both_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round((conv_fl + fm_fl) / both_s / 157.3e12, 4),
+                    "traffic": None, "flops_per_step": conv_fl + fm_fl,
+                    "note": "executed f32 MFMA flops (tap padding and the band's unused tile halves included) of both kernels over their summed time; the matrix "
+                            "cores hold ~1.6-1.7 GHz in these loops, i.e. ~105 TFLOP/s is what the pipe delivers when it never waits"}
         print(json.dumps({
             "metric": "Mpixels/s dense flow, %dx%d pair, learned single-scale model (%s), %dx%d window" % (
                 W, H, "tests/time_matching.lua" if tm else "opticalflow_model.lua getModel + processOutput" if nk < 0 else "version2/network.lua", win, win),
@@ -673,8 +693,10 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
                                     "true, %s), no volume in HBM" % (layers, win, win, K, W1, H1, "0.11" if nk == -2 else "nil")) if nk < 0 else
                                    ("version2/test.lua:40-53 in one call (dfe_version2_flow_pair_f32): SpatialContrastiveNormalization(3, gaussian1D(%d)) on both frames, crop, "
                                     "SpatialConvolution %s (shared, random-init), SpatialMatching(%d,%d) on %d planes %dx%d, first-min decode" % (nk, layers, win, win, K, W1, H1)),
-                       "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single", "stage_ms": stages},
-            "roofline": {"bound": bound, "kernel": kernel, "kernel_ms": round(kern_s * 1e3, 5), "launches_timed": n.value,
+                       "pairs_per_step": world, "sharding": "pair-per-gpu" if world > 1 else "single", "stage_ms": stages,
+                       "arith": "mfma (v_mfma_f32_16x16x4_f32: fused multiply-adds in the convolution, |a|^2+|b|^2-2ab in the matcher; tolerances in include/dfe.h)"
+                                if args.workload.endswith("-mfma") else "exact (separately rounded k-ordered sums: bit-identical to the CPU restatement)"},
+            "roofline": mfma if mfma else {"bound": bound, "kernel": kernel, "kernel_ms": round(kern_s * 1e3, 5), "launches_timed": n.value,
                          "achieved": round(balg / kern_s / 1e9, 2) if bound == "hbm" else round(laneops / kern_s / 1e12, 3),
                          "peak": HBM_PEAK_GBS if bound == "hbm" else round(64 * VALU_RATE_PER_CU * 256 * 2.4e9 / 1e12, 2),
                          "unit": "GB/s" if bound == "hbm" else "Tlane-op/s",

@@ -44,6 +44,20 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
     return DFE_OK;
 }
 
+int dfe_aux_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->aux_bytes) {
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->aux) DFE_HIP(ctx, hipFree(ctx->aux));
+        ctx->aux = nullptr;
+        ctx->aux_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->aux, bytes);
+        if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "aux hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        ctx->aux_bytes = bytes;
+    }
+    *out = ctx->aux;
+    return DFE_OK;
+}
+
 int dfe_graph_lookup(dfe_ctx *ctx, dfe_ctx::GraphSlot &slot, const void *key, size_t bytes) {
     if (!ctx->graphs || !ctx->stream || ctx->profile || ctx->stage_timers) return 0;   // (event records must not become graph nodes)
     const unsigned char *k = (const unsigned char *)key;
@@ -133,6 +147,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     for (const dfe_ctx::StageEvent &e : ctx->stage_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ingest) (void)hipFree(ctx->ingest);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->dflag) (void)hipFree(ctx->dflag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -55,6 +55,8 @@ struct dfe_ctx {
     size_t scratch_limit = (size_t)16 << 30;   // cost-volume bands are sized to fit (dfe_set_scratch_limit)
     void *ingest = nullptr;           // grow-only fp32 copy of a uint8 frame pair (ingest.hip), freed with the ctx
     size_t ingest_bytes = 0;
+    void *aux = nullptr;              // grow-only side buffer for small per-call planes (the matrix-core matcher's norms): NOT the arena, whose
+    size_t aux_bytes = 0;             // carved pointers a nested launcher must not invalidate
     int *dflag = nullptr;             // one device int for error flags raised by kernels
     char err[512] = {0};
     // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)
@@ -437,6 +439,12 @@ struct DfeSoftOut {
 };
 int dfe_feat_matching_flat_soft(dfe_ctx *ctx, const float *in1, int pitch1, long long plane1, const float *in2, int K, int H1, int W1, int maxh, int maxw,
                                 const DfeSoftOut *soft, bool *handled);
+// the matcher as a banded GEMM on the matrix cores (feat_matching_mfma.hip; option fm_mfma); norms: dfe_feat_matching_mfma_scratch floats
+bool dfe_feat_matching_mfma_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw);
+size_t dfe_feat_matching_mfma_scratch(int H1, int W1, int maxh, int maxw);
+int dfe_feat_matching_mfma(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *norms, float *out, long long *idx,
+                           float *xflow, float *yflow, bool *handled);
+int dfe_aux_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // the ctx's side buffer, grown to at least `bytes`
 bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw);   // the ctx / window conditions of the launcher below
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,
                                   int maxw, float *const *out, float f16_scale, bool *handled, const struct CvFineArgs *fine = nullptr);

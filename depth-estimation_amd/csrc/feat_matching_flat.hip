@@ -770,6 +770,13 @@ int dfe_feat_matching_flat_strided(dfe_ctx *ctx, const float *in1, int pitch1, l
 // nn.SpatialMatching(maxh, maxw) + `min` over the window + the decode of version2/test.lua:45-51, without the volume
 int dfe_feat_matching_flat_argmin(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, long long *idx, float *xflow,
                                   float *yflow, bool *handled) {
+    if (dfe_feat_matching_mfma_takes(ctx, K, H1, W1, maxh, maxw)) {   // opt-in (fm_mfma = 1): the banded GEMM on the matrix cores
+        void *nrm = nullptr;
+        int rc = dfe_aux_scratch(ctx, dfe_feat_matching_mfma_scratch(H1, W1, maxh, maxw) * sizeof(float), &nrm);
+        if (rc) return rc;
+        rc = dfe_feat_matching_mfma(ctx, in1, in2, K, H1, W1, maxh, maxw, (float *)nrm, nullptr, idx, xflow, yflow, handled);
+        if (rc != DFE_OK || *handled) return rc;
+    }
     return ff_launch(ctx, in1, W1, (long long)H1 * W1, in2, K, H1, W1, maxh, maxw, nullptr, idx, xflow, yflow, nullptr, handled);
 }
 

@@ -2187,6 +2187,14 @@ int dfe_spatial_matching_dispatch(dfe_ctx *ctx, const float *in1, const float *i
     DFE_REQUIRE(ctx, in1 && in2 && out, DFE_E_ARG, "dfe_spatial_matching_f32: NULL tensor");
     DFE_REQUIRE(ctx, K > 0 && H1 > 0 && W1 > 0 && maxh > 0 && maxw > 0, DFE_E_SHAPE,
                 "dfe_spatial_matching_f32: K=%d H1=%d W1=%d maxh=%d maxw=%d must be positive", K, H1, W1, maxh, maxw);
+    if (dfe_feat_matching_mfma_takes(ctx, K, H1, W1, maxh, maxw)) {   // opt-in (fm_mfma = 1): the banded GEMM on the matrix cores, costs to 1e-5
+        void *nrm = nullptr;
+        int rc = dfe_aux_scratch(ctx, dfe_feat_matching_mfma_scratch(H1, W1, maxh, maxw) * sizeof(float), &nrm);
+        if (rc) return rc;
+        bool handled = false;
+        rc = dfe_feat_matching_mfma(ctx, in1, in2, K, H1, W1, maxh, maxw, (float *)nrm, out, nullptr, nullptr, nullptr, &handled);
+        if (rc != DFE_OK || handled) return rc;
+    }
     {
         bool handled = false;   // lane <-> cell kernel with the feature tile in LDS (feat_matching.hip), bit-identical results
         int rc = dfe_feat_matching_fast(ctx, in1, in2, K, H1, W1, maxh, maxw, out, &handled);

@@ -243,3 +243,56 @@ def test_version2_with_matrix_core_convolution_at_vga(dfe, cuda):
     assert torch.equal(mm["index"][clear], exact["index"][clear])
     differ = int((mm["index"] != exact["index"]).sum())
     assert differ <= 0.02 * mm["index"].numel(), differ
+
+
+@pytest.mark.parametrize("K,H1,W1,mh", [(32, 448, 608, 17), (32, 60, 301, 17), (10, 50, 270, 16), (8, 23, 40, 17), (5, 9, 17, 16)])
+def test_matrix_core_matcher_within_tolerance_of_the_exact_kernels(dfe, cuda, K, H1, W1, mh):
+    """dfe_set_option("fm_mfma", 1): nn.SpatialMatching(17, 17) / (16, 16) as a banded GEMM on the matrix cores (csrc/feat_matching_mfma.hip,
+    |a|^2 + |b|^2 - 2 a.b with v_mfma_f32_16x16x4_f32).  Against the exact kernels: every cost within 1e-5 |c| + 1e-6 max|c| (stated in
+    include/dfe.h; the oracle on row bands confirms the exact side), every cell written (NaN pre-fill), the arg-min form's index equal to the
+    exact first minimum except where the exact volume's two best costs lie within twice that band -- the count of differing pixels is
+    reported and bounded -- and the decoded flows are the index's.  Shapes: version2's VGA matcher (2128 tiles = 8.3 rounds per block),
+    ragged widths / heights (W1 % 16, H1 % 8 != 0), K % 8 != 0 (zero-filled planes)."""
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    mw = mh
+    rng = np.random.default_rng(K + H1 + W1)
+    in1 = rng.standard_normal((K, H1, W1)).astype(np.float32)
+    in2 = rng.standard_normal((K, H1 + mh - 1, W1 + mw - 1)).astype(np.float32)
+    # plant a shifted copy so that many windows hold a near-zero cost (the cancellation case) next to large ones
+    in2[:, 3 : 3 + H1, 5 : 5 + W1] = in1 + 0.05 * rng.standard_normal((K, H1, W1)).astype(np.float32)
+    t1, t2 = T(in1, cuda), T(in2, cuda)
+    exact = torch.empty((H1, W1, mh, mw), device=cuda)
+    ctx.check(lib.dfe_spatial_matching_f32(ctx.handle, t1.data_ptr(), t2.data_ptr(), K, H1, W1, mh, mw, exact.data_ptr()))
+    assert not ctx.last_kernel().startswith("fmm_kernel")
+    for y0, y1 in [(0, min(2, H1)), (max(H1 - 2, 0), H1)]:
+        ref = orc.spatial_matching(np.ascontiguousarray(in1[:, y0:y1]), np.ascontiguousarray(in2[:, y0 : y1 + mh - 1]), mh, mw)
+        assert np.array_equal(exact[y0:y1].cpu().numpy(), ref)
+    with ctx.options(fm_mfma=1):
+        vol = torch.full((H1, W1, mh, mw), float("nan"), device=cuda)
+        ctx.check(lib.dfe_spatial_matching_f32(ctx.handle, t1.data_ptr(), t2.data_ptr(), K, H1, W1, mh, mw, vol.data_ptr()))
+        assert ctx.last_kernel() == "fmm_kernel", ctx.last_kernel()
+        idx = torch.full((H1, W1), -7, dtype=torch.int64, device=cuda)
+        xf, yf = torch.full((H1, W1), float("nan"), device=cuda), torch.full((H1, W1), float("nan"), device=cuda)
+        ctx.check(lib.dfe_spatial_matching_argmin_f32(ctx.handle, t1.data_ptr(), t2.data_ptr(), K, H1, W1, mh, mw, idx.data_ptr(), xf.data_ptr(), yf.data_ptr()))
+        assert ctx.last_kernel() == "fmm_kernel+argmin", ctx.last_kernel()
+    torch.cuda.synchronize()
+    assert int(torch.isnan(vol).sum()) == 0
+    amax = float(exact.abs().max())
+    err = (vol - exact).abs()
+    bad = err > 1e-5 * exact.abs() + 1e-6 * amax
+    assert not bool(bad.any()), "%d cells outside the tolerance, worst %g at cost %g" % (int(bad.sum()), float(err.max()), float(exact.reshape(-1)[err.argmax()]))
+    # the arg-min form sees the same matrix-core costs: its index is the first minimum of `vol`
+    assert torch.equal(idx, _first_min_index(vol) + 1)
+    want = _first_min_index(exact)
+    srt = torch.sort(exact.reshape(H1, W1, -1), dim=2).values
+    near = (srt[..., 1] - srt[..., 0]) <= 2 * (1e-5 * srt[..., 1].abs() + 1e-6 * amax)
+    differ = idx != want + 1
+    assert not bool((differ & ~near).any()), "%d pixels differ from the exact first minimum outside ties" % int((differ & ~near).sum())
+    assert int(differ.sum()) <= 0.01 * idx.numel() + 2, "differing pixels: %d of %d" % (int(differ.sum()), idx.numel())
+    i0 = idx - 1
+    lWin, tWin = (mw + 1) // 2 - 1, (mh + 1) // 2 - 1
+    assert torch.equal(yf, (i0 // mw - tWin).to(torch.float32)) and torch.equal(xf, (i0 % mw - lWin).to(torch.float32))
+    # the planted shift is what the interior finds
+    if H1 > 20:
+        assert float((idx[4:-4, 8:-8] == 3 * mw + 5 + 1).float().mean()) > 0.95
