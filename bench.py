@@ -862,6 +862,33 @@ def main():
         h2d = {"value": round(H * W / th / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(th * 1e3, 4), "host_bytes_per_step": int(2 * hu0.numel()),
                "note": "pinned host uint8 frames -> device per step (2 async copies + on-device conversion + the same pipeline), serial on one stream; "
                        "fp32 frames would move 4x the bytes"}
+        # ... and PIPELINED (host staging is what bounds the multi-GPU scaling): dfe_ingest_submit_u8 uploads pair i+1 on the
+        # ctx's copy stream into another of three device slots while dfe_flow_depth_pair_u8_slot computes pair i -- event-ordered, no host
+        # synchronisation inside the loop; every step still starts from host memory
+        slot = C.c_int()
+        nb = int(hu0.numel())
+
+        def submit():
+            ctx.check(lib.dfe_ingest_submit_u8(ctx.handle, hu0.data_ptr(), hu1.data_ptr(), nb, C.byref(slot)))
+            return slot.value
+
+        def run_pipelined(n):
+            cur = submit()
+            for _ in range(n):
+                nxt = submit()
+                ctx.check(lib.dfe_flow_depth_pair_u8_slot(ctx.handle, cur, Cc, H, W, k, hWin, wWin, cx, cy, 0.21, 1.0,
+                                                          flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), dconf.data_ptr()))
+                cur = nxt
+
+        run_pipelined(5)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        run_pipelined(nh)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - tp) / nh
+        h2d["pipelined"] = {"value": round(H * W / tp / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(tp * 1e3, 4),
+                            "of_resident": round((H * W / tp / 1e6) / (world * args.steps * H * W / elapsed / 1e6), 4),
+                            "note": "copy-engine transfer of pair i+1 (copy stream, another of three device slots) under the step of pair i: dfe_ingest_submit_u8 + dfe_flow_depth_pair_u8_slot"}
 
     scale1080 = None
     if world > 1 and args.workload == "vga":

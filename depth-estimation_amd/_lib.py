@@ -55,6 +55,8 @@ PROTOTYPES = {
                                              C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dfe_spatial_matching_strided_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "dfe_spatial_convolution_tanh_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "dfe_ingest_submit_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int)]),
+    "dfe_flow_depth_pair_u8_slot": (C.c_int, [C.c_void_p, C.c_int] + [C.c_int] * 6 + [C.c_float, C.c_float, C.c_double, C.c_float] + [C.c_void_p] * 4),
     "dfe_u8_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]),
     "dfe_min_dim0_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "dfe_rgb2y_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

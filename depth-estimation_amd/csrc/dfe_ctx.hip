@@ -148,6 +148,12 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ingest) (void)hipFree(ctx->ingest);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    for (int i = 0; i < DFE_NSLOT; ++i) {
+        if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
+        if (ctx->copied[i]) (void)hipEventDestroy(ctx->copied[i]);
+        if (ctx->consumed[i]) (void)hipEventDestroy(ctx->consumed[i]);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->dflag) (void)hipFree(ctx->dflag);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -37,6 +37,7 @@ enum DfeOpt {
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };
 extern const DfeOptName dfe_opt_names[DFE_NOPT];
 
+constexpr int DFE_NSLOT = 3;   // device slots of the pipelined ingest (ingest.hip)
 struct dfe_ctx {
     int opt[DFE_NOPT];
     dfe_ctx() { for (int i = 0; i < DFE_NOPT; ++i) opt[i] = -1; }
@@ -55,6 +56,14 @@ struct dfe_ctx {
     size_t scratch_limit = (size_t)16 << 30;   // cost-volume bands are sized to fit (dfe_set_scratch_limit)
     void *ingest = nullptr;           // grow-only fp32 copy of a uint8 frame pair (ingest.hip), freed with the ctx
     size_t ingest_bytes = 0;
+    // pipelined ingest (ingest.hip): a copy stream of the ctx's own and DFE_NSLOT device slots for frame pairs -- the upload (+ conversion)
+    // of pair i+1 runs beside the step of pair i; copied[s] / consumed[s] order the two streams per slot
+    hipStream_t copy_stream = nullptr;
+    void *slot[DFE_NSLOT] = {};        // two uint8 frames each
+    size_t slot_bytes = 0;            // bytes of ONE frame of a slot
+    hipEvent_t copied[DFE_NSLOT] = {}, consumed[DFE_NSLOT] = {};
+    bool slot_used[DFE_NSLOT] = {};
+    int slot_next = 0;
     void *aux = nullptr;              // grow-only side buffer for small per-call planes (the matrix-core matcher's norms): NOT the arena, whose
     size_t aux_bytes = 0;             // carved pointers a nested launcher must not invalidate
     int *dflag = nullptr;             // one device int for error flags raised by kernels

@@ -23,6 +23,25 @@ __global__ void u8_to_f32_kernel(const unsigned char *__restrict__ src, long lon
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = (float)src[(n4 << 2) + threadIdx.x] * scale;
 }
+// BOTH frames of a pair converted in one launch, 16 source bytes per thread and step (the pipelined ingest's conversion)
+__global__ __launch_bounds__(256) void u8_fetch_pair_kernel(const unsigned char *__restrict__ s0, const unsigned char *__restrict__ s1, long long n, float scale,
+                                                            float *__restrict__ d0, float *__restrict__ d1) {
+    const long long n16 = n >> 4;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < 2 * n16; e += (long long)gridDim.x * blockDim.x) {
+        const bool second = e >= n16;
+        const long long i = second ? e - n16 : e;
+        const uint4 v = reinterpret_cast<const uint4 *>(second ? s1 : s0)[i];
+        float4 *o = reinterpret_cast<float4 *>(second ? d1 : d0) + 4 * i;
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o[q] = make_float4((float)(w[q] & 255u) * scale, (float)((w[q] >> 8) & 255u) * scale, (float)((w[q] >> 16) & 255u) * scale, (float)(w[q] >> 24) * scale);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * (n & 15)) {
+        const int f = threadIdx.x >= (n & 15), t = threadIdx.x - f * (int)(n & 15);
+        (f ? d1 : d0)[(n16 << 4) + t] = (float)(f ? s1 : s0)[(n16 << 4) + t] * scale;
+    }
+}
 __global__ void u8_to_f32_bytes_kernel(const unsigned char *__restrict__ src, long long n, float scale, float *__restrict__ dst) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) dst[e] = (float)src[e] * scale;
 }
@@ -157,6 +176,85 @@ int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, i
     float *f0 = nullptr, *f1 = nullptr;
     int rc = ingest_pair(ctx, I0, I1, (long long)C * H * W, scale, &f0, &f1);
     if (rc) return rc;
+    return dfe_flow_depth_pair_f32(ctx, f0, f1, C, H, W, k, hWin, wWin, foe_x, foe_y, extract_threshold, flow, scores, depth, depth_conf);
+}
+
+// ---- pipelined ingest: host frames of pair i+1 travel while pair i computes -------------------------------------------------------
+// What the measurements on this stack say (tools/pipe_probe.py, pipe_probe2.py; profiles/r05_n_*):
+//   * asynchronous copies from pinned host memory on a second stream run on the copy engines BESIDE the sweep: 258 us per step
+//     against 245 resident (+ the conversion);
+//   * but a copy that has to wait for an event of the COMPUTE queue (hipStreamWaitEvent on the copy stream) makes hipMemcpyAsync block
+//     the HOST for a whole step: 160-360 us per submit, the loop slower than the serial one;
+//   * an upload KERNEL beside the sweep does not overlap at all: the sweep's 16 waves of 128 registers fill every SIMD's register file,
+//     the upload's waves are only placed when a sweep block leaves (249 us for a 40-us transfer, the next step 14 us late).
+// So: copy-engine transfers into one of THREE uint8 slots, no event wait on the copy stream; a slot's reuse is ordered on the host
+// (hipEventSynchronize on its consumed event -- recorded two pairs earlier, complete long before in a loop that stays one pair ahead);
+// the compute stream waits for the slot's copied event (a barrier packet) and converts both frames in one launch.
+int dfe_ingest_submit_u8(dfe_ctx *ctx, const uint8_t *hI0, const uint8_t *hI1, int64_t nbytes, int *slot_out) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, hI0 && hI1 && slot_out && nbytes > 0, DFE_E_ARG, "dfe_ingest_submit_u8: NULL frame or %lld bytes", (long long)nbytes);
+    if (!ctx->copy_stream) {
+        DFE_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < DFE_NSLOT; ++i) {
+            DFE_HIP(ctx, hipEventCreateWithFlags(&ctx->copied[i], hipEventDisableTiming));
+            DFE_HIP(ctx, hipEventCreateWithFlags(&ctx->consumed[i], hipEventDisableTiming));
+        }
+    }
+    if ((size_t)nbytes > ctx->slot_bytes) {                      // (grow-only; sizes settle with the first pair)
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < DFE_NSLOT; ++i) {
+            if (ctx->slot[i]) DFE_HIP(ctx, hipFree(ctx->slot[i]));
+            ctx->slot[i] = nullptr;
+            ctx->slot_used[i] = false;
+        }
+        ctx->slot_bytes = 0;
+        const size_t fb = ((size_t)nbytes + 255) / 256 * 256;
+        for (int i = 0; i < DFE_NSLOT; ++i) {
+            hipError_t e = hipMalloc(&ctx->slot[i], 2 * fb);
+            if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "ingest slot hipMalloc(%zu): %s", 2 * fb, hipGetErrorString(e));
+        }
+        ctx->slot_bytes = fb;
+    }
+    const int s = ctx->slot_next;
+    ctx->slot_next = (s + 1) % DFE_NSLOT;
+    // the slot's previous pair must have been consumed before its bytes are overwritten: ordered on the host (see above)
+    if (ctx->slot_used[s]) DFE_HIP(ctx, hipEventSynchronize(ctx->consumed[s]));
+    DFE_HIP(ctx, hipMemcpyAsync(ctx->slot[s], hI0, (size_t)nbytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    DFE_HIP(ctx, hipMemcpyAsync((char *)ctx->slot[s] + ctx->slot_bytes, hI1, (size_t)nbytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    DFE_HIP(ctx, hipEventRecord(ctx->copied[s], ctx->copy_stream));
+    ctx->slot_used[s] = true;
+    *slot_out = s;
+    return DFE_OK;
+}
+
+int dfe_flow_depth_pair_u8_slot(dfe_ctx *ctx, int slot, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, double extract_threshold,
+                                float scale, float *flow, float *scores, float *depth, float *depth_conf) {
+    DFE_ENTER(ctx);
+    DFE_REQUIRE(ctx, slot >= 0 && slot < DFE_NSLOT && ctx->slot_used[slot], DFE_E_ARG, "dfe_flow_depth_pair_u8_slot: slot %d holds no submitted pair", slot);
+    DFE_REQUIRE(ctx, C > 0 && H > 0 && W > 0 && scale > 0 && (size_t)C * H * W <= ctx->slot_bytes, DFE_E_SHAPE,
+                "dfe_flow_depth_pair_u8_slot: %dx%dx%d bytes (scale %g), the slot holds %zu", C, H, W, (double)scale, ctx->slot_bytes);
+    DFE_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->copied[slot], 0));
+    const uint8_t *d0 = (const uint8_t *)ctx->slot[slot], *d1 = d0 + ctx->slot_bytes;
+    // both frames converted by ONE launch (the serial entry's two conversion launches are 12 us of a 245-us step)
+    const long long n = (long long)C * H * W;
+    const size_t bytes = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    if (2 * bytes > ctx->ingest_bytes) {
+        DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->ingest) DFE_HIP(ctx, hipFree(ctx->ingest));
+        ctx->ingest = nullptr;
+        ctx->ingest_bytes = 0;
+        hipError_t e = hipMalloc(&ctx->ingest, 2 * bytes);
+        if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "frame buffer hipMalloc(%zu): %s", 2 * bytes, hipGetErrorString(e));
+        ctx->ingest_bytes = 2 * bytes;
+    }
+    float *f0 = (float *)ctx->ingest, *f1 = (float *)((char *)ctx->ingest + bytes);
+    {
+        DfeStageScope st(ctx, DFE_STAGE_LOAD);
+        hipLaunchKernelGGL(u8_fetch_pair_kernel, dim3(in_grid(2 * (n >> 4))), dim3(256), 0, ctx->stream, d0, d1, n, scale, f0, f1);
+        DFE_LAUNCH_CHECK(ctx);
+    }
+    DFE_HIP(ctx, hipEventRecord(ctx->consumed[slot], ctx->stream));   // (the conversion is the slot's only reader)
     return dfe_flow_depth_pair_f32(ctx, f0, f1, C, H, W, k, hWin, wWin, foe_x, foe_y, extract_threshold, flow, scores, depth, depth_conf);
 }
 

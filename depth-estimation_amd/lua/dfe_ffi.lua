@@ -86,6 +86,8 @@ int dfe_rgb2y_f32(dfe_ctx *ctx, const float *rgb, int H, int W, float *y);
 int dfe_min_dim0_f32(dfe_ctx *ctx, const float *in, int n, int64_t M, float *val, int64_t *idx);
 int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth, float *depth_conf);
 int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw, const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx);
+int dfe_ingest_submit_u8(dfe_ctx *ctx, const uint8_t *hI0, const uint8_t *hI1, int64_t nbytes, int *slot);
+int dfe_flow_depth_pair_u8_slot(dfe_ctx *ctx, int slot, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y, double extract_threshold, float scale, float *flow, float *scores, float *depth, float *depth_conf);
 int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const float *cur, int C, int H, int W, const float *norm_kernel_host, int norm_k, float threshold, float thresval, const dfe_filter_layer *layers, int nlayers, int hWin, int wWin, float *xflow, float *yflow, int64_t *idx, float *volume);
 int dfe_spatial_matching_argmin_f32(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, int64_t *idx, float *xflow, float *yflow);
 int dfe_spatial_convolution_mfma_f32(dfe_ctx *ctx, const float *in, const float *weight, const float *bias, int nIn, int nOut, int H, int W, int kH, int kW, int tanh_after, float *out);

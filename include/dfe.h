@@ -494,6 +494,19 @@ int dfe_flow_depth_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, i
  * at the load), so the results are bit-identical to the fp32 entries on the converted frames. */
 int dfe_multiscale_flow_pair_u8(dfe_ctx *ctx, const uint8_t *I0, const uint8_t *I1, int C, int H, int W, int k, int maxh, int maxw,
                                 const int *ratios, int nratios, float scale, float f16_scale, float *flow, int64_t *idx);
+/* ---- pipelined ingest: the frame loop's host boundary --------------------------------------------------------------------------- */
+/* replaces: the serial load -> filter -> match of depth_estimation_opticalflow.lua:66-150 (loader:getNextFrame, then the model) where
+ *   frames arrive in HOST memory.  dfe_ingest_submit_u8 starts the upload of a uint8 frame pair (nbytes per frame; pinned host memory --
+ *   dfe_host_alloc / dfe_host_register -- for a copy-engine transfer that runs beside the kernels) into one of the ctx's three device
+ *   slots on the ctx's own copy stream and returns the slot; dfe_flow_depth_pair_u8_slot runs dfe_flow_depth_pair_u8's step on that
+ *   slot's frames once they have landed (the compute stream waits for the slot's event; no host synchronisation).  Submit pair i+1, then
+ *   compute pair i: the next pair travels while the kernels of this one run.  A slot comes round again with every third submit; the
+ *   submit then waits ON THE HOST until the compute stream has consumed the slot's previous pair (two pairs back: in a loop that stays
+ *   one pair ahead it never actually waits).  Outputs as dfe_flow_depth_pair_u8 (bit-identical), ready in ctx-stream order. */
+int dfe_ingest_submit_u8(dfe_ctx *ctx, const uint8_t *hI0, const uint8_t *hI1, int64_t nbytes, int *slot);
+int dfe_flow_depth_pair_u8_slot(dfe_ctx *ctx, int slot, int C, int H, int W, int k, int hWin, int wWin, float foe_x, float foe_y,
+                                double extract_threshold, float scale, float *flow, float *scores, float *depth, float *depth_conf);
+
 
 /* ---- version2/: the single-scale learned model as ONE call -------------------------------------------------------------------- */
 /* replaces: version2/test.lua:40-53 on getNetwork(datap) of version2/network.lua:5-39 for one frame pair --

@@ -1364,3 +1364,47 @@ def test_min_dim0_is_the_sequential_first_minimum(dfe, cuda, n, M):
             best[w] = a[r][w]
             bi[w] = r
     assert np.array_equal(mn.cpu().numpy(), best, equal_nan=True) and np.array_equal(mi.cpu().numpy(), bi + 1)
+
+
+def test_pipelined_ingest_equals_the_serial_u8_entry(dfe, cuda):
+    """dfe_ingest_submit_u8 + dfe_flow_depth_pair_u8_slot (the upload of pair i+1 on the ctx's copy stream beside the step of pair i, two
+    device slots, event-ordered): a stream of DIFFERENT pairs through the pipeline gives, pair by pair, exactly what dfe_flow_depth_pair_u8
+    gives on the same frames -- slots are not overwritten before they are consumed, results do not arrive early."""
+    from ctypes import c_int
+
+    ctx = dfe.get_ctx(0)
+    lib = dfe.lib()
+    H, W, k, win = 96, 140, 7, 17
+    rng = np.random.default_rng(31)
+    pairs = []
+    for i in range(5):
+        u0 = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+        u1 = np.roll(u0, (i % 3 - 1, 2 - i % 4), axis=(1, 2))
+        pairs.append((torch.from_numpy(u0).pin_memory(), torch.from_numpy(u1).pin_memory()))
+
+    def outs():
+        return torch.full((2, H, W), -9.0, device=cuda), *(torch.full((H, W), -9.0, device=cuda) for _ in range(3))
+
+    want = []
+    for h0, h1 in pairs:
+        o = outs()
+        d0, d1 = h0.to(cuda), h1.to(cuda)
+        ctx.check(lib.dfe_flow_depth_pair_u8(ctx.handle, d0.data_ptr(), d1.data_ptr(), 3, H, W, k, win, win, 70.0, 40.0, 0.21, 1.0, *(t.data_ptr() for t in o)))
+        want.append(o)
+    torch.cuda.synchronize()
+    got = [outs() for _ in pairs]
+    slot = c_int()
+    ctx.check(lib.dfe_ingest_submit_u8(ctx.handle, pairs[0][0].data_ptr(), pairs[0][1].data_ptr(), 3 * H * W, byref(slot)))
+    cur = slot.value
+    for i in range(len(pairs)):
+        if i + 1 < len(pairs):
+            ctx.check(lib.dfe_ingest_submit_u8(ctx.handle, pairs[i + 1][0].data_ptr(), pairs[i + 1][1].data_ptr(), 3 * H * W, byref(slot)))
+            nxt = slot.value
+            assert nxt != cur
+        ctx.check(lib.dfe_flow_depth_pair_u8_slot(ctx.handle, cur, 3, H, W, k, win, win, 70.0, 40.0, 0.21, 1.0, *(t.data_ptr() for t in got[i])))
+        cur = nxt
+    torch.cuda.synchronize()
+    for i, (g, w_) in enumerate(zip(got, want)):
+        for a, b in zip(g, w_):
+            assert torch.equal(a, b), i
+    assert lib.dfe_flow_depth_pair_u8_slot(ctx.handle, 7, 3, H, W, k, win, win, 70.0, 40.0, 0.21, 1.0, *(t.data_ptr() for t in got[0])) != 0   # no such slot
