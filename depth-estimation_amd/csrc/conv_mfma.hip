@@ -93,6 +93,7 @@ struct CmBatch {
     float *out[2];
     int H[2], W[2];                 // input size of entry e (output: H - kH + 1, W - kW + 1)
     unsigned pitch[2], plane[2];    // floats between rows / planes of in[e] (a view is allowed)
+    float *nrm[2];                  // or NULL: [Ho][Wo] sum over the output planes of out^2 (the matrix-core matcher's |a|^2, |b|^2: feat_matching_mfma.hip)
     int tx[2];                      // tiles per output row
     int t0[3];                      // first tile of entry e; t0[n] = number of tiles
     int n;
@@ -202,6 +203,27 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
             tile_geom(t, ent, x0, y0);
             const int Ho = cb.H[ent] - kH + 1, Wo = cb.W[ent] - kW + 1;
             const int y = y0 + row, x = x0 + 16 * tsel + 4 * kq;    // D[pixel 4 kq + r][plane = lane & 15]
+            if (cb.nrm[ent]) {
+                // the pixels' squared norms over the output planes, for the matcher that follows: this lane's planes first, then the 16 lanes
+                // of its DPP row (partners at distance 8, 4, 2, 1); one lane per four pixels stores them
+                f4v sq = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (nt * 16 + m < nOut) {
+                        f4v r = acc[nt];
+                        if constexpr (TANH) r = f4v{tanhf(r[0]), tanhf(r[1]), tanhf(r[2]), tanhf(r[3])};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) sq[q] = fmaf(r[q], r[q], sq[q]);
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sq[q] = row16_sum_f32_ordered(sq[q]);
+                if (m == 0 && y < Ho) {
+                    float *o = cb.nrm[ent] + (size_t)y * Wo + x;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (x + q < Wo) o[q] = sq[q];
+                }
+            }
             if (y < Ho) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -233,7 +255,7 @@ static size_t conv_mfma_res_lds(int nIn, int nOut, int kH, int kW) {
 }
 // n <= 2 inputs (the two frames of a pair) through ONE layer in one launch; *handled = false: not this kernel's shape
 int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const int *H, const int *W, const int *in_pitch, const long long *in_plane,
-                            const dfe_filter_layer &L, float *const *out, bool *handled) {
+                            const dfe_filter_layer &L, float *const *out, bool *handled, float *const *nrm) {
     *handled = false;
     if (n < 1 || n > 2 || L.conn || L.nOut > 32) return DFE_OK;
     const size_t lds = conv_mfma_res_lds(L.nIn, L.nOut, L.kH, L.kW);
@@ -246,6 +268,7 @@ int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const i
         const long long pit = in_pitch ? in_pitch[e] : W[e], pla = in_plane ? in_plane[e] : (long long)H[e] * W[e];
         if (pit >= (1ll << 31) || pla >= (1ll << 31)) return DFE_OK;
         cb.in[e] = in[e]; cb.out[e] = out[e]; cb.H[e] = H[e]; cb.W[e] = W[e]; cb.pitch[e] = (unsigned)pit; cb.plane[e] = (unsigned)pla;
+        cb.nrm[e] = nrm ? nrm[e] : nullptr;
         cb.tx[e] = dfe_cdiv(W[e] - L.kW + 1, 64);
         cb.t0[e] = nt;
         nt += cb.tx[e] * dfe_cdiv(H[e] - L.kH + 1, 4);
@@ -276,7 +299,7 @@ int dfe_conv_mfma_launch(dfe_ctx *ctx, const float *in, const float *weight, con
     {   // the resident-weights kernel where the layer's weight matrix fits LDS next to two input tiles
         dfe_filter_layer L{};
         L.nIn = nIn; L.nOut = nOut; L.kH = kH; L.kW = kW; L.weight = weight; L.bias = bias; L.tanh_after = tanh_after;
-        int rc = dfe_conv_mfma_res_batch(ctx, 1, &in, &H, &W, nullptr, nullptr, L, &out, handled);
+        int rc = dfe_conv_mfma_res_batch(ctx, 1, &in, &H, &W, nullptr, nullptr, L, &out, handled, nullptr);
         if (rc || *handled) return rc;
     }
     const size_t lds = conv_mfma_lds_bytes(kH, kW);

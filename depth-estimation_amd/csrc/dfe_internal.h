@@ -188,8 +188,9 @@ int dfe_filter_layer_forward_batch_view(dfe_ctx *ctx, int n, const float *const 
                                         const long long *in_plane, float *const *out, bool *done);
 // the same layer of up to two inputs (views allowed) as an implicit GEMM on the matrix cores, weights resident in LDS (conv_mfma.hip):
 // fused multiply-adds in the reference's (input plane, ky, kx) order -- results differ from the exact kernels by that fusing only
+// nrm[e] (or NULL): the kernel also leaves the per-pixel squared norm of its output over the planes there ([Ho][Wo])
 int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const int *H, const int *W, const int *in_pitch, const long long *in_plane,
-                            const dfe_filter_layer &L, float *const *out, bool *handled);
+                            const dfe_filter_layer &L, float *const *out, bool *handled, float *const *nrm = nullptr);
 // nn.SpatialContrastiveNormalization with caller-provided scratch ((C + 3) * H * W floats): for the one-call pipelines (filters.hip)
 int dfe_contrastive_normalization_run(dfe_ctx *ctx, const float *in, int C, int H, int W, const float *kernel_host, int k, float threshold,
                                       float thresval, float *scratch, float *out);
@@ -451,8 +452,9 @@ int dfe_feat_matching_flat_soft(dfe_ctx *ctx, const float *in1, int pitch1, long
 // the matcher as a banded GEMM on the matrix cores (feat_matching_mfma.hip; option fm_mfma); norms: dfe_feat_matching_mfma_scratch floats
 bool dfe_feat_matching_mfma_takes(const dfe_ctx *ctx, int K, int H1, int W1, int maxh, int maxw);
 size_t dfe_feat_matching_mfma_scratch(int H1, int W1, int maxh, int maxw);
+// norms_ready: `norms` already holds |a|^2 [H1][W1] | |b|^2 [H2][W2] (left there by the convolution that made the features)
 int dfe_feat_matching_mfma(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *norms, float *out, long long *idx,
-                           float *xflow, float *yflow, bool *handled);
+                           float *xflow, float *yflow, bool *handled, bool norms_ready = false);
 int dfe_aux_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // the ctx's side buffer, grown to at least `bytes`
 bool dfe_feat_matching_win64_ok(const dfe_ctx *ctx, int K, int maxh, int maxw);   // the ctx / window conditions of the launcher below
 int dfe_feat_matching_win64_batch(dfe_ctx *ctx, int n, const float *const *in1, const float *const *in2, int K, const int *H1, const int *W1, int maxh,

@@ -292,15 +292,17 @@ bool dfe_feat_matching_mfma_takes(const dfe_ctx *ctx, int K, int H1, int W1, int
 
 // out != NULL: the volume; else the first-minimum decode (idx / xflow / yflow).  norms: dfe_feat_matching_mfma_scratch floats.
 int dfe_feat_matching_mfma(dfe_ctx *ctx, const float *in1, const float *in2, int K, int H1, int W1, int maxh, int maxw, float *norms, float *out, long long *idx,
-                           float *xflow, float *yflow, bool *handled) {
+                           float *xflow, float *yflow, bool *handled, bool norms_ready) {
     *handled = false;
     if (!dfe_feat_matching_mfma_takes(ctx, K, H1, W1, maxh, maxw) || !norms) return DFE_OK;
     const int H2 = H1 + maxh - 1, W2 = W1 + maxw - 1;
     float *na = norms, *nb = norms + (size_t)H1 * W1;
     const long long P1 = (long long)H1 * W1, P2 = (long long)H2 * W2;
-    hipLaunchKernelGGL(fmm_norm_kernel, dim3((unsigned)std::min<long long>((P1 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, in1, K, P1, na);
-    hipLaunchKernelGGL(fmm_norm_kernel, dim3((unsigned)std::min<long long>((P2 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, in2, K, P2, nb);
-    DFE_LAUNCH_CHECK(ctx);
+    if (!norms_ready) {
+        hipLaunchKernelGGL(fmm_norm_kernel, dim3((unsigned)std::min<long long>((P1 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, in1, K, P1, na);
+        hipLaunchKernelGGL(fmm_norm_kernel, dim3((unsigned)std::min<long long>((P2 + 255) / 256, 4096)), dim3(256), 0, ctx->stream, in2, K, P2, nb);
+        DFE_LAUNCH_CHECK(ctx);
+    }
     FmmArgs a{};
     a.in1 = in1; a.in2 = in2; a.na = na; a.nb = nb; a.out = out; a.idx = idx; a.xflow = xflow; a.yflow = yflow;
     a.K = K; a.H1 = H1; a.W1 = W1; a.H2 = H2; a.W2 = W2;

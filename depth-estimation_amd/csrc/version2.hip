@@ -81,13 +81,19 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
     const bool lean = !volume && (xflow || yflow || idx) && dfe_feat_matching_flat_argmin_takes(ctx, K, H1, W1, hWin, wWin);
     const size_t f_vol = (volume || lean) ? 0 : (size_t)P1 * N;
     auto al = [](size_t f) { return (f + 63) / 64 * 64; };
+    // both matrix-core options on: the last layer's convolution leaves the features' squared norms for the matcher (no pass of its own)
+    const bool mm_both = ctx->opt[DFE_OPT_CONV_MFMA] > 0 && dfe_feat_matching_mfma_takes(ctx, K, H1, W1, hWin, wWin) && layers[nlayers - 1].nOut <= 32 &&
+                         !layers[nlayers - 1].conn;
+    const size_t f_nrm = mm_both ? dfe_feat_matching_mfma_scratch(H1, W1, hWin, wWin) : 0;
     void *scr = nullptr;
-    int rc = dfe_scratch(ctx, (al(f_cn) + al(f_n) + al(f_c) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_vol)) * sizeof(float), &scr);
+    int rc = dfe_scratch(ctx, (al(f_cn) + al(f_n) + al(f_c) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_vol) + al(f_nrm)) * sizeof(float), &scr);
     if (rc) return rc;
     float *s_cn = (float *)scr, *n1 = s_cn + al(f_cn), *c0 = n1 + al(f_n);
     float *fa[2] = {c0 + al(f_c), c0 + al(f_c) + al(f_fa)};
     float *fb[2] = {fa[1] + al(f_fa), fa[1] + al(f_fa) + al(f_fb)};
     float *vol = volume ? volume : fb[1] + al(f_fb);
+    float *nrm = fb[1] + al(f_fb) + al(f_vol);                    // |a|^2 [H1][W1] | |b|^2 [H2][W2]
+    bool norms_ready = false;
     const float *ia = c0, *ib = n1;
     {
         DfeStageScope st(ctx, DFE_STAGE_FILTER);
@@ -103,8 +109,11 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
             float *o2[2] = {fa[i & 1], fb[i & 1]};
             bool mm = false;
             if (ctx->opt[DFE_OPT_CONV_MFMA] > 0) {   // opt-in: the layer as an implicit GEMM on the matrix cores (fused multiply-adds)
-                rc = dfe_conv_mfma_res_batch(ctx, 2, in2, H2, W2, nullptr, nullptr, layers[i], o2, &mm);
+                float *n2[2] = {nrm, nrm + (size_t)H1 * W1};
+                const bool last = mm_both && i == nlayers - 1;
+                rc = dfe_conv_mfma_res_batch(ctx, 2, in2, H2, W2, nullptr, nullptr, layers[i], o2, &mm, last ? n2 : nullptr);
                 if (rc) return rc;
+                norms_ready = mm && last;
             }
             if (!mm) rc = dfe_filter_layer_forward_batch(ctx, 2, in2, L2, H2, W2, o2);
             if (rc) return rc;
@@ -118,6 +127,10 @@ extern "C" int dfe_version2_flow_pair_f32(dfe_ctx *ctx, const float *prev, const
         // volume path: the same sums, the same first minimum)
         DfeStageScope st(ctx, DFE_STAGE_MATCH);
         bool done = false;
+        if (norms_ready) {
+            rc = dfe_feat_matching_mfma(ctx, ia, ib, K, H1, W1, hWin, wWin, nrm, nullptr, (long long *)idx, xflow, yflow, &done, true);
+            if (rc || done) return rc;
+        }
         rc = dfe_feat_matching_flat_argmin(ctx, ia, ib, K, H1, W1, hWin, wWin, (long long *)idx, xflow, yflow, &done);
         if (rc || done) return rc;
         DFE_REQUIRE(ctx, !lean, DFE_E_UNSUPPORTED, "dfe_version2_flow_pair_f32: the matcher declined a shape its predicate took");

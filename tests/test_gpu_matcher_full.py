@@ -243,6 +243,18 @@ def test_version2_with_matrix_core_convolution_at_vga(dfe, cuda):
     assert torch.equal(mm["index"][clear], exact["index"][clear])
     differ = int((mm["index"] != exact["index"]).sum())
     assert differ <= 0.02 * mm["index"].numel(), differ
+    # both matrix-core forms: the convolution's epilogue leaves |a|^2, |b|^2 for the banded-GEMM matcher (two launches for the pair).  Against
+    # the volume of the same features: the index is its first minimum wherever the two best costs are further apart than the matcher's band
+    with ctx.options(conv_mfma=1, fm_mfma=1):
+        both = v2.flowPair(net, datap, tp, tc, one_call=True, want_volume=False)
+        assert ctx.last_kernel() == "fmm_kernel+argmin", ctx.last_kernel()
+    srt = torch.sort(vm.reshape(vm.shape[0], vm.shape[1], -1), dim=2).values
+    near = (srt[..., 1] - srt[..., 0]) <= 2 * (1e-5 * srt[..., 1].abs() + 1e-6 * float(vm.abs().max()))
+    d2 = both["index"] != mm["index"]
+    assert not bool((d2 & ~near).any()), int((d2 & ~near).sum())
+    assert int(d2.sum()) <= 0.01 * d2.numel(), int(d2.sum())
+    for k in ("xflow", "yflow"):
+        assert torch.equal(both[k][~d2], mm[k][~d2]), k
 
 
 @pytest.mark.parametrize("K,H1,W1,mh", [(32, 448, 608, 17), (32, 60, 301, 17), (10, 50, 270, 16), (8, 23, 40, 17), (5, 9, 17, 16)])

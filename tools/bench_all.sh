@@ -3,7 +3,7 @@
 set -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 tag=${1:-bench}; shift
-wls=${@:-vga 720p 1080p vga-luma vga-pyramid 720p-pyramid 1080p-pyramid 4k-pyramid 4k-pyramid-f16 1080p-pyramid-f16 vga-pyramid-f16 vga-pyramid-learned 1080p-pyramid-learned 720p-radial vga-f16 1080p-f16 4k-f16 version2-vga version2-180p time-matching}
+wls=${@:-vga 720p 1080p vga-luma vga-pyramid 720p-pyramid 1080p-pyramid 4k-pyramid 4k-pyramid-f16 1080p-pyramid-f16 vga-pyramid-f16 vga-pyramid-learned 1080p-pyramid-learned 720p-radial vga-f16 1080p-f16 4k-f16 version2-vga version2-vga-mfma version2-180p time-matching vga-learned vga-learned-thr 720p-learned}
 mkdir -p gpurun_out
 for w in $wls; do
   timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline > gpurun_out/${tag}_bench_$w.log 2>&1
