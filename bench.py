@@ -804,13 +804,17 @@ def main():
     if rank == 0:
         Ho, Wo = H - k + 1 - hWin + 1, W - k + 1 - wWin + 1
         try:
-            vol = torch.empty((Ho, Wo, hWin, wWin), device=dev, dtype=torch.float16 if f16 else torch.float32)
+            # the caller-owned volume, from the library's allocator (include/dfe.h dfe_device_alloc: physically contiguous where granted)
+            vol, vol_contig = C.c_void_p(), C.c_int()
+            rc_alloc = lib.dfe_device_alloc(ctx.handle, Ho * Wo * hWin * wWin * (2 if f16 else 4), C.byref(vol), C.byref(vol_contig))
+            if rc_alloc != 0:
+                raise torch.OutOfMemoryError()
 
             def build():
                 if f16:
-                    ctx.check(lib.dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, 2.0 ** -8, vol.data_ptr()))
+                    ctx.check(lib.dfe_ssd_cost_volume_f16(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, 2.0 ** -8, vol))
                 else:
-                    ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol.data_ptr()))
+                    ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, k, hWin, wWin, vol))
 
             for _ in range(5):
                 build()
@@ -822,7 +826,7 @@ def main():
             ctx.check(lib.dfe_profile_read(ctx.handle, C.byref(b_ms), C.byref(b_n)))
             ctx.check(lib.dfe_profile_enable(ctx.handle, 0))
             build_ms, build_kernel = b_ms.value / 20, ctx.last_kernel()   # (per build = per pair, whatever the number of band launches)
-            del vol
+            ctx.check(lib.dfe_device_free(ctx.handle, vol))
         except torch.OutOfMemoryError:
             pass
 

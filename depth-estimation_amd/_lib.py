@@ -11,7 +11,7 @@ DFE_MAX_RATIOS = 10
 
 # keys of dfe_set_option / dfe_get_option (include/dfe.h)
 OPTION_KEYS = ("cascade_px", "fine_fuse", "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10",
-               "fm64", "fm_rows", "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "graphs")
+               "fm64", "fm_rows", "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "arena_contig", "graphs")
 
 c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
@@ -89,6 +89,8 @@ PROTOTYPES = {
         [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_double] + [C.c_void_p] * 6,
     ),
     "dfe_set_scratch_limit": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "dfe_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "dfe_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "dfe_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dfe_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "dfe_profile_read_each": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int]),

@@ -14,6 +14,7 @@ const DfeOptName dfe_opt_names[DFE_NOPT] = {
     {"fm_rows", "DFE_FM_ROWS", false},         {"sweep_ovh", "DFE_SWEEP_OVH", false},         {"sweep_blocks", "DFE_SWEEP_BLOCKS", false},
     {"debug_arena", "DFE_DEBUG_ARENA", false}, {"fm_flat", "DFE_FM_FLAT", false},             {"fm_split", "DFE_FM_SPLIT", false},
     {"conv_narrow", "DFE_CONV_NARROW", false}, {"conv_mfma", "DFE_CONV_MFMA", false},         {"fm_mfma", "DFE_FM_MFMA", false},
+    {"arena_contig", "DFE_ARENA_CONTIG", false},
 };
 
 int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...) {
@@ -25,22 +26,64 @@ int dfe_fail(dfe_ctx *ctx, int code, const char *fmt, ...) {
     return code;
 }
 
-int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->scratch_bytes) {
+int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out, bool plain) {
+    void *&arena = plain ? ctx->scratch_plain : ctx->scratch;
+    size_t &arena_bytes = plain ? ctx->scratch_plain_bytes : ctx->scratch_bytes;
+    if (bytes > arena_bytes) {
         // grow-only; a free/realloc here is a stream-ordered hazard only if a previous op still
         // uses the arena, so drain the stream first (rare: sizes settle after the first call).
         DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->scratch) DFE_HIP(ctx, hipFree(ctx->scratch));
-        ctx->scratch = nullptr;
-        ctx->scratch_bytes = 0;
-        hipError_t e = hipMalloc(&ctx->scratch, bytes);
-        if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-        ctx->scratch_bytes = bytes;
-        // DFE_DEBUG_ARENA=1: where the arena landed (the 1080p step time is bimodal per PROCESS; DESIGN section 5 ties it to this)
-        if (ctx->opt[DFE_OPT_DEBUG_ARENA] > 0) fprintf(stderr, "[dfe] scratch arena %p .. %p (%zu bytes, %s2 MiB-aligned)\n", ctx->scratch, (char *)ctx->scratch + bytes,
-                                               bytes, ((uintptr_t)ctx->scratch & ((1u << 21) - 1)) ? "not " : "");
+        if (arena) DFE_HIP(ctx, hipFree(arena));
+        arena = nullptr;
+        arena_bytes = 0;
+        hipError_t e = hipErrorUnknown;
+        bool contig = false;
+        // Physically contiguous memory first: the driver then maps the arena with large page-table fragments.  A plain hipMalloc of this
+        // size is usually assembled from scattered 2 MiB (or smaller) pieces, and the sweeps -- whose blocks together write a fresh 2.6 MB
+        // volume row every ~2 us -- then lose up to 10 % to translation misses (vga-luma 0.250 against 0.224 ms per pair in EVERY context of
+        // a process; vga-pyramid 0.077 -> 0.073, 720p-radial 0.180 -> 0.172: tools/mode_probe.py, profiles/r05_q_*, r05_r_*).  Falls back to
+        // hipMalloc when no such range is free.
+        // `plain` callers: the batched convolution writes 4..32 feature planes side by side from every block; in contiguous memory the
+        // planes' fixed distance puts those streams on the same channels (conv 4 -> 10 planes: 45.6 against 36.1 us for a VGA pair,
+        // vga-learned 0.211 against 0.196 ms, tools/conv_place_probe.py), which scattered pages break up.
+        if (!plain && ctx->opt_bool(DFE_OPT_ARENA_CONTIG, true)) {
+            e = hipExtMallocWithFlags(&arena, bytes, hipDeviceMallocContiguous);
+            contig = e == hipSuccess;
+            if (!contig) { (void)hipGetLastError(); arena = nullptr; }
+        }
+        if (!contig) e = hipMalloc(&arena, bytes);
+        if (e != hipSuccess) { arena = nullptr; return dfe_fail(ctx, DFE_E_ALLOC, "scratch hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        arena_bytes = bytes;
+        // DFE_DEBUG_ARENA=1: where the arena landed and what it is made of
+        if (ctx->opt[DFE_OPT_DEBUG_ARENA] > 0)
+            fprintf(stderr, "[dfe] scratch arena %p .. %p (%zu bytes, %s2 MiB-aligned, %s)\n", arena, (char *)arena + bytes, bytes,
+                    ((uintptr_t)arena & ((1u << 21) - 1)) ? "not " : "", contig ? "physically contiguous" : "plain hipMalloc");
     }
-    *out = ctx->scratch;
+    *out = arena;
+    return DFE_OK;
+}
+
+int dfe_device_alloc(dfe_ctx *ctx, size_t bytes, void **ptr, int *contiguous) {
+    DFE_REQUIRE(ctx, ptr && bytes > 0, DFE_E_ARG, "dfe_device_alloc: ptr = %p, bytes = %zu", (void *)ptr, bytes);
+    DFE_HIP(ctx, hipSetDevice(ctx->device));
+    *ptr = nullptr;
+    bool contig = false;
+    if (ctx->opt_bool(DFE_OPT_ARENA_CONTIG, true)) {
+        contig = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous) == hipSuccess;
+        if (!contig) { (void)hipGetLastError(); *ptr = nullptr; }
+    }
+    if (!contig) {
+        hipError_t e = hipMalloc(ptr, bytes);
+        if (e != hipSuccess) { *ptr = nullptr; return dfe_fail(ctx, DFE_E_ALLOC, "dfe_device_alloc hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    }
+    if (contiguous) *contiguous = contig ? 1 : 0;
+    return DFE_OK;
+}
+
+int dfe_device_free(dfe_ctx *ctx, void *ptr) {
+    if (!ptr) return DFE_OK;
+    DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));   // nothing of this ctx may still be writing there
+    DFE_HIP(ctx, hipFree(ptr));
     return DFE_OK;
 }
 
@@ -146,6 +189,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (const dfe_ctx::StageEvent &e : ctx->stage_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->scratch_plain) (void)hipFree(ctx->scratch_plain);
     if (ctx->ingest) (void)hipFree(ctx->ingest);
     if (ctx->aux) (void)hipFree(ctx->aux);
     for (int i = 0; i < DFE_NSLOT; ++i) {

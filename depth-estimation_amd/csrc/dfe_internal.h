@@ -32,6 +32,7 @@ enum DfeOpt {
     DFE_OPT_CONV_NARROW,      // batched convolution: 64 x 16 output tiles (0: 128 x 8; automatic: for kernels of 9 x 9 and larger)
     DFE_OPT_CONV_MFMA,        // one-call models: filter layers as implicit GEMMs on the matrix cores (fused multiply-adds; default 0 = exact kernels)
     DFE_OPT_FM_MFMA,          // feature matcher as a banded GEMM on the matrix cores, |a|^2 + |b|^2 - 2 a.b (default 0 = exact k-ordered sums)
+    DFE_OPT_ARENA_CONTIG,     // scratch arena from physically contiguous memory (hipDeviceMallocContiguous; 0: plain hipMalloc)
     DFE_NOPT
 };
 struct DfeOptName { const char *key; const char *env; bool env_presence_means_zero; };
@@ -51,8 +52,10 @@ struct dfe_ctx {
     int cv_tyq = 0;                   // 0 = pick the tile height per shape; else dfe_set_cost_volume_tile's code (tuning / tests)
     int ncu = 256;                    // compute units of the device
     const char *last_kernel = "";
-    void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx)
+    void *scratch = nullptr;          // grow-only device arena (never shrinks; freed with the ctx), physically contiguous where the driver grants it
     size_t scratch_bytes = 0;
+    void *scratch_plain = nullptr;    // the arena of the paths that run learned filter stacks: a plain hipMalloc (dfe_scratch's `plain`)
+    size_t scratch_plain_bytes = 0;
     size_t scratch_limit = (size_t)16 << 30;   // cost-volume bands are sized to fit (dfe_set_scratch_limit)
     void *ingest = nullptr;           // grow-only fp32 copy of a uint8 frame pair (ingest.hip), freed with the ctx
     size_t ingest_bytes = 0;
@@ -177,7 +180,9 @@ struct CvFineArgs {
 int cv_frames_finest_fused(dfe_ctx *ctx, const float *I0p, const float *I1p, int C, int Hp, int Wp, int k, int maxh, int maxw, const CvFineArgs &fine,
                            bool *handled);
 bool cv_finest_plan_ok(dfe_ctx *ctx, int Hp, int Wp, int maxh, int maxw);   // cv_frames_finest_fused (with a parent scale) would take this frame
-int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out);   // arena of at least `bytes`
+// arena of at least `bytes`.  plain = false: physically contiguous memory if the driver has it (the volume sweeps' arena); plain = true: a
+// plain hipMalloc, for the paths whose convolutions write many feature planes side by side (see dfe_scratch in dfe_ctx.hip for both measurements)
+int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out, bool plain = false);
 // one layer of a filter stack (filters.hip): in [nIn][H][W] -> out [nOut][H-kH+1][W-kW+1], nn.Tanh fused behind it when
 // L.tanh_after (the same tanhf as dfe_tanh_f32: bit-identical to the two separate calls)
 int dfe_filter_layer_forward(dfe_ctx *ctx, const float *in, const dfe_filter_layer &L, int H, int W, float *out);

@@ -1044,7 +1044,7 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
     // the per-scale cost volumes below use the same arena for their own temporaries only through cv_frames_dispatch, which
     // needs none; one allocation up front keeps every stage's buffers alive until the cascade has read them
     void *scr = nullptr;
-    rc = dfe_scratch(ctx, total, &scr);
+    rc = dfe_scratch(ctx, total, &scr, filt != nullptr);   // (learned filters: the convolutions' arena, see dfe_scratch)
     if (rc) return rc;
     // the same call again (same buffers, shapes and arena): replay its launches as a graph
     struct { const void *I0, *I1, *flow, *idx, *scr; int C, H, W, k, maxh, maxw, nratios, ratios[DFE_MAX_RATIOS]; float f16, u8; } gkey;

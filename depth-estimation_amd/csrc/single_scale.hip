@@ -109,7 +109,7 @@ extern "C" int dfe_flow_pair_filtered_f32(dfe_ctx *ctx, const float *I0, const f
     const size_t f_vol = lean ? 0 : (size_t)P1 * N;
     const size_t f_idx = (lean || index) ? 0 : (size_t)P1 * 2, f_sc = (lean || scores || !use_threshold) ? 0 : (size_t)P1;
     void *scr = nullptr;
-    int rc = dfe_scratch(ctx, (al(f_c0) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_in1) + 2 * al(f_vol) + al(f_idx) + al(f_sc)) * sizeof(float), &scr);
+    int rc = dfe_scratch(ctx, (al(f_c0) + 2 * al(f_fa) + 2 * al(f_fb) + al(f_in1) + 2 * al(f_vol) + al(f_idx) + al(f_sc)) * sizeof(float), &scr, nlayers > 0);
     if (rc) return rc;
     float *c0 = (float *)scr;
     float *fa[2] = {c0 + al(f_c0), c0 + al(f_c0) + al(f_fa)};

@@ -235,6 +235,9 @@ extern __shared__ __attribute__((aligned(16))) char dfe_smem[];
 #ifndef DFE_LEAD_FROM_IMAGE
 #define DFE_LEAD_FROM_IMAGE 1
 #endif
+#ifndef DFE_Q_UNDEF
+#define DFE_Q_UNDEF 1
+#endif
 #ifndef DFE_ROLES_STATIC
 #define DFE_ROLES_STATIC 1
 #endif
@@ -1316,6 +1319,11 @@ __global__ __launch_bounds__(1024) void ssd_cv_rowimg_kernel(const float *__rest
 #pragma unroll
                         for (int x = 0; x < TQ; ++x) st[(TQ * (wave - QW0) + x) * D + dqf] = v[x];
                     }
+                } else if constexpr (K == 7 && DFE_Q_UNDEF) {
+                    // the other waves never read their quarter state: "redefine" the two slots the task would have written, so that the join
+                    // of the two paths needs no register copies on this side (4 v_mov per row on 12 waves otherwise)
+#pragma unroll
+                    for (int x = 0; x < TQ; ++x) asm volatile("" : "=v"(ringq[(m + 5) % 6][x]), "=v"(ringq[m][x]));
                 }
             };
             auto do_mini = [&]() {

@@ -29,6 +29,8 @@ int dfe_set_option(dfe_ctx *ctx, const char *key, int value);
 int dfe_get_option(dfe_ctx *ctx, const char *key, int *value);
 const char *dfe_last_kernel(const dfe_ctx *ctx);
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
+int dfe_device_alloc(dfe_ctx *ctx, size_t bytes, void **ptr, int *contiguous);
+int dfe_device_free(dfe_ctx *ctx, void *ptr);
 int dfe_profile_enable(dfe_ctx *ctx, int on);
 int dfe_profile_read(dfe_ctx *ctx, double *total_ms, int *launches);
 int dfe_profile_read_each(dfe_ctx *ctx, double *total_ms, int *launches, float *each_ms, int cap);

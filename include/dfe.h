@@ -78,7 +78,7 @@ int dfe_set_cost_volume_tile(dfe_ctx *ctx, int tyq);
 /* Behaviour switches of the launchers (tuning and tests; none is needed for correct results -- every choice has a parity test or is
  * a pure scheduling choice).  value >= 0 forces, -1 restores the launcher's own choice per shape.  Keys: "cascade_px", "fine_fuse",
  * "mid_fuse", "fine_nq", "mid_nq", "prep_tiles", "xpose", "xpose_nt", "soft_epilogue", "conv_batch", "conv_nt10", "fm64", "fm_rows",
- * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
+ * "sweep_ovh", "sweep_blocks", "debug_arena", "fm_flat", "fm_split", "conv_narrow", "conv_mfma", "fm_mfma", "arena_contig", "graphs".  The library reads the environment ONCE, in dfe_ctx_create
  * (DFE_<KEY> variables of the tuning scripts) -- never inside an op, so an op's behaviour depends on its ctx only.
  * Two keys trade the exact arithmetic for the matrix cores, both OFF unless set to 1: "conv_mfma" (the one-call models' filter layers as
  * implicit GEMMs, v_mfma_f32_16x16x4_f32: the reference's (input plane, ky, kx) order with FUSED multiply-adds, <= 1e-5 relative to
@@ -94,6 +94,14 @@ const char *dfe_last_kernel(const dfe_ctx *ctx);
 /* upper bound for the ctx scratch arena that holds a materialised cost volume inside the one-call
  * pipelines (default 16 GiB); larger volumes are processed in bands of output rows */
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
+/* device memory for a caller-owned cost volume (the `out` of dfe_ssd_cost_volume_f32 and friends): physically contiguous where the driver
+ * grants it (hipExtMallocWithFlags + hipDeviceMallocContiguous), a plain hipMalloc otherwise; *contiguous (may be NULL) says which.  The
+ * sweeps write a volume at up to 10 % more bytes per second into contiguous memory (large page-table fragments; the ctx's own arena is
+ * allocated the same way, option "arena_contig").  Any device pointer works as `out`; this is the allocation that is fastest to fill.
+ * replaces: torch.Tensor():resize() of the matcher's output on the reference side (SpatialMatching.lua:24), for callers that want the
+ * placement.  dfe_device_free releases it (NULL is allowed). */
+int dfe_device_alloc(dfe_ctx *ctx, size_t bytes, void **ptr, int *contiguous);
+int dfe_device_free(dfe_ctx *ctx, void *ptr);
 /* per-launch HIP-event timing of the cost-volume kernel on the ctx stream (bench.py's roofline):
  * enable, run, then read the summed kernel time and launch count (read synchronises and resets) */
 int dfe_profile_enable(dfe_ctx *ctx, int on);

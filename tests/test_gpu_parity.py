@@ -1408,3 +1408,45 @@ def test_pipelined_ingest_equals_the_serial_u8_entry(dfe, cuda):
         for a, b in zip(g, w_):
             assert torch.equal(a, b), i
     assert lib.dfe_flow_depth_pair_u8_slot(ctx.handle, 7, 3, H, W, k, win, win, 70.0, 40.0, 0.21, 1.0, *(t.data_ptr() for t in got[0])) != 0   # no such slot
+
+
+def test_device_alloc_and_arena_placement_do_not_change_results(dfe, cuda):
+    """dfe_device_alloc / dfe_device_free (include/dfe.h): a caller-owned volume in the library's memory (physically contiguous where the driver
+    grants it) holds exactly what a torch-allocated one holds and what the oracle computes; the one-call pipeline gives the same bits with the
+    ctx arena contiguous (default) or a plain hipMalloc (option arena_contig = 0, a fresh context each so that each really allocates)."""
+    from ctypes import c_int, c_void_p
+    from depth_estimation_amd.context import Context
+
+    lib = dfe.lib()
+    ctx = dfe.get_ctx(0)
+    H, W, k, win = 70, 150, 7, 33
+    f0, f1, _, (cx, cy) = rp.synth_pair(H, W, C=3, seed=12, max_flow=9)
+    t0, t1 = T(f0, cuda), T(f1, cuda)
+    Ho, Wo = H - k + 1 - win + 1, W - k + 1 - win + 1
+    ref = torch.empty((Ho, Wo, win, win), device=cuda)
+    ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, ref.data_ptr()))
+    assert np.array_equal(ref.cpu().numpy(), orc.ssd_cost_volume(f0, f1, k, k, win, win))
+    p, contig = c_void_p(), c_int(-1)
+    ctx.check(lib.dfe_device_alloc(ctx.handle, ref.numel() * 4, byref(p), byref(contig)))
+    assert p.value and contig.value in (0, 1)
+    ctx.check(lib.dfe_ssd_cost_volume_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, k, win, win, p))
+    back = torch.empty_like(ref)
+    torch.cuda.synchronize()
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(c_void_p(back.data_ptr()), p, ctypes.c_size_t(ref.numel() * 4), c_int(3)) == 0
+    assert torch.equal(back, ref)
+    ctx.check(lib.dfe_device_free(ctx.handle, p))
+    ctx.check(lib.dfe_device_free(ctx.handle, None))
+    assert lib.dfe_device_alloc(ctx.handle, 0, byref(p), None) != 0
+    res = []
+    for contig_opt in (1, 0):
+        c2 = Context(0)
+        c2.set_option("arena_contig", contig_opt)
+        o = [torch.full((2, H, W), -9.0, device=cuda)] + [torch.full((H, W), -9.0, device=cuda) for _ in range(3)]
+        c2.check(lib.dfe_flow_depth_pair_f32(c2.handle, t0.data_ptr(), t1.data_ptr(), 3, H, W, k, win, win, cx, cy, 0.21, *(t.data_ptr() for t in o)))
+        torch.cuda.synchronize()
+        res.append(o)
+        del c2
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
