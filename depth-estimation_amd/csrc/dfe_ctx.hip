@@ -38,11 +38,12 @@ int dfe_scratch(dfe_ctx *ctx, size_t bytes, void **out, bool plain) {
         arena_bytes = 0;
         hipError_t e = hipErrorUnknown;
         bool contig = false;
-        // Physically contiguous memory first: the driver then maps the arena with large page-table fragments.  A plain hipMalloc of this
-        // size is usually assembled from scattered 2 MiB (or smaller) pieces, and the sweeps -- whose blocks together write a fresh 2.6 MB
-        // volume row every ~2 us -- then lose up to 10 % to translation misses (vga-luma 0.250 against 0.224 ms per pair in EVERY context of
-        // a process; vga-pyramid 0.077 -> 0.073, 720p-radial 0.180 -> 0.172: tools/mode_probe.py, profiles/r05_q_*, r05_r_*).  Falls back to
-        // hipMalloc when no such range is free.
+        // Physically contiguous memory first.  A plain hipMalloc of this size is assembled from scattered pieces, and how they happen to
+        // lie decides up to 10 % of a sweep's time: vga-luma 0.250 against 0.224 ms per pair, the same in EVERY call on a given arena, one
+        // plain arena in three to six fast, every contiguous one fast; vga-pyramid 0.077 -> 0.073, 720p-radial 0.180 -> 0.172
+        // (tools/mode_probe.py, profiles/r05_q_*, r05_r_*).  The per-CU translation counters are the same for both kinds
+        // (profiles/r05_v_*): the difference is behind the L2, in how the physical layout spreads the sweep's row-sized write streams
+        // over DRAM channels and banks.  Falls back to hipMalloc when no contiguous range is free.
         // `plain` callers: the batched convolution writes 4..32 feature planes side by side from every block; in contiguous memory the
         // planes' fixed distance puts those streams on the same channels (conv 4 -> 10 planes: 45.6 against 36.1 us for a VGA pair,
         // vga-learned 0.211 against 0.196 ms, tools/conv_place_probe.py), which scattered pages break up.

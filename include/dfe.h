@@ -96,7 +96,7 @@ const char *dfe_last_kernel(const dfe_ctx *ctx);
 int dfe_set_scratch_limit(dfe_ctx *ctx, size_t bytes);
 /* device memory for a caller-owned cost volume (the `out` of dfe_ssd_cost_volume_f32 and friends): physically contiguous where the driver
  * grants it (hipExtMallocWithFlags + hipDeviceMallocContiguous), a plain hipMalloc otherwise; *contiguous (may be NULL) says which.  The
- * sweeps write a volume at up to 10 % more bytes per second into contiguous memory (large page-table fragments; the ctx's own arena is
+ * sweeps write a volume at up to 10 % more bytes per second into contiguous memory than into an unlucky plain allocation (the ctx's own arena is
  * allocated the same way, option "arena_contig").  Any device pointer works as `out`; this is the allocation that is fastest to fill.
  * replaces: torch.Tensor():resize() of the matcher's output on the reference side (SpatialMatching.lua:24), for callers that want the
  * placement.  dfe_device_free releases it (NULL is allowed). */

@@ -17,7 +17,7 @@ tail -1 gpurun_out/${tag}_smoke.log
 timeout -k 10 600 python bench.py > gpurun_out/${tag}_bench_default.log 2>&1 || { tail -5 gpurun_out/${tag}_bench_default.log; exit 1; }
 tail -1 gpurun_out/${tag}_bench_default.log | cut -c1-600
 bash tools/bench_all.sh $tag || exit $?
-bash tools/kstats.sh $tag vga vga-f16 720p-radial vga-pyramid vga-pyramid-learned 1080p-pyramid-learned 1080p-pyramid-f16 version2-vga time-matching > gpurun_out/${tag}_kstats.log 2>&1 || { tail -5 gpurun_out/${tag}_kstats.log; exit 1; }
+bash tools/kstats.sh $tag vga vga-f16 720p-radial vga-pyramid vga-pyramid-learned 1080p-pyramid-learned 1080p-pyramid-f16 version2-vga version2-vga-mfma vga-learned vga-luma time-matching > gpurun_out/${tag}_kstats.log 2>&1 || { tail -5 gpurun_out/${tag}_kstats.log; exit 1; }
 cat gpurun_out/${tag}_kstats.log
 timeout -k 10 300 python tools/time_version2.py > gpurun_out/${tag}_time_version2.log 2>&1 || { tail -5 gpurun_out/${tag}_time_version2.log; exit 1; }
 grep -v amdgpu.ids gpurun_out/${tag}_time_version2.log

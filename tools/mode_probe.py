@@ -20,10 +20,10 @@ flow = torch.empty((2, H, W), device=dev); scores = torch.empty((H, W), device=d
 lib = d.lib()
 
 
-def timeit(ctx, n=150):
+def timeit(ctx, n=int(os.environ.get('PROBE_N', '150'))):
     def step():
         ctx.check(lib.dfe_flow_depth_pair_f32(ctx.handle, t0.data_ptr(), t1.data_ptr(), Cc, H, W, k, hWin, wWin, cx, cy, 0.21, flow.data_ptr(), scores.data_ptr(), depth.data_ptr(), dconf.data_ptr()))
-    for _ in range(20): step()
+    for _ in range(int(os.environ.get('PROBE_WARM', '20'))): step()
     torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(n): step()
