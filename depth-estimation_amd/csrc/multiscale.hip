@@ -947,6 +947,9 @@ int fill_cascade(dfe_ctx *ctx, CascadeGeom &g, const int *ratios, int nratios, i
     return DFE_OK;
 }
 
+#ifndef DFE_PREP_EPT
+#define DFE_PREP_EPT 8     // elements per thread of prep_scales_kernel (tuning)
+#endif
 int grid1d(long long n, int per_block) {
     long long b = (n + per_block - 1) / per_block;
     if (b > 256 * 32) b = 256 * 32;
@@ -1134,10 +1137,10 @@ static int multiscale_flow_pair(dfe_ctx *ctx, const float *I0, const float *I1, 
                 hipLaunchKernelGGL(prep_tiles_kernel<float>, dim3(dfe_cdiv(W, PT), dfe_cdiv(H, PT), 2 * C), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, pq, 0.f);
         } else {
             if (u8_scale > 0.f)
-                hipLaunchKernelGGL(prep_scales_kernel<unsigned char>, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream,
+                hipLaunchKernelGGL(prep_scales_kernel<unsigned char>, dim3(grid1d(prep_max, 256 * DFE_PREP_EPT), nratios), dim3(256), 0, ctx->stream,
                                    (const unsigned char *)I0, (const unsigned char *)I1, C, H, W, pl, pt, ps, u8_scale);
             else
-                hipLaunchKernelGGL(prep_scales_kernel<float>, dim3(grid1d(prep_max, 256 * 8), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps, 0.f);
+                hipLaunchKernelGGL(prep_scales_kernel<float>, dim3(grid1d(prep_max, 256 * DFE_PREP_EPT), nratios), dim3(256), 0, ctx->stream, I0, I1, C, H, W, pl, pt, ps, 0.f);
         }
         DFE_LAUNCH_CHECK(ctx);
     }
