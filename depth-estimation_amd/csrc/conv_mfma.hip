@@ -16,6 +16,15 @@
 //   exact zeros to the chain.
 #include "dfe_internal.h"
 
+#ifndef DFE_CM_ROTPRIO
+#define DFE_CM_ROTPRIO 0
+#endif
+#ifndef DFE_CM_SCHED
+#define DFE_CM_SCHED 1
+#endif
+#ifndef DFE_CM_ABL
+#define DFE_CM_ABL 0   // tuning: 1 = the step loop without its LDS reads, 2 = no output stores, 3 = no staging of the next tile
+#endif
 namespace {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
     int cur = 0;
     for (; t < ntiles; t += gridDim.x) {
         const int tn = t + gridDim.x;
-        if (tn < ntiles) load_tile(tn);                             // (in flight behind the step loop)
+        if (tn < ntiles && DFE_CM_ABL != 3) load_tile(tn);          // (in flight behind the step loop)
         const char *tb = reinterpret_cast<const char *>(tile0 + cur * TSZ + abase);
         f4v acc[NT];
 #pragma unroll
@@ -177,26 +186,95 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
         }
         const int *kp = ktab + kq;                                  // lane (m, kq) walks k = 4 s + kq
         const float *wp = wl + (kq * 16 + m) * NT;
-        int off[CH];
+        // Two register sets: a chunk's operands are requested one chunk AHEAD, behind the MFMAs of the chunk before it, so that a wave's
+        // reads never wait in front of its own MFMAs.  (One set -- reads, wait, MFMAs -- left the matrix pipe idle whenever the four waves
+        // of a SIMD, which leave every barrier in phase, all sat in their reads at once: 74 % MFMA-busy by the counters,
+        // profiles/r05_y_pmc_version2_mfma.txt.)
+        int off[CH] = {};
+        float a0[CH], a1[CH];
+        bv_t b0[CH], b1[CH];
+        auto fetch = [&](float (&a)[CH], bv_t (&b)[CH]) {
+#if DFE_CM_ABL == 1
 #pragma unroll
-        for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];
-        for (int s = 0; s < steps; s += CH) {
-            float a[CH];
-            bv_t b[CH];
+            for (int j = 0; j < CH; ++j) { a[j] = __int_as_float(off[j]); for (int nt = 0; nt < NT; ++nt) b[j][nt] = __int_as_float(off[j] + nt); }
+#else
 #pragma unroll
             for (int j = 0; j < CH; ++j) a[j] = *reinterpret_cast<const float *>(tb + off[j]);
 #pragma unroll
             for (int j = 0; j < CH; ++j) b[j] = *reinterpret_cast<const bv_t *>(wp + j * 4 * 16 * NT);
+#endif
             wp += CH * 4 * 16 * NT;
             kp += 4 * CH;
-            if (s + CH < steps) {
+        };
+        auto taps = [&]() {
+#if DFE_CM_ABL == 1
 #pragma unroll
-                for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];    // the next chunk's taps: in flight behind this chunk's MFMAs
-            }
+            for (int j = 0; j < CH; ++j) off[j] += j;
+#else
+#pragma unroll
+            for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];
+#endif
+        };
+        auto mm = [&](const float (&a)[CH], const bv_t (&b)[CH]) {
+#if DFE_CM_ABL == 4
+#pragma unroll
+            for (int j = 0; j < CH; ++j) asm volatile("" ::"v"(a[j]), "v"(b[j]));
+#else
 #pragma unroll
             for (int j = 0; j < CH; ++j)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][nt], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][nt], acc[nt], 0, 0, 0);
+#if DFE_CM_ABL == 5
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j][nt], acc[nt], 0, 0, 0);
+#endif
+                }
+#endif
+        };
+        // (the scheduler is told to put one operand read and one address add behind every MFMA instead of all 24 reads in front of the
+        //  sixteen MFMAs: a wave that runs ALONE on its SIMD -- the last one of a tile, the matrix pipe's arbitration is not fair -- then
+        //  still keeps the pipe busy: DFE_CM_SCHED)
+        auto interleave = [&]() {
+#if DFE_CM_SCHED
+#pragma unroll
+            for (int q = 0; q < CH * NT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // one VALU (an A address)
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+            }
+#endif
+        };
+        const int nch = steps / CH;
+        taps();
+        fetch(a0, b0);                                               // chunk 0
+        taps();                                                      // (one chunk past the end: reads initialised LDS, never used)
+        int c = 0;
+        for (; c + 2 < nch; c += 2) {                                // a0 / b0 hold chunk c
+#if DFE_CM_ROTPRIO
+            // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one pair of chunks each: whatever the
+            // arbiter's own order is, they now advance together and reach the tile's barrier together
+            switch (((wave >> 2) + (c >> 1)) & 3) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+#endif
+            fetch(a1, b1);
+            taps();
+            mm(a0, b0);
+            interleave();
+            fetch(a0, b0);
+            taps();
+            mm(a1, b1);
+            interleave();
+        }
+        if (c + 1 < nch) {
+            fetch(a1, b1);
+            mm(a0, b0);
+            mm(a1, b1);
+        } else {
+            mm(a0, b0);
         }
         {
             int ent, x0, y0;
@@ -224,7 +302,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
                         if (x + q < Wo) o[q] = sq[q];
                 }
             }
-            if (y < Ho) {
+            if (y < Ho && (DFE_CM_ABL != 2 || acc[0][0] == 1234.5f)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int plane = nt * 16 + m;
@@ -241,8 +319,10 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
                 }
             }
         }
-        if (tn < ntiles) store_tile(tile0 + (cur ^ 1) * TSZ);
-        __syncthreads();
+        if (tn < ntiles && DFE_CM_ABL != 3) store_tile(tile0 + (cur ^ 1) * TSZ);
+        // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. every wave would wait here until the tile's output stores are
+        // acknowledged by the memory -- with nothing on the matrix pipe meanwhile
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         cur ^= 1;
     }
 }

@@ -20,12 +20,25 @@
 //   B operand at an immediate offset.
 #include "dfe_internal.h"
 
+#ifndef DFE_FMM_PIPE
+#define DFE_FMM_PIPE 1
+#endif
+#ifndef DFE_FMM_KC16
+#define DFE_FMM_KC16 1
+#endif
 namespace {
+
+template <int I, int N, class F> __device__ __forceinline__ void fmm_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fmm_static_for<I + 1, N>(f);
+    }
+}
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int FMM_R = 8;     // output rows per block (= waves)
-constexpr int FMM_KC = 8;    // planes per stage (two MFMA k-steps)
+constexpr int FMM_KC = 8;    // planes per stage (two MFMA k-steps); the arg-min form takes 16 where K % 16 == 0
 constexpr int FMM_T = FMM_R * 64;
 
 struct FmmArgs {
@@ -68,10 +81,10 @@ __device__ __forceinline__ void fmm_glds16(unsigned voff, const void *sbase, con
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(la) : "memory");
 }
 
-template <int MH, int MW, bool ARGMIN>
+template <int MH, int MW, bool ARGMIN, int KC = FMM_KC>
 __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
     static_assert(MW == 16 || MW == 17, "the band is one tile and a triangle of the next");
-    constexpr int R = FMM_R, KC = FMM_KC;
+    constexpr int R = FMM_R;
     constexpr int BROWS = (R + MH - 1 + 3) & ~3;          // in2 rows of a tile (20: rounded up so that requests of 2 / 4 / 8 rows tile it)
     constexpr int BPS = BROWS * 32 + 16;                  // floats per staged in2 plane (+16: lanes kq and kq + 1 on different banks)
     constexpr int APS = R * 16;                           // ... per staged in1 plane (one A read per 2 MH MFMAs: its 2-way conflict does not matter)
@@ -182,6 +195,42 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
             const float *sb = fmm_smem + (gs & 1) * BUF;
             const float *Bw = sb + kq * BPS + wave * 32 + j;          // lane (j, kq): in2 plane kq, tile row wave + dy, column 16 tile + j
             const float *Aw = sb + KC * BPS + kq * APS + wave * 16 + j;
+            if constexpr (ARGMIN && DFE_FMM_PIPE) {
+                // The operands of k-step ks + 1 are requested BETWEEN the MFMAs of k-step ks (one read behind every MFMA: the scheduler is told
+                // so), in a second register set -- the arg-min form has the registers (no volume addressing).  With all reads in front of a
+                // k-step's MFMAs the two waves of a SIMD, which leave every barrier together, both sat in their reads at once and the matrix
+                // pipe idled a quarter of the time; only the first k-step of a stage is still exposed (its data arrive behind a barrier).
+                float ac = -2.f * Aw[0];
+                float bc[MH][2];
+#pragma unroll
+                for (int dy = 0; dy < MH; ++dy) { bc[dy][0] = Bw[dy * 32]; bc[dy][1] = Bw[dy * 32 + 16]; }
+                __builtin_amdgcn_sched_barrier(0);                    // (the first k-step's reads stay in front of its MFMAs)
+                fmm_static_for<0, KC / 4>([&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value;
+                    float an = 0.f;
+                    float bn[MH][2];
+                    if constexpr (ks + 1 < KC / 4) {
+                        an = -2.f * Aw[(ks + 1) * 4 * APS];
+#pragma unroll
+                        for (int dy = 0; dy < MH; ++dy) { bn[dy][0] = Bw[(ks + 1) * 4 * BPS + dy * 32]; bn[dy][1] = Bw[(ks + 1) * 4 * BPS + dy * 32 + 16]; }
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < MH; ++dy)
+#pragma unroll
+                        for (int tl = 0; tl < 2; ++tl) acc[dy][tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac, bc[dy][tl], acc[dy][tl], 0, 0, 0);
+                    if constexpr (ks + 1 < KC / 4) {
+#pragma unroll
+                        for (int n = 0; n < 2 * MH; ++n) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read of the next k-step
+                        }
+                        ac = an;
+#pragma unroll
+                        for (int dy = 0; dy < MH; ++dy) { bc[dy][0] = bn[dy][0]; bc[dy][1] = bn[dy][1]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
 #pragma unroll
             for (int ks = 0; ks < KC / 4; ++ks) {
                 // all 2 MH + 1 operands of the k-step are requested before its first MFMA
@@ -195,6 +244,7 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) acc[dy][tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[dy][tl], acc[dy][tl], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my requests of the next stage have landed; behind the barrier everyone's have
             __syncthreads();
@@ -309,8 +359,13 @@ int dfe_feat_matching_mfma(dfe_ctx *ctx, const float *in1, const float *in2, int
     a.gx = dfe_cdiv(W1, 16); a.ntiles = a.gx * dfe_cdiv(H1, FMM_R);
     a.lWin = (maxw + 1) / 2 - 1; a.tWin = (maxh + 1) / 2 - 1;
     const int BROWS = (FMM_R + maxh - 1 + 3) & ~3;
-    const size_t lds = ((size_t)2 * (FMM_KC * (BROWS * 32 + 16) + FMM_KC * (FMM_R * 16)) + (size_t)2 * BROWS * 32) * sizeof(float);
-    void (*kern)(FmmArgs) = out ? (maxh == 17 ? fmm_kernel<17, 17, false> : fmm_kernel<16, 16, false>) : (maxh == 17 ? fmm_kernel<17, 17, true> : fmm_kernel<16, 16, true>);
+    // the arg-min form stages 16 planes at a time where K allows it: three of four k-steps then have their operands requested behind MFMAs
+    const bool kc16 = DFE_FMM_KC16 && !out && K % 16 == 0;
+    const int KC = kc16 ? 16 : FMM_KC;
+    const size_t lds = ((size_t)2 * (KC * (BROWS * 32 + 16) + KC * (FMM_R * 16)) + (size_t)2 * BROWS * 32) * sizeof(float);
+    void (*kern)(FmmArgs) = out      ? (maxh == 17 ? fmm_kernel<17, 17, false> : fmm_kernel<16, 16, false>)
+                            : kc16 ? (maxh == 17 ? fmm_kernel<17, 17, true, 16> : fmm_kernel<16, 16, true, 16>)
+                                   : (maxh == 17 ? fmm_kernel<17, 17, true> : fmm_kernel<16, 16, true>);
     DFE_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int nblk = a.ntiles < ctx->ncu ? a.ntiles : ctx->ncu;
     {

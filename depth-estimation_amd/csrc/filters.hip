@@ -459,16 +459,19 @@ struct CnFused {
     float threshold, thresval;
     CnKernel kk;
 };
-constexpr int CN_TW = 64, CN_TH = 16;
+constexpr int CN_TW = 64, CN_TH = 16, CN_CG = 3;
 extern __shared__ float cn_smem[];
 
 template <int MODE, int KT>   // KT: the kernel size as a constant (taps unrolled, coefficients in scalar registers), 0 = any size <= CN_MAXK
 __global__ __launch_bounds__(256) void cn_fused_kernel(CnFused a) {
 #pragma clang fp contract(off)
     const int k = KT ? KT : a.kk.k, pl = k / 2, RH = CN_TH + k - 1, SW = CN_TW + k - 1;
-    float *src = cn_smem;                   // [RH][SW] the plane's tile with its halo, zero outside the frame
-    float *tmpl = src + RH * SW;            // [RH][TW] after the horizontal pass
-    float *qt = tmpl + RH * CN_TW;          // [RH][SW] MODE 1: est / coef on the halo'd tile
+    // up to CN_CG planes are staged and filtered together (round 5: one plane at a time meant three barriers per plane -- nine for an RGB
+    // frame -- in a kernel whose 600 blocks are a launch of two rounds: 30 + 22 us per VGA pair, nearly all of it latency)
+    float *src = cn_smem;                   // [CG][RH][SW] the planes' tiles with their halo, zero outside the frame
+    float *tmpl = src;                      // [CG][RH][TW] after the horizontal pass: OVER the tiles (the pass goes through registers), so that
+                                            // a block needs 31 / 41 KB and every block of a VGA pair is resident at once
+    float *qt = src + CN_CG * RH * SW;      // [RH][SW] MODE 1: est / coef on the halo'd tile
     float *kl = qt + (MODE == 1 ? RH * SW : 0);   // KT == 0: the coefficients (a run-time index into the argument block would be a scalar load per tap)
     const int f = blockIdx.z, H = a.H, W = a.W, C = a.C;
     const float *in = a.in[f];
@@ -488,38 +491,62 @@ __global__ __launch_bounds__(256) void cn_fused_kernel(CnFused a) {
         }
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < C; ++c) {
-        __syncthreads();                    // the previous plane's vertical pass is done with tmpl (and everyone with src)
+    for (int c0 = 0; c0 < C; c0 += CN_CG) {
+        const int nc = min(CN_CG, C - c0);
+        __syncthreads();                    // the previous group's vertical pass is done with tmpl (and everyone with src)
         for (int i = threadIdx.x; i < RH * SW; i += 256) {
             const int r = i / SW, cc = i - r * SW, yy = y0 + r - pl, xx = x0 + cc - pl;
-            float v = 0.f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                v = in[c * P + (long long)yy * W + xx];
-                if (MODE == 1) { const float y = v - qt[i]; v = y * y; }      // (qt[i] is this thread's own write)
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            float v[CN_CG];
+#pragma unroll
+            for (int g = 0; g < CN_CG; ++g) v[g] = (ok && g < nc) ? in[(c0 + g) * P + (long long)yy * W + xx] : 0.f;   // (all planes' loads in flight together)
+#pragma unroll
+            for (int g = 0; g < CN_CG; ++g) {
+                if (g >= nc) break;
+                float w = v[g];
+                if (MODE == 1 && ok) { const float y = w - qt[i]; w = y * y; }      // (qt[i] is this thread's own write)
+                src[g * RH * SW + i] = w;
             }
-            src[i] = v;
         }
         __syncthreads();
-        for (int r = ty; r < RH; r += 4) {
-            const float *sr = src + r * SW + tx;
-            float t = 0.f;
-            if (KT) {
+        constexpr int NR = (CN_TH + (KT ? KT : CN_MAXK) - 1 + 3) / 4;   // rows of the horizontal pass per thread
+        float hp[CN_CG][NR];
 #pragma unroll
-                for (int v = 0; v < (KT ? KT : 1); ++v) t = t + kn(v) * sr[v];
-            } else {
-                for (int v = 0; v < k; ++v) t = t + kn(v) * sr[v];
+        for (int g = 0; g < CN_CG; ++g)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int r = ty + 4 * n;
+                float t = 0.f;
+                if (g < nc && r < RH) {
+                    const float *sr = src + g * RH * SW + r * SW + tx;
+                    if (KT) {
+#pragma unroll
+                        for (int v = 0; v < (KT ? KT : 1); ++v) t = t + kn(v) * sr[v];
+                    } else {
+                        for (int v = 0; v < k; ++v) t = t + kn(v) * sr[v];
+                    }
+                }
+                hp[g][n] = t;
             }
-            tmpl[r * CN_TW + tx] = t;
-        }
+        __syncthreads();                    // everyone has read the tiles: their space takes the horizontal pass's results
+#pragma unroll
+        for (int g = 0; g < CN_CG; ++g)
+#pragma unroll
+            for (int n = 0; n < NR; ++n) {
+                const int r = ty + 4 * n;
+                if (g < nc && r < RH) tmpl[g * RH * CN_TW + r * CN_TW + tx] = hp[g][n];
+            }
         __syncthreads();
+        for (int g = 0; g < nc; ++g) {      // (plane outer, tap inner: the term order of the stand-alone passes)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float *tc = tmpl + (ty + 4 * j) * CN_TW + tx;
-            if (KT) {
+            for (int j = 0; j < 4; ++j) {
+                const float *tc = tmpl + g * RH * CN_TW + (ty + 4 * j) * CN_TW + tx;
+                if (KT) {
 #pragma unroll
-                for (int u = 0; u < (KT ? KT : 1); ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
-            } else {
-                for (int u = 0; u < k; ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
+                    for (int u = 0; u < (KT ? KT : 1); ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
+                } else {
+                    for (int u = 0; u < k; ++u) s[j] = s[j] + kn(u) * tc[u * CN_TW];
+                }
             }
         }
     }
@@ -589,14 +616,13 @@ int dfe_contrastive_normalization_run2(dfe_ctx *ctx, const float *in0, const flo
     a.C = C; a.H = H; a.W = W; a.threshold = threshold; a.thresval = thresval;
     const dim3 grid(dfe_cdiv(W, CN_TW), dfe_cdiv(H, CN_TH), nf);
     const int RH = CN_TH + k - 1, SW = CN_TW + k - 1;
-    const size_t lds0 = ((size_t)RH * SW + (size_t)RH * CN_TW + CN_MAXK) * sizeof(float), lds1 = lds0 + (size_t)RH * SW * sizeof(float);
-    if (k == 17) {
-        hipLaunchKernelGGL((cn_fused_kernel<0, 17>), grid, dim3(256), lds0, ctx->stream, a);
-        hipLaunchKernelGGL((cn_fused_kernel<1, 17>), grid, dim3(256), lds1, ctx->stream, a);
-    } else {
-        hipLaunchKernelGGL((cn_fused_kernel<0, 0>), grid, dim3(256), lds0, ctx->stream, a);
-        hipLaunchKernelGGL((cn_fused_kernel<1, 0>), grid, dim3(256), lds1, ctx->stream, a);
-    }
+    const size_t lds0 = ((size_t)CN_CG * RH * SW + CN_MAXK) * sizeof(float), lds1 = lds0 + (size_t)RH * SW * sizeof(float);
+    void (*k0)(CnFused) = k == 17 ? cn_fused_kernel<0, 17> : cn_fused_kernel<0, 0>;
+    void (*k1)(CnFused) = k == 17 ? cn_fused_kernel<1, 17> : cn_fused_kernel<1, 0>;
+    if (lds0 > 64 * 1024) DFE_HIP(ctx, hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+    if (lds1 > 64 * 1024) DFE_HIP(ctx, hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    hipLaunchKernelGGL(k0, grid, dim3(256), lds0, ctx->stream, a);
+    hipLaunchKernelGGL(k1, grid, dim3(256), lds1, ctx->stream, a);
     DFE_LAUNCH_CHECK(ctx);
     return DFE_OK;
 }

@@ -1198,6 +1198,12 @@ def test_contrastive_normalization_equals_oracle(dfe, cuda):
         ref = orc.contrastive_normalization(x, g)
         assert np.array_equal(out, ref)
         assert abs(float(out.mean())) < 0.05 and 0.5 < float(out.std()) < 1.5
+    # plane counts other than 3: the kernel stages planes in groups of three (one plane, a group and a remainder, two full groups)
+    for C, k, H, W in ((1, 5, 30, 70), (5, 9, 37, 90), (6, 17, 20, 130), (2, 17, 18, 66)):
+        x = (rng.random((C, H, W)) * 3 + 1).astype(np.float32)
+        g = orc.gaussian1D(k)
+        out = dfe.network.SpatialContrastiveNormalization(C, torch.from_numpy(g)).forward(T(x, cuda)).cpu().numpy()
+        assert np.array_equal(out, orc.contrastive_normalization(x, g)), (C, k)
     flat = np.full((3, 16, 16), 2.0, np.float32)                      # constant input: zero after the subtraction, divided by thresval
     assert float(np.abs(dfe.network.SpatialContrastiveNormalization(3, torch.from_numpy(orc.gaussian1D(5))).forward(T(flat, cuda)).cpu().numpy()).max()) < 1e-2
 
