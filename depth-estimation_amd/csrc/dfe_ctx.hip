@@ -191,6 +191,7 @@ void dfe_ctx_destroy(dfe_ctx *ctx) {
     for (const dfe_ctx::StageEvent &e : ctx->stage_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->scratch_plain) (void)hipFree(ctx->scratch_plain);
+    if (ctx->cn_coef) (void)hipFree(ctx->cn_coef);
     if (ctx->ingest) (void)hipFree(ctx->ingest);
     if (ctx->aux) (void)hipFree(ctx->aux);
     for (int i = 0; i < DFE_NSLOT; ++i) {

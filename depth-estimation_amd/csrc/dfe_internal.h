@@ -69,6 +69,12 @@ struct dfe_ctx {
     int slot_next = 0;
     void *aux = nullptr;              // grow-only side buffer for small per-call planes (the matrix-core matcher's norms): NOT the arena, whose
     size_t aux_bytes = 0;             // carved pointers a nested launcher must not invalidate
+    // nn.SpatialContrastiveNormalization's border-correction plane (the estimator of a tensor of ones): a function of the frame size, the
+    // plane count and the kernel only -- kept from call to call (filters.hip)
+    float *cn_coef = nullptr;
+    size_t cn_coef_floats = 0;
+    int cn_key[4] = {0, 0, 0, 0};     // H, W, C, k of the plane that is there (k = 0: none)
+    float cn_key_kn[33] = {};
     int *dflag = nullptr;             // one device int for error flags raised by kernels
     char err[512] = {0};
     // optional per-launch timing of the cost-volume kernel (dfe_profile_enable)

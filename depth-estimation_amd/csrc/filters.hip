@@ -457,6 +457,7 @@ struct CnFused {
     int cx[2], cy[2], cw[2], ch[2];        // crop window of out[f] (cw x ch at (cx, cy); the whole frame: 0, 0, W, H)
     int C, H, W;
     float threshold, thresval;
+    int coef_ready;                         // MODE 0: the coefficient plane (coef[0] == coef[1]) is already there
     CnKernel kk;
 };
 constexpr int CN_TW = 64, CN_TH = 16, CN_CG = 3;
@@ -562,13 +563,14 @@ __global__ __launch_bounds__(256) void cn_fused_kernel(CnFused a) {
         for (int j = 0; j < 4; ++j) {
             const int y = y0 + ty + 4 * j;
             if (y >= H) continue;
+            a.est[f][(long long)y * W + x] = s[j];
+            if (a.coef_ready || f != 0) continue;       // (one plane for both frames, kept in the ctx from call to call)
             float cf = 0.f;
             for (int c = 0; c < C; ++c)
                 for (int u = 0; u < k; ++u) {
                     const int yy = y + u - pl;
                     cf = cf + kn(u) * ((yy >= 0 && yy < H) ? ro : 0.f);
                 }
-            a.est[f][(long long)y * W + x] = s[j];
             a.coef[f][(long long)y * W + x] = cf;
         }
     } else {
@@ -607,8 +609,24 @@ int dfe_contrastive_normalization_run2(dfe_ctx *ctx, const float *in0, const flo
     const long long P = (long long)H * W;
     const int nf = in1 ? 2 : 1;
     a.in[0] = in0; a.in[1] = in1; a.out[0] = out0; a.out[1] = out1;
+    // the border-correction plane depends on (H, W, C, kernel) only: computed by the first call with these, read by every later one
+    bool same = ctx->cn_coef && ctx->cn_key[0] == H && ctx->cn_key[1] == W && ctx->cn_key[2] == C && ctx->cn_key[3] == k;
+    for (int i = 0; same && i < k; ++i) same = ctx->cn_key_kn[i] == a.kk.kn[i];
+    if (!same) {
+        if ((size_t)P > ctx->cn_coef_floats) {
+            DFE_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->cn_coef) DFE_HIP(ctx, hipFree(ctx->cn_coef));
+            ctx->cn_coef = nullptr; ctx->cn_coef_floats = 0; ctx->cn_key[3] = 0;
+            hipError_t e = hipMalloc(&ctx->cn_coef, (size_t)P * sizeof(float));
+            if (e != hipSuccess) return dfe_fail(ctx, DFE_E_ALLOC, "normalisation coefficients hipMalloc(%lld floats): %s", P, hipGetErrorString(e));
+            ctx->cn_coef_floats = (size_t)P;
+        }
+        ctx->cn_key[0] = H; ctx->cn_key[1] = W; ctx->cn_key[2] = C; ctx->cn_key[3] = k;
+        for (int i = 0; i < k; ++i) ctx->cn_key_kn[i] = a.kk.kn[i];
+    }
+    a.coef_ready = same ? 1 : 0;
     for (int f = 0; f < 2; ++f) {
-        a.coef[f] = scratch + 2 * f * P;
+        a.coef[f] = ctx->cn_coef;
         a.est[f] = scratch + (2 * f + 1) * P;
         a.cx[f] = 0; a.cy[f] = 0; a.cw[f] = W; a.ch[f] = H;
     }

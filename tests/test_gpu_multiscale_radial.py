@@ -1204,6 +1204,12 @@ def test_contrastive_normalization_equals_oracle(dfe, cuda):
         g = orc.gaussian1D(k)
         out = dfe.network.SpatialContrastiveNormalization(C, torch.from_numpy(g)).forward(T(x, cuda)).cpu().numpy()
         assert np.array_equal(out, orc.contrastive_normalization(x, g)), (C, k)
+    # the border-correction plane is kept in the ctx between calls: the same shape again (read back), then another kernel of the same size and
+    # another plane count at that size (recomputed) -- every time the oracle's result
+    for C, g in ((3, orc.gaussian1D(17)), (3, orc.gaussian1D(17)), (3, np.linspace(1, 2, 17).astype(np.float32)), (2, orc.gaussian1D(17)), (3, orc.gaussian1D(17))):
+        x = (rng.random((C, 40, 100)) * 3 + 1).astype(np.float32)
+        out = dfe.network.SpatialContrastiveNormalization(C, torch.from_numpy(g)).forward(T(x, cuda)).cpu().numpy()
+        assert np.array_equal(out, orc.contrastive_normalization(x, g))
     flat = np.full((3, 16, 16), 2.0, np.float32)                      # constant input: zero after the subtraction, divided by thresval
     assert float(np.abs(dfe.network.SpatialContrastiveNormalization(3, torch.from_numpy(orc.gaussian1D(5))).forward(T(flat, cuda)).cpu().numpy()).max()) < 1e-2
 
