@@ -16,8 +16,8 @@
 //   exact zeros to the chain.
 #include "dfe_internal.h"
 
-#ifndef DFE_CM_ROTPRIO
-#define DFE_CM_ROTPRIO 0
+#ifndef DFE_CM_STAMPS
+#define DFE_CM_STAMPS 0
 #endif
 #ifndef DFE_CM_SCHED
 #define DFE_CM_SCHED 1
@@ -104,6 +104,7 @@ struct CmBatch {
     unsigned pitch[2], plane[2];    // floats between rows / planes of in[e] (a view is allowed)
     float *nrm[2];                  // or NULL: [Ho][Wo] sum over the output planes of out^2 (the matrix-core matcher's |a|^2, |b|^2: feat_matching_mfma.hip)
     int tx[2];                      // tiles per output row
+    unsigned txm[2];                // ceil(2^32 / tx): by = (rel * txm) >> 32 on the scalar unit (exact: rel < 2^16)
     int t0[3];                      // first tile of entry e; t0[n] = number of tiles
     int n;
 };
@@ -145,20 +146,35 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
         er[j] = rem / TW; ec[j] = rem - er[j] * TW;
         ep[j] = (unsigned)i;                                        // (times the entry's plane stride at the load)
     }
+    // (everything here is wave-uniform: the multiply-high stands in for a division, which the compiler would run on the VECTOR unit even
+    //  for uniform operands -- and next to f32 MFMAs every vector instruction costs its full issue time: the matrix pipe does not run
+    //  beside it, profiles/r05_y_conv_mfma_stamps.txt)
     auto tile_geom = [&](int t, int &ent, int &x0, int &y0) {
         ent = (cb.n > 1 && t >= cb.t0[1]) ? 1 : 0;
-        const int rel = t - cb.t0[ent], by = rel / cb.tx[ent];
+        const int rel = t - cb.t0[ent], by = cb.tx[ent] == 1 ? rel : (int)__umulhi((unsigned)rel, cb.txm[ent]);   // (tx = 1: the reciprocal 2^32 has no 32-bit form)
         x0 = (rel - by * cb.tx[ent]) * TC; y0 = by * TR;
     };
     float stg[NLD];
+    unsigned eo[2][NLD];                                            // element j's offset inside a tile of entry e (floats): interior tiles need no clamp
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) eo[e][j] = ep[j] * cb.plane[e < cb.n ? e : 0] + (unsigned)er[j] * cb.pitch[e < cb.n ? e : 0] + (unsigned)ec[j];
     auto load_tile = [&](int t) {
         int ent, x0, y0;
         tile_geom(t, ent, x0, y0);
         const float *__restrict__ in = cb.in[ent];
+        if (y0 + TH <= cb.H[ent] && x0 + TW <= cb.W[ent]) {          // (uniform) the tile and its halo lie inside the frame: scalar base + the thread's offsets
+            const float *__restrict__ base = in + ((size_t)y0 * cb.pitch[ent] + x0);
 #pragma unroll
-        for (int j = 0; j < NLD; ++j)
-            if (tid + 1024 * j < TSZ)
-                stg[j] = in[(size_t)ep[j] * cb.plane[ent] + (size_t)min(y0 + er[j], cb.H[ent] - 1) * cb.pitch[ent] + min(x0 + ec[j], cb.W[ent] - 1)];
+            for (int j = 0; j < NLD; ++j)
+                if (tid + 1024 * j < TSZ) stg[j] = base[ent ? eo[1][j] : eo[0][j]];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NLD; ++j)
+                if (tid + 1024 * j < TSZ)
+                    stg[j] = in[(size_t)ep[j] * cb.plane[ent] + (size_t)min(y0 + er[j], cb.H[ent] - 1) * cb.pitch[ent] + min(x0 + ec[j], cb.W[ent] - 1)];
+        }
     };
     auto store_tile = [&](float *buf) {
 #pragma unroll
@@ -174,7 +190,12 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
     typedef float bv_t __attribute__((ext_vector_type(NT)));
     int cur = 0;
     for (; t < ntiles; t += gridDim.x) {
+#if DFE_CM_STAMPS
+        unsigned st_[5];
+        st_[0] = (unsigned)__builtin_readcyclecounter();
+#endif
         const int tn = t + gridDim.x;
+        const int nch = steps / CH;
         if (tn < ntiles && DFE_CM_ABL != 3) load_tile(tn);          // (in flight behind the step loop)
         const char *tb = reinterpret_cast<const char *>(tile0 + cur * TSZ + abase);
         f4v acc[NT];
@@ -198,10 +219,23 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
 #pragma unroll
             for (int j = 0; j < CH; ++j) { a[j] = __int_as_float(off[j]); for (int nt = 0; nt < NT; ++nt) b[j][nt] = __int_as_float(off[j] + nt); }
 #else
+#if DFE_CM_ABL == 6 || DFE_CM_ABL == 9     // A operands at immediate offsets: no address adds, no tap table
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = *reinterpret_cast<const float *>(tb + 64 * j);
+#elif DFE_CM_ABL == 8                      // no A reads at all
+#pragma unroll
+            for (int j = 0; j < CH; ++j) a[j] = __int_as_float(off[0]);
+#else
 #pragma unroll
             for (int j = 0; j < CH; ++j) a[j] = *reinterpret_cast<const float *>(tb + off[j]);
+#endif
+#if DFE_CM_ABL == 7 || DFE_CM_ABL == 9     // no B reads
+#pragma unroll
+            for (int j = 0; j < CH; ++j) for (int nt = 0; nt < NT; ++nt) b[j][nt] = __int_as_float(off[0]);
+#else
 #pragma unroll
             for (int j = 0; j < CH; ++j) b[j] = *reinterpret_cast<const bv_t *>(wp + j * 4 * 16 * NT);
+#endif
 #endif
             wp += CH * 4 * 16 * NT;
             kp += 4 * CH;
@@ -210,6 +244,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
 #if DFE_CM_ABL == 1
 #pragma unroll
             for (int j = 0; j < CH; ++j) off[j] += j;
+#elif DFE_CM_ABL == 6 || DFE_CM_ABL == 8 || DFE_CM_ABL == 9
 #else
 #pragma unroll
             for (int j = 0; j < CH; ++j) off[j] = kp[4 * j];
@@ -244,22 +279,14 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
             }
 #endif
         };
-        const int nch = steps / CH;
         taps();
         fetch(a0, b0);                                               // chunk 0
         taps();                                                      // (one chunk past the end: reads initialised LDS, never used)
+#if DFE_CM_STAMPS
+        st_[1] = (unsigned)__builtin_readcyclecounter();
+#endif
         int c = 0;
         for (; c + 2 < nch; c += 2) {                                // a0 / b0 hold chunk c
-#if DFE_CM_ROTPRIO
-            // the four waves of a SIMD (w, w + 4, w + 8, w + 12) take turns at the top issue priority, one pair of chunks each: whatever the
-            // arbiter's own order is, they now advance together and reach the tile's barrier together
-            switch (((wave >> 2) + (c >> 1)) & 3) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-            }
-#endif
             fetch(a1, b1);
             taps();
             mm(a0, b0);
@@ -276,11 +303,19 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
         } else {
             mm(a0, b0);
         }
+#if DFE_CM_STAMPS
+        asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[NT - 1][3]));   // (the accumulators are complete)
+        st_[2] = (unsigned)__builtin_readcyclecounter();
+#endif
         {
             int ent, x0, y0;
             tile_geom(t, ent, x0, y0);
             const int Ho = cb.H[ent] - kH + 1, Wo = cb.W[ent] - kW + 1;
             const int y = y0 + row, x = x0 + 16 * tsel + 4 * kq;    // D[pixel 4 kq + r][plane = lane & 15]
+            // (row, tsel, y and the tile's origin are wave-uniform: the output's base address is scalar arithmetic, a lane adds its plane and
+            //  its four pixels as ONE 32-bit offset)
+            const size_t obase = (size_t)y * Wo + (size_t)(x0 + 16 * tsel);
+            const unsigned HoWo = (unsigned)Ho * (unsigned)Wo;
             if (cb.nrm[ent]) {
                 // the pixels' squared norms over the output planes, for the matcher that follows: this lane's planes first, then the 16 lanes
                 // of its DPP row (partners at distance 8, 4, 2, 1); one lane per four pixels stores them
@@ -296,7 +331,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sq[q] = row16_sum_f32_ordered(sq[q]);
                 if (m == 0 && y < Ho) {
-                    float *o = cb.nrm[ent] + (size_t)y * Wo + x;
+                    float *o = cb.nrm[ent] + obase + 4u * (unsigned)kq;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (x + q < Wo) o[q] = sq[q];
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
                 for (int nt = 0; nt < NT; ++nt) {
                     const int plane = nt * 16 + m;
                     if (plane >= nOut) continue;
-                    float *o = cb.out[ent] + ((size_t)plane * Ho + y) * Wo + x;
+                    float *o = cb.out[ent] + obase + ((unsigned)plane * HoWo + 4u * (unsigned)kq);
                     f4v r = acc[nt];
                     if constexpr (TANH) r = f4v{tanhf(r[0]), tanhf(r[1]), tanhf(r[2]), tanhf(r[3])};
                     if (x + 3 < Wo && !(((uintptr_t)o) & 15)) *reinterpret_cast<f4v *>(o) = r;
@@ -322,8 +357,21 @@ __global__ __launch_bounds__(1024) void conv_mfma_res_kernel(CmBatch cb, const f
         if (tn < ntiles && DFE_CM_ABL != 3) store_tile(tile0 + (cur ^ 1) * TSZ);
         // LDS-only barrier: __syncthreads() also drains vmcnt, i.e. every wave would wait here until the tile's output stores are
         // acknowledged by the memory -- with nothing on the matrix pipe meanwhile
+#if DFE_CM_STAMPS
+        st_[3] = (unsigned)__builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         cur ^= 1;
+#if DFE_CM_STAMPS
+        st_[4] = (unsigned)__builtin_readcyclecounter();
+        {
+            const int it = (t - (int)blockIdx.x) / (int)gridDim.x;
+            if (blockIdx.x == 3 && lane == 0 && it < 8) {
+                unsigned *dbg = reinterpret_cast<unsigned *>(cb.out[0]);
+                for (int q = 0; q < 5; ++q) dbg[(it * 16 + wave) * 5 + q] = st_[q];
+            }
+        }
+#endif
     }
 }
 
@@ -350,6 +398,8 @@ int dfe_conv_mfma_res_batch(dfe_ctx *ctx, int n, const float *const *in, const i
         cb.in[e] = in[e]; cb.out[e] = out[e]; cb.H[e] = H[e]; cb.W[e] = W[e]; cb.pitch[e] = (unsigned)pit; cb.plane[e] = (unsigned)pla;
         cb.nrm[e] = nrm ? nrm[e] : nullptr;
         cb.tx[e] = dfe_cdiv(W[e] - L.kW + 1, 64);
+        cb.txm[e] = cb.tx[e] == 1 ? 0u : (unsigned)(((1ull << 32) + cb.tx[e] - 1) / cb.tx[e]);
+        if ((long long)cb.tx[e] * dfe_cdiv(H[e] - L.kH + 1, 4) >= 65536) return DFE_OK;   // (the kernel's multiply-high division is exact below that)
         cb.t0[e] = nt;
         nt += cb.tx[e] * dfe_cdiv(H[e] - L.kH + 1, 4);
     }
