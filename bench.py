@@ -678,8 +678,9 @@ def main_learned_single(args, world, rank, local_rank, dev, torch, dist, d, rp):
             mfma = {"bound": "mfma", "kernel": "conv_mfma_res_kernel + fmm_kernel+argmin", "kernel_ms": round(both_s * 1e3, 5), "launches_timed": n.value,
                     "achieved": round((conv_fl + fm_fl) / both_s / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round((conv_fl + fm_fl) / both_s / 157.3e12, 4),
                     "traffic": None, "flops_per_step": conv_fl + fm_fl,
-                    "note": "executed f32 MFMA flops (tap padding and the band's unused tile halves included) of both kernels over their summed time; the matrix "
-                            "cores hold ~1.6-1.7 GHz in these loops, i.e. ~105 TFLOP/s is what the pipe delivers when it never waits"}
+                    "note": "executed f32 MFMA flops (tap padding and the band's unused tile halves included) of both kernels over their summed time; the pipe "
+                            "by itself delivers 155 TFLOP/s (tools/ubench/mfma_rate.hip), but every vector instruction of a wave -- operand addresses, the "
+                            "arg-min epilogue -- adds its issue time: the f32 matrix pipe does not run beside the vector ALU (DESIGN 4.17)"}
         print(json.dumps({
             "metric": "Mpixels/s dense flow, %dx%d pair, learned single-scale model (%s), %dx%d window" % (
                 W, H, "tests/time_matching.lua" if tm else "opticalflow_model.lua getModel + processOutput" if nk < 0 else "version2/network.lua", win, win),

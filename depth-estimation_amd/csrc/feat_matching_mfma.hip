@@ -175,17 +175,17 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
         // outside the band never win a minimum and need no mask either.
         const float na_i = p.na[(long long)min(y, p.H1 - 1) * p.W1 + min(x0 + j, p.W1 - 1)];   // (A operand of the extra step: pixel i = lane & 15)
         f4v acc[MH][2];
-        {
-            f4v pen0, pen1;
+        f4v pen[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * q + r;
-                pen0[r] = j - i >= 0 ? 0.f : __int_as_float(0x7f800000);
-                pen1[r] = 16 + j - i < MW ? 0.f : __int_as_float(0x7f800000);
-            }
-#pragma unroll
-            for (int dy = 0; dy < MH; ++dy) { acc[dy][0] = pen0; acc[dy][1] = pen1; }
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * q + r;
+            pen[0][r] = j - i >= 0 ? 0.f : __int_as_float(0x7f800000);
+            pen[1][r] = 16 + j - i < MW ? 0.f : __int_as_float(0x7f800000);
         }
+        // (tried: the two penalty vectors as the C operand of the tile's first MFMAs instead of 136 register copies -- the second copy of the
+        //  k-step's code that needs cost the allocator 120 B of scratch: 130 -> 168 us)
+#pragma unroll
+        for (int dy = 0; dy < MH; ++dy) { acc[dy][0] = pen[0]; acc[dy][1] = pen[1]; }
         for (int sg = 0; sg < nstages; ++sg, ++gs) {
             {   // the next stage -- of this tile, or stage 0 of the next one -- in flight behind this stage's MFMAs
                 const bool same = sg + 1 < nstages;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) mn[r] = fminf(mn[r], acc[dy][tl][r]);
+                    for (int r = 0; r < 4; ++r) mn[r] = fminf(mn[r], acc[dy][tl][r]);   // (the compiler's mix of v_min / v_min3 is the fastest of three forms tried)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #define FMM_STEP(ctrl) mn[r] = fminf(mn[r], __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mn[r]), ctrl, 0xf, 0xf, false)));
