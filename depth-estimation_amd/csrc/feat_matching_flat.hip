@@ -80,6 +80,10 @@ struct FfArgs {
     float *full, *full_conf, *scores;  // [2][hFull][wFull] (plane 0 = y), [hFull][wFull], [H1][W1]; each may be NULL (idx above: [H1][W1])
 };
 enum { FF_VOLUME = 0, FF_ARGMIN = 1, FF_SOFT = 2 };
+#ifndef DFE_FF_SOFT_FAST
+#define DFE_FF_SOFT_FAST 1
+#endif
+constexpr float FF_TIE = 1e-6f;   // FF_SOFT without a threshold: cells this close to a window's minimum may share its maximal probability
 
 template <int MW> struct FfGeom {
     static constexpr int PITCH = (64 * FF_PX + 2 * (MW - 1) + 8 + 3) / 4 * 4;   // floats per LDS tile row (piece A | piece B)
@@ -502,6 +506,38 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                         }
                     }
                     m = row16_max_f32(m);
+                    const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
+                    const bool live = g0 + ll < p.NG && xg + q < p.W1;
+                    long long id = 0;
+                    float score = 0.f, conf = 1.f;
+                    // Without a threshold only the arg-max of the probabilities leaves the kernel.  p = e * (1 / sum) with e = exp2((cmin - c) log2 e):
+                    // the largest e is exactly 1 (the minimum's), and a cell more than FF_TIE above the minimum has e <= 1 - 2^-20, whose product
+                    // with 1 / sum rounds strictly below 1 / sum.  So a window with ONE cell within FF_TIE of its minimum has that cell as its only
+                    // maximal probability whatever the sum is -- no exponential, no sum, no division: 3 instead of 12 vector instructions per cell.
+                    // Windows with several such cells (flat regions, exact ties) take the full arithmetic below, wave by wave: same results.
+                    bool full = p.use_thr != 0;
+                    int fi = 0x7fffffff;
+                    if (!full && DFE_FF_SOFT_FAST) {
+                        const float lim = FF_TIE - m;                     // (m = max(-c) = -cmin)
+                        int cnt = 0;
+#pragma unroll
+                        for (int j = NJ4 - 1; j >= 0; --j)
+#pragma unroll
+                            for (int i = 3; i >= 0; --i) {
+                                const bool on = 64 * j + 4 * t + i < WN && v[4 * j + i] <= lim;
+                                cnt += on ? 1 : 0;
+                                fi = on ? 64 * j + 4 * t + i : fi;
+                            }
+#define FF_STEP(ctrl) cnt += __builtin_amdgcn_update_dpp(0, cnt, ctrl, 0xf, 0xf, false); fi = min(fi, __builtin_amdgcn_update_dpp(0, fi, ctrl, 0xf, 0xf, false));
+                        FF_STEP(0x128) FF_STEP(0x124) FF_STEP(0x4E) FF_STEP(0xB1)
+#undef FF_STEP
+                        full = __builtin_amdgcn_ballot_w64(cnt != 1) != 0;    // (wave-uniform)
+                    } else {
+                        full = true;
+                    }
+                    if (!full) {
+                        id = (long long)fi + 1;
+                    } else {
                     float s = 0.f;
 #pragma unroll
                     for (int j = 0; j < NJ4; ++j)
@@ -516,10 +552,6 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                     const float inv = 1.0f / s;
 #pragma unroll
                     for (int n = 0; n < 4 * NJ4; ++n) v[n] = v[n] * inv;   // (cells beyond the window: 0 * inv = 0, below every probability's use)
-                    const int xg = ll >= nA ? (ll - nA) * PX : xA0 + ll * PX;
-                    const bool live = g0 + ll < p.NG && xg + q < p.W1;
-                    long long id;
-                    float score = 0.f, conf = 1.f;
                     if (!p.use_thr) {
                         // input:max(3), first maximum; where it equals the centre cell's probability the index is the centre's (:156-160)
                         float b = v[0];
@@ -574,6 +606,7 @@ __global__ __launch_bounds__(1024) void feat_matching_flat_kernel(FfArgs p) {
                             score = (float)a;
                         }
                         conf = score > p.thr ? 1.f : 0.f;                  // scores:gt(threshold)
+                    }
                     }
                     if (live && t == 0) {
                         const int py = y_first + (ll >= nA ? 1 : 0), pxc = xg + q;

@@ -222,3 +222,44 @@ def test_sequential_runs_convolution_and_tanh_as_one_launch(dfe, cuda):
     assert all(torch.equal(a, b) for a, b in zip(res[True][2], res[False][2]))
     layers = [dict(weight=m.weight.cpu().numpy(), bias=m.bias.cpu().numpy(), tanh=i < 2) for i, m in enumerate(filt.modules[::2])]
     assert np.allclose(res[True][0].cpu().numpy(), rp.filter_stack_oracle(x.cpu().numpy(), layers), rtol=0, atol=2e-6)
+
+
+def test_single_scale_unique_minimum_fast_path_and_its_ties(dfe, cuda):
+    """The soft-max epilogue without a threshold skips the exponentials for windows whose minimum is alone within 1e-6 (FF_TIE): planted
+    windows with TWO exactly equal minima (a feature patch repeated at two displacements), with a second cell a few 1e-7 above the minimum
+    (inside the band: the full arithmetic decides) and a few 1e-5 above it (outside: the fast path), all inside waves whose other windows
+    are ordinary -- index, flow and full planes equal the staged modules' bit for bit, and the volume says which case each pixel is."""
+    rng = np.random.default_rng(17)
+    K, mh, mw, H1, W1 = 6, 16, 16, 40, 300
+    H2, W2 = H1 + mh - 1, W1 + mw - 1
+    geo = dict(layers=[[3, 1, 1, K]], maxh=mh, maxw=mw, multiscale=False, output_extraction_method="max", hImg=H2, wImg=W2, prefilter=True)
+    b = (rng.standard_normal((K, H2, W2)) * 2).astype(np.float32)
+    a_full = (rng.standard_normal((K, H2, W2)) * 2).astype(np.float32)
+    ny, nx = (mh + 1) // 2 - 1, (mw + 1) // 2 - 1                  # prepareInput's narrow: patch 1 = a_full[:, ny : ny + H1, nx : nx + W1]
+    a = a_full[:, ny : ny + H1, nx : nx + W1]
+    # rows 5..9: patch 1 is a copy of in2 shifted by (3, 4) -> cost 0 at one cell; rows 12..16: in2 carries that patch at (3, 4) AND (9, 11)
+    a[:, 5:10] = b[:, 5 + 3 : 10 + 3, 4 : 4 + W1]
+    b[:, 12 + 9 : 17 + 9, 11 : 11 + 200] = b[:, 12 + 3 : 17 + 3, 4 : 4 + 200]
+    a[:, 12:17, :200] = b[:, 12 + 3 : 17 + 3, 4 : 4 + 200]
+    # rows 20..24: the second copy perturbed so that its cost is a few 1e-7; rows 28..32: a few 1e-5
+    for r0, eps in ((20, 1.5e-4), (28, 1.5e-3)):
+        b[:, r0 + 9 : r0 + 5 + 9, 11 : 11 + 200] = b[:, r0 + 3 : r0 + 5 + 3, 4 : 4 + 200]
+        b[0, r0 + 9 : r0 + 5 + 9, 11 : 11 + 200] += np.float32(eps)
+        a[:, r0 : r0 + 5, :200] = b[:, r0 + 3 : r0 + 5 + 3, 4 : 4 + 200]
+    model = dfe.getModel(geo, True, True)
+    ctx = dfe.get_ctx(0)
+    ta, tb = T(a_full, cuda), T(b, cuda)
+    one = model.forwardFlow([ta, tb], None, one_call=True)
+    assert ctx.last_kernel() == "feat_matching_flat_kernel+softmax"
+    stg = model.forwardFlow([ta, tb], None, one_call=False)
+    _same(one, stg, None)
+    vol = orc.spatial_matching(np.ascontiguousarray(a), b, mh, mw).reshape(H1, W1, -1)
+    srt = np.sort(vol, axis=2)
+    gap = srt[..., 1] - srt[..., 0]
+    assert (gap[12:17, :200] == 0).all() and (gap[5:10] > 1e-3).all()                       # exact ties / a lone minimum
+    assert ((gap[20:25, :200] > 0) & (gap[20:25, :200] < 1e-6)).mean() > 0.9                # inside the band
+    assert (gap[28:33, :200] > 1e-6).all() and (gap[28:33, :200] < 1e-4).mean() > 0.9       # just outside it
+    idx = one["index"].cpu().numpy()
+    assert (idx[5:10] == 3 * mw + 4 + 1).all()
+    assert (idx[12:17, :200] == 3 * mw + 4 + 1).all()                                       # the first of two equal maxima
+    assert (idx[28:33, :200] == 3 * mw + 4 + 1).all()
