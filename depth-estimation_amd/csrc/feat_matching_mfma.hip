@@ -7,8 +7,8 @@
 // two 16 x 16 tiles; the window's 17 cells of a pixel are the band dx = x' - x in [0, 17) of them (272 of 512 products used: the
 // price of a dense tile on a banded problem).  K = 32: 16 MFMAs per (16 pixels, dy), 4.6 M per VGA pair = 60 us of matrix-core time
 // against the 120 us the vector form needs at its best.
-// NUMERICS: the cost is ONE k-ordered fmaf chain of the MFMA over (-2 a_k) b_k, k < K, then |a|^2 * 1 and 1 * |b|^2 (the norms summed in
-// fp32 by fmm_norm_kernel ride in the GEMM as an extra k-step).  It differs from the exact sum of squared differences by cancellation: about 1e-7 (|a|^2 + |b|^2) absolute,
+// NUMERICS: the cost is ONE fmaf chain of the MFMA: |a|^2 * 1 and 1 * |b|^2 first (the norms, summed in fp32 by fmm_norm_kernel or by the
+// convolution's epilogue, ride in the GEMM as an extra k-step), then (-2 a_k) b_k in k order.  It differs from the exact sum of squared differences by cancellation: about 1e-7 (|a|^2 + |b|^2) absolute,
 // i.e. the relative error of a SMALL cost (a good match) is larger than that of the exact kernel.  Tolerance as tested
 // (tests/test_gpu_matcher_full.py): |c - exact| <= 1e-5 |exact| + 1e-6 max|exact|; arg-min equal except where the two best exact
 // costs lie within that band.  The exact kernels stay the default.
@@ -182,10 +182,21 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
             pen[0][r] = j - i >= 0 ? 0.f : __int_as_float(0x7f800000);
             pen[1][r] = 16 + j - i < MW ? 0.f : __int_as_float(0x7f800000);
         }
-        // (tried: the two penalty vectors as the C operand of the tile's first MFMAs instead of 136 register copies -- the second copy of the
-        //  k-step's code that needs cost the allocator 120 B of scratch: 130 -> 168 us)
+        // ---- the norms' k-step FIRST, with the band penalties as its C operand: lane (i or j, kq): A = (|a_i|^2, 1, 0, 0)[kq],
+        // B = (1, |b|^2, 0, 0)[kq]; the accumulators start as pen + |a|^2 + |b|^2 without 136 register copies (next to f32 MFMAs a vector
+        // instruction is not free).  (The norms of this tile's in2 pixels came with its stage 0, complete behind the last barrier.)
+        {
+            const float *nbw = nbt + wave * 32 + j;
+            const float m0 = kq == 0 ? 1.f : 0.f, m1 = kq == 1 ? 1.f : 0.f;
+            const float a = kq == 0 ? na_i : m1;
+            float b[MH][2];
 #pragma unroll
-        for (int dy = 0; dy < MH; ++dy) { acc[dy][0] = pen[0]; acc[dy][1] = pen[1]; }
+            for (int dy = 0; dy < MH; ++dy) { b[dy][0] = fmaf(m1, nbw[dy * 32], m0); b[dy][1] = fmaf(m1, nbw[dy * 32 + 16], m0); }
+#pragma unroll
+            for (int dy = 0; dy < MH; ++dy)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) acc[dy][tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[dy][tl], pen[tl], 0, 0, 0);
+        }
         for (int sg = 0; sg < nstages; ++sg, ++gs) {
             {   // the next stage -- of this tile, or stage 0 of the next one -- in flight behind this stage's MFMAs
                 const bool same = sg + 1 < nstages;
@@ -248,19 +259,6 @@ __global__ __launch_bounds__(FMM_T) void fmm_kernel(FmmArgs p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // my requests of the next stage have landed; behind the barrier everyone's have
             __syncthreads();
-        }
-        // ---- the norms' k-step: lane (i or j, kq): A = (|a_i|^2, 1, 0, 0)[kq], B = (1, |b|^2, 0, 0)[kq]
-        const float *nbw = nbt + wave * 32 + j;
-        {
-            const float m0 = kq == 0 ? 1.f : 0.f, m1 = kq == 1 ? 1.f : 0.f;
-            const float a = kq == 0 ? na_i : m1;
-            float b[MH][2];
-#pragma unroll
-            for (int dy = 0; dy < MH; ++dy) { b[dy][0] = fmaf(m1, nbw[dy * 32], m0); b[dy][1] = fmaf(m1, nbw[dy * 32 + 16], m0); }
-#pragma unroll
-            for (int dy = 0; dy < MH; ++dy)
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) acc[dy][tl] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[dy][tl], acc[dy][tl], 0, 0, 0);
         }
         // ---- epilogue: lane (q = kq, j) holds the costs of pixels i = 4 q + r against column j of every (dy, tile)
         if constexpr (ARGMIN) {
